@@ -1,0 +1,168 @@
+/* maest_hip.h -- C ABI of libmaest_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * MAEST mel-spectrogram -> patchout-ViT hot path.
+ *
+ * The reference (palonso/MAEST) is pure Python with NO plugin / operator / FFI interface: its
+ * boundary for this path is the Python API get_maest() / MAEST.forward() / predict_labels() /
+ * Module.training_step() (models/maest.py:1467-1569, 831-939; models/module.py:73-102), and every
+ * tensor op underneath is a stock torch / torchaudio call.  This header therefore declares the
+ * entry points that the drop-in Python package (maest_amd/, same API as the reference) binds with
+ * ctypes; each one cites the reference call site whose library op it replaces.
+ *
+ * Conventions
+ *  - Every function returns int status: 0 = MAEST_OK; non-zero -> maest_last_error() has the text.
+ *  - All tensor arguments are CALLER-OWNED DEVICE pointers (e.g. torch.Tensor.data_ptr()), row-major,
+ *    with explicit sizes / leading dimensions in ELEMENTS.  The library never allocates, frees or
+ *    retains memory and never synchronises: work is enqueued on `stream` (a hipStream_t passed as
+ *    void*; NULL = the null stream), so every entry point is hipGraph-capturable.
+ *  - dtype codes: MAEST_F32 (fp32, "parity mode": exact-fp32 MFMA) and MAEST_BF16 (bf16 operands,
+ *    fp32 accumulate, "perf mode").  The residual stream, LayerNorm statistics, softmax statistics,
+ *    logits and all parameter gradients are fp32 in both modes.
+ *  - No torch types, no C++ types: plain pointers and integers only.
+ */
+#ifndef MAEST_HIP_H
+#define MAEST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAEST_ABI_VERSION 1
+
+#define MAEST_OK 0
+#define MAEST_ERR_INVALID 1 /* bad argument (shape / alignment / dtype) */
+#define MAEST_ERR_LAUNCH 2  /* HIP launch failure */
+
+#define MAEST_F32 0
+#define MAEST_BF16 1
+
+/* GEMM epilogues */
+#define MAEST_EPI_NONE 0     /* C = acc + bias                                           */
+#define MAEST_EPI_GELU 1     /* aux_out = acc + bias (optional) ; C = gelu_erf(acc+bias) */
+#define MAEST_EPI_RESIDUAL 2 /* C(fp32) = acc + bias + aux_in(fp32)                      */
+#define MAEST_EPI_DGELU 3    /* C = acc * gelu_erf'(aux_in)     (aux_in in out_dtype)    */
+#define MAEST_EPI_ATOMIC 4   /* C(fp32) += acc   (split-K accumulate, C pre-zeroed)      */
+
+int maest_version(void);
+const char* maest_last_error(void);
+
+/* ---- K8, K10-K12, K13 head, K4 (im2col form) and their dgrad / wgrad ---------------------------
+ * nn.Linear: models/maest.py:353,355,361,376 ; :197-199,203-206 ; :572,579 ; nn.Conv2d :238-240.
+ *   C[M,N] = epilogue( sum_k A[m,k] * B[n,k] )      A:[M,K] lda, B:[N,K] ldb (both k-contiguous)
+ * in_dtype = dtype of A and B; out_dtype = dtype of C / aux_out (and aux_in for DGELU).
+ * K must be a multiple of 64 (bf16) / 32 (fp32): callers zero-pad.  bias: fp32 [N] or NULL. */
+int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int in_dtype,
+                  void* C, int64_t ldc, int out_dtype, int M, int N, int K,
+                  const float* bias, int epi, const void* aux_in, void* aux_out, int64_t ld_aux,
+                  int split_k, void* stream);
+
+/* ---- 2-D transpose with zero padding: dst[c, r] = src[r, c], dst rows padded to ld_dst ----------
+ * (operand preparation for the wgrad GEMMs: dW = dY^T X needs both operands token-contiguous). */
+int maest_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols,
+                    int dtype, void* stream);
+
+/* ---- fp32 -> bf16 cast of parameters, optionally also emitting the transpose ---------------------
+ * dst[r,c] = bf16(src[r,c]) ; dst_t[c,r] = bf16(src[r,c]) (dst / dst_t may be NULL).
+ * With dtype == MAEST_F32 it is a plain copy / transpose (parity mode). */
+int maest_cast_weights(const float* src, void* dst, void* dst_t, int rows, int cols, int dtype,
+                       void* stream);
+
+/* ---- K7 LayerNorm over the last dim (nn.LayerNorm: models/maest.py:395,405,499,553,571) ---------
+ * x: fp32 [rows, cols] (ldx); y: y_dtype [rows, cols] (ldy); mean/rstd: fp32 [rows] or NULL.
+ * cols must be 768. */
+int maest_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                        int64_t ldy, int y_dtype, float* mean, float* rstd, int rows, int cols,
+                        float eps, void* stream);
+/* dx_out[r,:] = dres[r,:] (may be NULL) + LN'(dy)[r,:]   (fp32), plus an optional copy of dx_out in
+ * `dx_lp_dtype` (operand of the next dgrad GEMM).  dgamma/dbeta (fp32 [cols]) are ACCUMULATED
+ * (atomics) -- zero them first. */
+int maest_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const float* x, int64_t ldx,
+                        const float* gamma, const float* mean, const float* rstd,
+                        const float* dres, float* dx_out, void* dx_lp, int dx_lp_dtype,
+                        float* dgamma, float* dbeta, int rows, int cols, void* stream);
+
+/* ---- K9 fused softmax attention (Attention.forward: models/maest.py:362-375) ---------------------
+ * qkv: [B*N, 2304] with column = s*768 + h*64 + d  (s = 0,1,2 for q,k,v), exactly the layout the
+ * reference's qkv Linear produces before its reshape/permute (:362-363).
+ * out: [B*N, 768] (column = h*64 + d), i.e. the reference's (attn @ v).transpose(1,2).reshape(B,N,C).
+ * lse: fp32 [B, 12, N] log-sum-exp of the scaled scores (saved for backward) or NULL. */
+int maest_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int dtype, float scale,
+                   void* stream);
+/* delta: fp32 [B,12,N] workspace (rowsum(dO*O)); dqkv: [B*N, 2304] same layout as qkv. */
+int maest_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                   float* delta, void* dqkv, int B, int N, int dtype, float scale, void* stream);
+
+/* ---- K16 + K4 operand: mixup + im2col of the 16x16 / stride-10 patches ---------------------------
+ * PatchEmbed.forward (models/maest.py:243-256) fused with Module.training_step's mixup
+ * (models/module.py:77-83) and with the structured-patchout column selection (models/maest.py:684-687:
+ * dropped time columns are never computed -- mathematically identical).
+ * x: fp32 [B, F, T]; perm: int32 [B] or NULL; lam: fp32 [B] or NULL (x' = lam*x + (1-lam)*x[perm]).
+ * t_idx: int32 [Tk] kept patch columns (sorted) or NULL (= all T' columns).
+ * out: dtype [B*Fp*Tk, 256], row = b*Fp*Tk + f*Tk + tk, col = ky*16 + kx. */
+int maest_patch_im2col(const float* x, int B, int F, int T, const int32_t* perm, const float* lam,
+                       const int32_t* t_idx, int Fp, int Tk, void* out, int dtype, void* stream);
+
+/* ---- K5 + K6: positional add + token assembly (models/maest.py:645-675, 769, 785-796) ------------
+ * patches: fp32 [B*Fp*Tk, 768] (conv output incl. bias); x0: fp32 [B, 2 + Fp*Tk, 768]
+ *   x0[b,0] = cls + new_pos[0]; x0[b,1] = dist + new_pos[1];
+ *   x0[b, 2 + f*Tk + tk] = patches[...] + time_pos[:, toffset + t_idx[tk]] + freq_pos[:, f]
+ * time_pos: fp32 [768, Tt]; freq_pos: fp32 [768, Fp]. */
+int maest_token_assemble(const float* patches, const float* cls_token, const float* dist_token,
+                         const float* new_pos, const float* freq_pos, const float* time_pos,
+                         int Tt, int toffset, const int32_t* t_idx, int B, int Fp, int Tk, float* x0,
+                         void* stream);
+/* Backward of the above: dx0 fp32 [B, N, 768] -> dpatches (dtype, [B*Fp*Tk, 768]) and ACCUMULATED
+ * fp32 grads d_cls[768], d_dist[768], d_new_pos[2,768], d_freq_pos[768,Fp], d_time_pos[768,Tt]. */
+int maest_token_assemble_bwd(const float* dx0, int B, int Fp, int Tk, int Tt, int toffset,
+                             const int32_t* t_idx, void* dpatches, int dtype, float* d_cls,
+                             float* d_dist, float* d_new_pos, float* d_freq_pos, float* d_time_pos,
+                             void* stream);
+
+/* ---- K13 / K14: final LayerNorm on the cls/dist tokens + feature pooling -------------------------
+ * models/maest.py:806-810, 905-906: xn = LN_eps(x)[:, 0:2]; cls = xn[:,0]; dist = xn[:,1];
+ * feat = (cls + dist)/2.   x: fp32 [B, N, 768].  Outputs fp32 [B,768] each; mean/rstd fp32 [B,2]. */
+int maest_head_pool_fwd(const float* x, int B, int N, const float* gamma, const float* beta, float eps,
+                        float* cls, float* dist, float* feat, float* mean, float* rstd, void* stream);
+/* d_cls_total = d_cls + d_feat/2 (either may be NULL), same for dist; writes dx fp32 [B,N,768]
+ * rows 0,1 (all other rows are ZEROED), accumulates dgamma/dbeta. */
+int maest_head_pool_bwd(const float* d_cls, const float* d_dist, const float* d_feat, const float* x,
+                        int B, int N, const float* gamma, const float* mean, const float* rstd,
+                        float* dx, float* dgamma, float* dbeta, void* stream);
+/* early-exit embedding (models/maest.py:825-829): emb[b] = cat(x[b,0], x[b,1], mean(x[b,2:], 0)) */
+int maest_embed_pool(const float* x, int B, int N, float* emb, void* stream);
+
+/* ---- K18: BCE-with-logits, mean reduction (models/module.py:90, 299-301) ------------------------
+ * loss (fp32 scalar, ACCUMULATED: zero it first) += weight * mean(max(z,0) - z*y + log1p(exp(-|z|)))
+ * dlogits = weight * (sigmoid(z) - y) / (rows*cols)  (or NULL).
+ * Optional fused label mixup: y' = lam[b]*y[b] + (1-lam[b])*y[perm[b]]. */
+int maest_bce_logits(const float* z, const float* y, const int32_t* perm, const float* lam, int rows,
+                     int cols, float weight, float* loss, float* dlogits, void* stream);
+
+/* ---- K15: predict_labels tail (models/maest.py:936-938): act[c] = mean_b sigmoid(z[b,c]) */
+int maest_sigmoid_mean(const float* z, int rows, int cols, float* act, void* stream);
+
+/* ---- column sums (bias gradients): out[c] += sum_r src[r,c]  (fp32 out, ACCUMULATED) */
+int maest_colsum(const void* src, int64_t ld, int rows, int cols, int dtype, float* out, void* stream);
+
+/* ---- K17 SpecMasking on explicit stripes (helpers/spec_masking.py:27-33): zero x[b,:,s:s+w] for the
+ * time stripes and x[b,s:s+w,:] for the frequency stripes.  stripes: int32 [B, n, 2] (start,width). */
+int maest_spec_mask(float* x, int B, int F, int T, const int32_t* t_stripes, int n_t,
+                    const int32_t* f_stripes, int n_f, void* stream);
+
+/* ---- K1-K3 fused log-mel front end (models/helpers/melspectrogram.py:47-60) -----------------------
+ * wave: fp32 [B, S]; out: fp32 [B, 96, T] with T = 1 + S/256.  window: fp32 [512] periodic Hann;
+ * fb_start/fb_len: int32 [96] first FFT bin and number of non-zero taps of each mel band;
+ * fb_w: fp32 [96, fb_stride] tap weights; twiddle: fp32 [512, 2] = (re, im) of exp(-2*pi*i*k/512).
+ * out = (log10(1 + log_scale * mel) - norm_mean) / norm_2std.  Requires S > 256 (reflect padding). */
+int maest_logmel(const float* wave, int B, int S, const float* window, const float* twiddle,
+                 const int32_t* fb_start, const int32_t* fb_len, const float* fb_w, int fb_stride,
+                 float log_scale, float norm_mean, float norm_2std, float* out, void* stream);
+
+/* ---- optimizer-side helper: scale a flat fp32 gradient bucket (after the RCCL all-reduce) */
+int maest_scale_f32(float* x, int64_t n, float alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAEST_HIP_H */

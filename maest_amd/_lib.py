@@ -1,0 +1,103 @@
+"""ctypes binding of libmaest_hip.so (C ABI: include/maest_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or a tensor that is not
+on a HIP device reaches a kernel wrapper, an exception is raised.  (``_testing_override`` exists
+so that tests/emu can run the same kernel sources under the host SIMT emulator; nothing in the
+package calls it.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmaest_hip.so")
+
+F32 = 0
+BF16 = 1
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_ATOMIC = 0, 1, 2, 3, 4
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes, in the order of include/maest_hip.h
+SIGNATURES = {
+    "maest_gemm_nt": [_P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _I, _P, _P, _L, _I, _P],
+    "maest_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
+    "maest_cast_weights": [_P, _P, _P, _I, _I, _I, _P],
+    "maest_layernorm_fwd": [_P, _L, _P, _P, _P, _L, _I, _P, _P, _I, _I, _F, _P],
+    "maest_layernorm_bwd": [_P, _L, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
+    "maest_attn_fwd": [_P, _P, _P, _I, _I, _I, _F, _P],
+    "maest_attn_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "maest_patch_im2col": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _P],
+    "maest_token_assemble": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P],
+    "maest_token_assemble_bwd": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P],
+    "maest_head_pool_fwd": [_P, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P],
+    "maest_head_pool_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "maest_embed_pool": [_P, _I, _I, _P, _P],
+    "maest_bce_logits": [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P],
+    "maest_sigmoid_mean": [_P, _I, _I, _P, _P],
+    "maest_colsum": [_P, _L, _I, _I, _I, _P, _P],
+    "maest_spec_mask": [_P, _I, _I, _I, _P, _I, _P, _I, _P],
+    "maest_logmel": [_P, _I, _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _P],
+    "maest_scale_f32": [_P, _L, _F, _P],
+}
+
+_lib = None
+_host_emulation = False  # set only by tests/emu
+
+
+class MaestHipError(RuntimeError):
+    pass
+
+
+def _bind(lib):
+    lib.maest_version.restype = c_int
+    lib.maest_version.argtypes = []
+    lib.maest_last_error.restype = c_char_p
+    lib.maest_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = c_int
+        fn.argtypes = argtypes
+    return lib
+
+
+def load():
+    """Load (once) and return the bound library; raise loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MaestHipError(
+                f"{LIB_PATH} not found: the MI355X kernels are not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "maest_amd has no CPU fallback.")
+        _lib = _bind(ctypes.CDLL(LIB_PATH))
+        if _lib.maest_version() != 1:
+            raise MaestHipError("libmaest_hip.so ABI version mismatch")
+    return _lib
+
+
+def _testing_override(path):
+    """tests/emu only: bind a host-emulation build of the same sources."""
+    global _lib, _host_emulation
+    _lib = _bind(ctypes.CDLL(path))
+    _host_emulation = True
+    return _lib
+
+
+def _testing_restore():
+    global _lib, _host_emulation
+    _lib = None
+    _host_emulation = False
+
+
+def host_emulation():
+    return _host_emulation
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise MaestHipError(f"{name} failed (status {rc}): {lib.maest_last_error().decode()}")

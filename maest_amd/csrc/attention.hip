@@ -1,0 +1,510 @@
+// Fused softmax attention, forward and backward, for the MAEST ViT blocks
+// (reference: Attention.forward, models/maest.py:358-378 -- qkv reshape/permute :362-364,
+//  (q @ k^T) * scale :371, softmax :372, attn @ v :375; backward = autograd of the same).
+//
+// Layout contract (no head-major copies anywhere): q/k/v are read in place from the qkv Linear's
+// output [B*N, 2304] (column = s*768 + head*64 + d) and the result is written as [B*N, 768]
+// (column = head*64 + d), which IS the reference's (attn @ v).transpose(1, 2).reshape(B, N, C).
+//
+// MFMA scheme (wave64, 32x32 tiles, head_dim = 64).  A 32x32 MFMA leaves D with lane <-> column and
+// registers <-> rows; such a D can be fed back, register-for-register, as the B operand of a second
+// MFMA whose reduction runs over D's ROW index, provided the A operand is read with the same
+// row permutation from a TRANSPOSED LDS tile (common.h: acc_to_chunk / read_transposed_chunk).
+// Hence, with "^T" meaning "keys/queries on the D-row axis":
+//   forward   S^T = K Q^T            -> softmax stats are per lane (lane = query)
+//             O^T = V^T P^T          (A = V^T tile in LDS, B = P^T registers)
+//   dK/dV     S   = Q K^T, dP = dO V^T   (lane = key), dV^T = dO^T P, dK^T = Q^T dS
+//   dQ        S^T = K Q^T, dP^T = V dO^T (lane = query), dQ^T = K^T dS^T
+// so the probability tile never leaves registers and no cross-lane shuffles are needed beyond one
+// half-wave exchange for the running max.  Scores are never written to HBM; the only saved
+// statistic is the per-row log-sum-exp.  N is ragged (560, 290, 281, 875, 1685 ...): tail keys are
+// masked, tail rows are zero-filled in LDS and never stored.
+//
+// One template serves both numeric modes: T = bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate,
+// fp32 softmax) and T = float (v_mfma_f32_32x32x2_f32, exact fp32 -- parity mode).
+#include "common.h"
+
+namespace maest {
+
+constexpr int HD = 64;         // head dim
+constexpr int NHEADS = 12;
+constexpr int QKV_LD = 3 * NHEADS * HD;  // 2304
+constexpr int OUT_LD = NHEADS * HD;      // 768
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float NEG_BIG = -1.0e30f;
+
+template <typename T>
+struct AttnCfg {
+    static constexpr int ELT = (int)sizeof(T);
+    static constexpr int ROWB = HD * ELT;            // bytes of one head row: 128 / 256
+    static constexpr int NCH = ROWB / 16;            // 16-byte chunks per row: 8 / 16
+    static constexpr int EPC = 16 / ELT;             // elements per chunk: 8 / 4
+    static constexpr int STEPS = NCH / 2;            // chunk steps over d: 4 / 8
+    static constexpr int PITCH = ROWB + 16;          // row-major LDS pitch: 144 / 272
+    static constexpr int PITCH_T = 64 * ELT + (ELT == 2 ? 8 : 16);  // transposed tile pitch: 136 / 272
+    static constexpr int ROWS_PER_PASS = 256 / NCH;  // rows staged by 256 threads per pass: 32 / 16
+    static constexpr int PASSES64 = 64 / ROWS_PER_PASS;  // 2 / 4
+    static constexpr int TILE = 64 * PITCH;          // bytes of a 64-row row-major tile
+    static constexpr int TILE_T = 64 * PITCH_T;      // bytes of a [64 d][64 rows] transposed tile
+    static constexpr int ASTEPS = acc_steps<T>::value;
+};
+
+// ---- 64-row tile staging: global -> registers -> LDS (row-major and/or transposed) -------------
+template <typename T>
+struct TileRegs {
+    chunk16 c[AttnCfg<T>::PASSES64];
+};
+
+// rows [r0, r0+64) of a 64-wide head slice; `base` points at (row 0, d 0); rows >= nrows read as 0
+template <typename T>
+__device__ __forceinline__ void tile_load(TileRegs<T>& t, const T* base, int64_t row_stride, int r0,
+                                          int nrows, int tid) {
+    using C = AttnCfg<T>;
+    const int c = tid % C::NCH;
+    const int rr = tid / C::NCH;
+#pragma unroll
+    for (int p = 0; p < C::PASSES64; ++p) {
+        const int r = r0 + rr + p * C::ROWS_PER_PASS;
+        if (r < nrows) {
+            t.c[p] = *reinterpret_cast<const chunk16*>(base + (int64_t)r * row_stride + c * C::EPC);
+        } else {
+            t.c[p].w[0] = 0; t.c[p].w[1] = 0; t.c[p].w[2] = 0; t.c[p].w[3] = 0;
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void tile_store_rows(const TileRegs<T>& t, char* lds, int tid) {
+    using C = AttnCfg<T>;
+    const int c = tid % C::NCH;
+    const int rr = tid / C::NCH;
+#pragma unroll
+    for (int p = 0; p < C::PASSES64; ++p)
+        *reinterpret_cast<chunk16*>(lds + (rr + p * C::ROWS_PER_PASS) * C::PITCH + c * 16) = t.c[p];
+}
+// lds_t[d][row]  (pitch PITCH_T)
+template <typename T>
+__device__ __forceinline__ void tile_store_transposed(const TileRegs<T>& t, char* lds_t, int tid) {
+    using C = AttnCfg<T>;
+    const int c = tid % C::NCH;
+    const int rr = tid / C::NCH;
+#pragma unroll
+    for (int p = 0; p < C::PASSES64; ++p) {
+        const int r = rr + p * C::ROWS_PER_PASS;
+        if constexpr (C::ELT == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint16_t v = (uint16_t)(t.c[p].w[e >> 1] >> ((e & 1) * 16));
+                *reinterpret_cast<uint16_t*>(lds_t + (c * 8 + e) * C::PITCH_T + r * 2) = v;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                *reinterpret_cast<uint32_t*>(lds_t + (c * 4 + e) * C::PITCH_T + r * 4) = t.c[p].w[e];
+        }
+    }
+}
+
+// per-lane operand fragments of one row (row = lane&31 of a 32-row group), chunks 2s+h
+template <typename T>
+__device__ __forceinline__ void row_frags_load(chunk16 (&f)[AttnCfg<T>::STEPS], const T* base,
+                                               int64_t row_stride, int row, int nrows, int h) {
+    using C = AttnCfg<T>;
+    const int r = row < nrows ? row : nrows - 1;  // clamped rows are never stored
+#pragma unroll
+    for (int s = 0; s < C::STEPS; ++s)
+        f[s] = *reinterpret_cast<const chunk16*>(base + (int64_t)r * row_stride + (2 * s + h) * C::EPC);
+}
+
+// acc[32 x 32] += sum_d  A_lds[row0 + (lane&31)][d] * frag[d]   (A from a row-major LDS tile)
+template <typename T>
+__device__ __forceinline__ void mma_rows(f32x16_t& acc, const char* lds, int row0, int lane,
+                                         const chunk16 (&frag)[AttnCfg<T>::STEPS]) {
+    using C = AttnCfg<T>;
+    const char* rp = lds + (row0 + (lane & 31)) * C::PITCH + (lane >> 5) * 16;
+#pragma unroll
+    for (int s = 0; s < C::STEPS; ++s) {
+        const chunk16 a = *reinterpret_cast<const chunk16*>(rp + s * 32);
+        mma_chunk<T>(acc, a, frag[s]);
+    }
+}
+// acc2[d-block db][32 d x 32 cols] += sum_{rho in 32-row group rho0} At[d][rho] * P[rho][col]
+template <typename T>
+__device__ __forceinline__ void mma_transposed(f32x16_t (&acc)[2], const char* lds_t, int rho0, int lane,
+                                               const f32x16_t& p) {
+    using C = AttnCfg<T>;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < C::ASTEPS; ++s) {
+        const chunk16 b = acc_to_chunk<T>(p, s);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const chunk16 a = read_transposed_chunk<T>(lds_t + (db * 32 + (lane & 31)) * C::PITCH_T, rho0, s, h);
+            mma_chunk<T>(acc[db], a, b);
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* dst, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, float a, float b, float c, float d) {
+    chunk8 v;
+    v.w[0] = pack_bf2(a, b);
+    v.w[1] = pack_bf2(c, d);
+    *reinterpret_cast<chunk8*>(dst) = v;
+}
+template <>
+__device__ __forceinline__ void store4<float>(float* dst, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(dst) = make_float4(a, b, c, d);
+}
+// write a [64 d][32 cols] accumulator pair (lane = col = row of the output matrix) to global
+template <typename T>
+__device__ __forceinline__ void store_dT(const f32x16_t (&acc)[2], T* row_ptr, int lane, float mul) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            store4<T>(row_ptr + db * 32 + 8 * g + 4 * h, acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul,
+                      acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
+}
+
+// =================================================================================== forward
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                       float* __restrict__ lse, int N, float scale) {
+    using C = AttnCfg<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;               // K[key][d]
+    char* vt_lds = smem + C::TILE;    // V^T[d][key]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q = q0 + (lane & 31);
+    const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
+    const T* kbase = qbase + NHEADS * HD;
+    const T* vbase = qbase + 2 * NHEADS * HD;
+
+    chunk16 qf[C::STEPS];
+    row_frags_load<T>(qf, qbase, QKV_LD, q, N, h);
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
+    float m_run = NEG_BIG, l_run = 0.0f;
+    const float c2 = scale * LOG2E;
+
+    const int ntiles = (N + 63) / 64;
+    TileRegs<T> kr, vr;
+    tile_load<T>(kr, kbase, QKV_LD, 0, N, tid);
+    tile_load<T>(vr, vbase, QKV_LD, 0, N, tid);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();  // previous tile fully consumed
+        tile_store_rows<T>(kr, k_lds, tid);
+        tile_store_transposed<T>(vr, vt_lds, tid);
+        __syncthreads();
+        if (kt + 1 < ntiles) {
+            tile_load<T>(kr, kbase, QKV_LD, (kt + 1) * 64, N, tid);
+            tile_load<T>(vr, vbase, QKV_LD, (kt + 1) * 64, N, tid);
+        }
+        // S^T[key][q]
+        f32x16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+            mma_rows<T>(s[kb], k_lds, kb * 32, lane, qf);
+        }
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + kb * 32 + frag_row(r, lane);
+                const float t = key < N ? s[kb][r] * c2 : NEG_BIG;
+                s[kb][r] = t;
+                mx = fmaxf(mx, t);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(s[kb][r] - m_new);
+                s[kb][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;  // per half-wave partial; halves are merged at the end
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) mma_transposed<T>(o, vt_lds, kb * 32, lane, s[kb]);
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q < N) {
+        store_dT<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv);
+        if (lse != nullptr && h == 0) lse[((int64_t)b * NHEADS + head) * N + q] = m_run * LN2 + logf(l_tot);
+    }
+}
+
+// =================================================================================== delta
+// delta[b,head,q] = sum_d dO[b,q,head,d] * O[b,q,head,d]      (4 lanes per (row, head))
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int N) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * N * NHEADS;
+    int64_t item = gid >> 2;
+    const int quarter = (int)(gid & 3);
+    const bool valid = item < total;
+    if (!valid) item = total - 1;
+    const int64_t row = item / NHEADS;
+    const int head = (int)(item - row * NHEADS);
+    const T* po = o + row * OUT_LD + head * HD + quarter * 16;
+    const T* pd = dout + row * OUT_LD + head * HD + quarter * 16;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += elem_traits<T>::to_f32(po[i]) * elem_traits<T>::to_f32(pd[i]);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (valid && quarter == 0) {
+        const int64_t bb = row / N;
+        const int64_t qq = row - bb * N;
+        delta[(bb * NHEADS + head) * N + qq] = acc;
+    }
+}
+
+// =================================================================================== dK, dV
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                            const float* __restrict__ lse,
+                                                            const float* __restrict__ delta,
+                                                            T* __restrict__ dqkv, int N, float scale) {
+    using C = AttnCfg<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* q_lds = smem;                          // Q[q][d]
+    char* do_lds = q_lds + C::TILE;              // dO[q][d]
+    char* qt_lds = do_lds + C::TILE;             // Q^T[d][q]
+    char* dot_lds = qt_lds + C::TILE_T;          // dO^T[d][q]
+    float* lse_lds = reinterpret_cast<float*>(dot_lds + C::TILE_T);  // [64] (pre-multiplied by log2e)
+    float* dl_lds = lse_lds + 64;                                    // [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int key = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
+    const T* kbase = qbase + NHEADS * HD;
+    const T* vbase = qbase + 2 * NHEADS * HD;
+    const T* dobase = dout + (int64_t)b * N * OUT_LD + head * HD;
+    const float* lse_b = lse + ((int64_t)b * NHEADS + head) * N;
+    const float* dl_b = delta + ((int64_t)b * NHEADS + head) * N;
+
+    chunk16 kf[C::STEPS], vf[C::STEPS];
+    row_frags_load<T>(kf, kbase, QKV_LD, key, N, h);
+    row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
+    const bool key_ok = key < N;
+
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.0f; dv[db][r] = 0.0f; }
+    const float c2 = scale * LOG2E;
+
+    const int ntiles = (N + 63) / 64;
+    TileRegs<T> qr, dr;
+    tile_load<T>(qr, qbase, QKV_LD, 0, N, tid);
+    tile_load<T>(dr, dobase, OUT_LD, 0, N, tid);
+    for (int qt = 0; qt < ntiles; ++qt) {
+        __syncthreads();
+        tile_store_rows<T>(qr, q_lds, tid);
+        tile_store_rows<T>(dr, do_lds, tid);
+        tile_store_transposed<T>(qr, qt_lds, tid);
+        tile_store_transposed<T>(dr, dot_lds, tid);
+        if (tid < 64) {
+            const int qq = qt * 64 + tid;
+            lse_lds[tid] = qq < N ? lse_b[qq] * LOG2E : 0.0f;
+            dl_lds[tid] = qq < N ? dl_b[qq] : 0.0f;
+        }
+        __syncthreads();
+        if (qt + 1 < ntiles) {
+            tile_load<T>(qr, qbase, QKV_LD, (qt + 1) * 64, N, tid);
+            tile_load<T>(dr, dobase, OUT_LD, (qt + 1) * 64, N, tid);
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+            mma_rows<T>(s, q_lds, qb * 32, lane, kf);     // S[q][key]
+            mma_rows<T>(dp, do_lds, qb * 32, lane, vf);   // dP[q][key]
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ql = qb * 32 + 8 * g + 4 * h;  // local q of register 4g (4 consecutive rows)
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_lds + ql);
+                const float4 d4 = *reinterpret_cast<const float4*>(dl_lds + ql);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+                const float dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const bool ok = key_ok && (qt * 64 + ql + e) < N;
+                    const float p = ok ? exp2f(s[r] * c2 - lv[e]) : 0.0f;
+                    s[r] = p;                       // P
+                    dp[r] = p * (dp[r] - dvv[e]);   // dS (unscaled)
+                }
+            }
+            mma_transposed<T>(dv, dot_lds, qb * 32, lane, s);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+            mma_transposed<T>(dk, qt_lds, qb * 32, lane, dp);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+        }
+    }
+    if (key_ok) {
+        T* row = dqkv + ((int64_t)b * N + key) * QKV_LD + head * HD;
+        store_dT<T>(dk, row + NHEADS * HD, lane, scale);
+        store_dT<T>(dv, row + 2 * NHEADS * HD, lane, 1.0f);
+    }
+}
+
+// =================================================================================== dQ
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                          const float* __restrict__ lse,
+                                                          const float* __restrict__ delta,
+                                                          T* __restrict__ dqkv, int N, float scale) {
+    using C = AttnCfg<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;                 // K[key][d]
+    char* v_lds = k_lds + C::TILE;      // V[key][d]
+    char* kt_lds = v_lds + C::TILE;     // K^T[d][key]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
+    const T* kbase = qbase + NHEADS * HD;
+    const T* vbase = qbase + 2 * NHEADS * HD;
+    const T* dobase = dout + (int64_t)b * N * OUT_LD + head * HD;
+
+    chunk16 qf[C::STEPS], dof[C::STEPS];
+    row_frags_load<T>(qf, qbase, QKV_LD, q, N, h);
+    row_frags_load<T>(dof, dobase, OUT_LD, q, N, h);
+    const bool q_ok = q < N;
+    const int qc = q_ok ? q : N - 1;
+    const float lse_q = lse[((int64_t)b * NHEADS + head) * N + qc] * LOG2E;
+    const float dl_q = delta[((int64_t)b * NHEADS + head) * N + qc];
+
+    f32x16_t dq[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[db][r] = 0.0f;
+    const float c2 = scale * LOG2E;
+
+    const int ntiles = (N + 63) / 64;
+    TileRegs<T> kr, vr;
+    tile_load<T>(kr, kbase, QKV_LD, 0, N, tid);
+    tile_load<T>(vr, vbase, QKV_LD, 0, N, tid);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        tile_store_rows<T>(kr, k_lds, tid);
+        tile_store_rows<T>(vr, v_lds, tid);
+        tile_store_transposed<T>(kr, kt_lds, tid);
+        __syncthreads();
+        if (kt + 1 < ntiles) {
+            tile_load<T>(kr, kbase, QKV_LD, (kt + 1) * 64, N, tid);
+            tile_load<T>(vr, vbase, QKV_LD, (kt + 1) * 64, N, tid);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+            mma_rows<T>(s, k_lds, kb * 32, lane, qf);     // S^T[key][q]
+            mma_rows<T>(dp, v_lds, kb * 32, lane, dof);   // dP^T[key][q]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kt * 64 + kb * 32 + frag_row(r, lane);
+                const float p = (kk < N) ? exp2f(s[r] * c2 - lse_q) : 0.0f;
+                dp[r] = p * (dp[r] - dl_q);   // dS^T (unscaled)
+            }
+            mma_transposed<T>(dq, kt_lds, kb * 32, lane, dp);   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+        }
+    }
+    if (q_ok) store_dT<T>(dq, dqkv + ((int64_t)b * N + q) * QKV_LD + head * HD, lane, scale);
+}
+
+template <typename T>
+static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, hipStream_t st) {
+    using C = AttnCfg<T>;
+    const int smem_bytes = C::TILE + C::TILE_T;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+        once = true;
+    }
+    dim3 grid((N + 127) / 128, NHEADS, B);
+    hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, N, scale);
+    return check_launch("maest_attn_fwd");
+}
+
+template <typename T>
+static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                           void* dqkv, int B, int N, float scale, hipStream_t st) {
+    using C = AttnCfg<T>;
+    const int smem_a = 2 * C::TILE + 2 * C::TILE_T + 512;
+    const int smem_b = 2 * C::TILE + C::TILE_T;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem_a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem_b);
+        once = true;
+    }
+    const int64_t items = (int64_t)B * N * NHEADS * 4;
+    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
+                       (const T*)out, (const T*)dout, delta, B, N);
+    dim3 grid((N + 127) / 128, NHEADS, B);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, grid, dim3(256), smem_a, st, (const T*)qkv, (const T*)dout, lse,
+                       (const float*)delta, (T*)dqkv, N, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), smem_b, st, (const T*)qkv, (const T*)dout, lse,
+                       (const float*)delta, (T*)dqkv, N, scale);
+    return check_launch("maest_attn_bwd");
+}
+
+}  // namespace maest
+
+using namespace maest;
+
+extern "C" int maest_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int dtype, float scale,
+                              void* stream) {
+    MAEST_REQUIRE(qkv && out, "maest_attn_fwd: null pointer");
+    MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_fwd: bad shape B=%d N=%d", B, N);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_attn_fwd: bad dtype %d", dtype);
+    MAEST_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "maest_attn_fwd: 16-byte alignment");
+    return dtype == MAEST_BF16 ? attn_fwd_launch<bf16_t>(qkv, out, lse, B, N, scale, (hipStream_t)stream)
+                               : attn_fwd_launch<float>(qkv, out, lse, B, N, scale, (hipStream_t)stream);
+}
+
+extern "C" int maest_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                              float* delta, void* dqkv, int B, int N, int dtype, float scale, void* stream) {
+    MAEST_REQUIRE(qkv && out && dout && lse && delta && dqkv, "maest_attn_bwd: null pointer");
+    MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_bwd: bad shape B=%d N=%d", B, N);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_attn_bwd: bad dtype %d", dtype);
+    return dtype == MAEST_BF16
+               ? attn_bwd_launch<bf16_t>(qkv, out, dout, lse, delta, dqkv, B, N, scale, (hipStream_t)stream)
+               : attn_bwd_launch<float>(qkv, out, dout, lse, delta, dqkv, B, N, scale, (hipStream_t)stream);
+}

@@ -1,0 +1,169 @@
+// maest_amd device-side common definitions (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/maest_hip.h"
+
+namespace maest {
+
+// ------------------------------------------------------------------ element types
+typedef uint16_t bf16_t;  // raw bfloat16 bits; all conversions are explicit integer ops
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float bf2f(bf16_t h) {
+    uint32_t u = ((uint32_t)h) << 16;
+    return __builtin_bit_cast(float, u);
+}
+// round-to-nearest-even, NaN preserved as quiet NaN
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// A 16-byte MFMA operand chunk: 8 bf16 or 4 fp32, as loaded from LDS / global.
+struct __attribute__((aligned(16))) chunk16 {
+    uint32_t w[4];
+};
+struct __attribute__((aligned(8))) chunk8 {
+    uint32_t w[2];
+};
+
+template <typename T>
+struct elem_traits;
+template <>
+struct elem_traits<bf16_t> {
+    static constexpr int kPerChunk = 8;  // elements per 16-byte chunk
+    __device__ static __forceinline__ float to_f32(bf16_t v) { return bf2f(v); }
+    __device__ static __forceinline__ bf16_t from_f32(float v) { return f2bf(v); }
+};
+template <>
+struct elem_traits<float> {
+    static constexpr int kPerChunk = 4;
+    __device__ static __forceinline__ float to_f32(float v) { return v; }
+    __device__ static __forceinline__ float from_f32(float v) { return v; }
+};
+
+// One "chunk step" of a 32x32 MFMA accumulation: every lane supplies a 16-byte piece of its
+// A row (row = lane&31) and of its B row (col = lane&31); lanes 0-31 and 32-63 supply DIFFERENT
+// k-slices.  bf16: one v_mfma_f32_32x32x16_bf16 (16 k per step).  fp32: four
+// v_mfma_f32_32x32x2_f32 (8 k per step, exact fp32 fmaf chain).  The reduction is invariant to
+// any permutation of k that A and B share, which is what every caller relies on.
+template <typename T>
+__device__ __forceinline__ void mma_chunk(f32x16_t& acc, const chunk16& a, const chunk16& b);
+
+template <>
+__device__ __forceinline__ void mma_chunk<bf16_t>(f32x16_t& acc, const chunk16& a, const chunk16& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                  __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const chunk16& a, const chunk16& b) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w[q]),
+                                                   __builtin_bit_cast(float, b.w[q]), acc, 0, 0, 0);
+}
+
+// C/D fragment map of every 32x32 MFMA on gfx950: register r of lane l holds
+//   row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),   col = l & 31.
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// Convert `n` consecutive accumulator registers (rows of one D column) into the B/A operand
+// chunk of a follow-up MFMA whose reduction index is the D row index.
+//   bf16: regs [8s, 8s+8)  -> rows 16s + 8(j>>2) + 4h + (j&3)
+//   fp32: regs [4s, 4s+4)  -> rows  8s + 4h + j
+template <typename T>
+__device__ __forceinline__ chunk16 acc_to_chunk(const f32x16_t& p, int s);
+template <>
+__device__ __forceinline__ chunk16 acc_to_chunk<bf16_t>(const f32x16_t& p, int s) {
+    chunk16 c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c.w[j] = pack_bf2(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
+    return c;
+}
+template <>
+__device__ __forceinline__ chunk16 acc_to_chunk<float>(const f32x16_t& p, int s) {
+    chunk16 c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float v = p[4 * s + j];  // by-value copy first: never bit_cast a vector-element lvalue
+        c.w[j] = __builtin_bit_cast(uint32_t, v);
+    }
+    return c;
+}
+
+// Matching operand read from a TRANSPOSED LDS tile  At[i][rho]  (row pitch `pitch` bytes):
+// lane (i = lane&31, h = lane>>5) fetches the rho values listed above for step s of the
+// 32-row sub-tile starting at row `rho0`.
+template <typename T>
+__device__ __forceinline__ chunk16 read_transposed_chunk(const char* row_ptr, int rho0, int s, int h);
+template <>
+__device__ __forceinline__ chunk16 read_transposed_chunk<bf16_t>(const char* row_ptr, int rho0, int s, int h) {
+    const chunk8 lo = *reinterpret_cast<const chunk8*>(row_ptr + (rho0 + 16 * s + 4 * h) * 2);
+    const chunk8 hi = *reinterpret_cast<const chunk8*>(row_ptr + (rho0 + 16 * s + 8 + 4 * h) * 2);
+    chunk16 c;
+    c.w[0] = lo.w[0]; c.w[1] = lo.w[1]; c.w[2] = hi.w[0]; c.w[3] = hi.w[1];
+    return c;
+}
+template <>
+__device__ __forceinline__ chunk16 read_transposed_chunk<float>(const char* row_ptr, int rho0, int s, int h) {
+    return *reinterpret_cast<const chunk16*>(row_ptr + (rho0 + 8 * s + 4 * h) * 4);
+}
+template <typename T>
+struct acc_steps;  // chunk steps per 32-row accumulator tile
+template <>
+struct acc_steps<bf16_t> { static constexpr int value = 2; };
+template <>
+struct acc_steps<float> { static constexpr int value = 4; };
+
+// ------------------------------------------------------------------ wave helpers (wave64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// exact-erf GELU (nn.GELU default) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks dispatched round-robin over the 8 XCDs
+// (block b -> XCD b % 8, observed) are renumbered so that each XCD owns a contiguous range of
+// logical tile ids and therefore re-uses operand panels out of its private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------ host-side error plumbing
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+}  // namespace maest
+
+#define MAEST_REQUIRE(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            maest::set_error(__VA_ARGS__);  \
+            return MAEST_ERR_INVALID;       \
+        }                                   \
+    } while (0)

@@ -1,0 +1,211 @@
+// Patch-embedding operand builder, positional add / token assembly and their backward, plus the
+// training-time input augmentations that the reference applies on the way in.
+// (reference: PatchEmbed.forward models/maest.py:243-256 = Conv2d(1,768,k=16,s=10) :238-240;
+//  time/freq positional add :645-675; structured patchout :684-687; flatten/transpose :769;
+//  cls/dist tokens :785-796; mixup models/module.py:77-83; SpecMasking helpers/spec_masking.py:27-33.)
+//
+// The 16x16 / stride-10 convolution is evaluated as a GEMM [B*9*Tk, 256] x [768, 256]^T on the MFMA
+// kernel (gemm.hip); this file produces its A operand straight from the (optionally mixed-up)
+// spectrogram, ONLY for the time columns that survive structured patchout -- dropped columns are
+// never computed, which is mathematically identical to computing then discarding them.
+#include "common.h"
+
+namespace maest {
+
+constexpr int PE_D = 768;
+constexpr int PE_K = 16;   // patch edge
+constexpr int PE_S = 10;   // stride
+
+// one thread = one (patch row, ky): 16 contiguous input samples -> 16 contiguous operand elements
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ x, int B, int F, int T,
+                                                           const int32_t* __restrict__ perm,
+                                                           const float* __restrict__ lam,
+                                                           const int32_t* __restrict__ t_idx, int Fp, int Tk,
+                                                           void* __restrict__ out, int dtype) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * Fp * Tk * PE_K;
+    if (gid >= total) return;
+    const int ky = (int)(gid & 15);
+    const int64_t prow = gid >> 4;
+    const int tk = (int)(prow % Tk);
+    const int f = (int)((prow / Tk) % Fp);
+    const int b = (int)(prow / ((int64_t)Tk * Fp));
+    const int tcol = (t_idx != nullptr ? t_idx[tk] : tk) * PE_S;
+    const float* src = x + ((int64_t)b * F + f * PE_S + ky) * T + tcol;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = src[i];
+    if (lam != nullptr) {
+        const float l = lam[b];
+        const float* src2 = x + ((int64_t)perm[b] * F + f * PE_S + ky) * T + tcol;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = v[i] * l + src2[i] * (1.0f - l);
+    }
+    const int64_t o = prow * 256 + ky * 16;
+    if (dtype == MAEST_BF16) {
+        chunk16* dst = reinterpret_cast<chunk16*>(reinterpret_cast<bf16_t*>(out) + o);
+        chunk16 c0, c1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            c0.w[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+            c1.w[i] = pack_bf2(v[8 + 2 * i], v[8 + 2 * i + 1]);
+        }
+        dst[0] = c0;
+        dst[1] = c1;
+    } else {
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+}
+
+// x0[b, n, c4]: one thread per 4 channels of one token
+__global__ __launch_bounds__(256) void token_assemble_kernel(const float* __restrict__ patches,
+                                                             const float* __restrict__ cls_token,
+                                                             const float* __restrict__ dist_token,
+                                                             const float* __restrict__ new_pos,
+                                                             const float* __restrict__ freq_pos,
+                                                             const float* __restrict__ time_pos, int Tt, int toffset,
+                                                             const int32_t* __restrict__ t_idx, int B, int Fp, int Tk,
+                                                             float* __restrict__ x0) {
+    const int Ntok = 2 + Fp * Tk;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * Ntok * (PE_D / 4);
+    if (gid >= total) return;
+    const int c = (int)(gid % (PE_D / 4)) * 4;
+    const int64_t tok = gid / (PE_D / 4);
+    const int n = (int)(tok % Ntok);
+    const int b = (int)(tok / Ntok);
+    float o[4];
+    if (n == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = cls_token[c + e] + new_pos[c + e];
+    } else if (n == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = dist_token[c + e] + new_pos[PE_D + c + e];
+    } else {
+        const int j = n - 2;
+        const int f = j / Tk, tk = j - f * Tk;
+        const int tcol = toffset + (t_idx != nullptr ? t_idx[tk] : tk);
+        const float4 p = *reinterpret_cast<const float4*>(patches + ((int64_t)b * Fp * Tk + j) * PE_D + c);
+        const float pv[4] = {p.x, p.y, p.z, p.w};
+        // reference order: (conv + time_pos) + freq_pos   (maest.py:670,675)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = (pv[e] + time_pos[(int64_t)(c + e) * Tt + tcol]) + freq_pos[(int64_t)(c + e) * Fp + f];
+    }
+    *reinterpret_cast<float4*>(x0 + tok * PE_D + c) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// grid (Ntok, 3): thread = channel; loops over the batch (coalesced over channels)
+__global__ __launch_bounds__(256) void token_assemble_bwd_kernel(const float* __restrict__ dx0, int B, int Fp, int Tk,
+                                                                 int Tt, int toffset,
+                                                                 const int32_t* __restrict__ t_idx,
+                                                                 void* __restrict__ dpatches, int dtype,
+                                                                 float* __restrict__ d_cls, float* __restrict__ d_dist,
+                                                                 float* __restrict__ d_new_pos,
+                                                                 float* __restrict__ d_freq_pos,
+                                                                 float* __restrict__ d_time_pos) {
+    const int Ntok = 2 + Fp * Tk;
+    const int n = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float g = dx0[((int64_t)b * Ntok + n) * PE_D + c];
+        s += g;
+        if (n >= 2 && dpatches != nullptr) {
+            const int64_t o = ((int64_t)b * Fp * Tk + (n - 2)) * PE_D + c;
+            if (dtype == MAEST_BF16) reinterpret_cast<bf16_t*>(dpatches)[o] = f2bf(g);
+            else reinterpret_cast<float*>(dpatches)[o] = g;
+        }
+    }
+    if (n == 0) {
+        d_cls[c] += s;
+        d_new_pos[c] += s;
+    } else if (n == 1) {
+        d_dist[c] += s;
+        d_new_pos[PE_D + c] += s;
+    } else {
+        const int j = n - 2;
+        const int f = j / Tk, tk = j - f * Tk;
+        const int tcol = toffset + (t_idx != nullptr ? t_idx[tk] : tk);
+        unsafeAtomicAdd(d_freq_pos + (int64_t)c * Fp + f, s);
+        unsafeAtomicAdd(d_time_pos + (int64_t)c * Tt + tcol, s);
+    }
+}
+
+// zero stripes: grid (B, n_t + n_f)
+__global__ __launch_bounds__(256) void spec_mask_kernel(float* __restrict__ x, int F, int T,
+                                                        const int32_t* __restrict__ t_stripes, int n_t,
+                                                        const int32_t* __restrict__ f_stripes, int n_f) {
+    const int b = blockIdx.x, s = blockIdx.y;
+    float* xb = x + (int64_t)b * F * T;
+    if (s < n_t) {
+        int st = t_stripes[((int64_t)b * n_t + s) * 2], w = t_stripes[((int64_t)b * n_t + s) * 2 + 1];
+        if (st < 0) st = 0;
+        if (st + w > T) w = T - st;
+        for (int i = threadIdx.x; i < F * w; i += 256) xb[(int64_t)(i / w) * T + st + (i % w)] = 0.0f;
+    } else {
+        const int k = s - n_t;
+        int st = f_stripes[((int64_t)b * n_f + k) * 2], w = f_stripes[((int64_t)b * n_f + k) * 2 + 1];
+        if (st < 0) st = 0;
+        if (st + w > F) w = F - st;
+        for (int i = threadIdx.x; i < w * T; i += 256) xb[(int64_t)st * T + i] = 0.0f;
+    }
+}
+
+}  // namespace maest
+
+using namespace maest;
+
+extern "C" int maest_patch_im2col(const float* x, int B, int F, int T, const int32_t* perm, const float* lam,
+                                  const int32_t* t_idx, int Fp, int Tk, void* out, int dtype, void* stream) {
+    MAEST_REQUIRE(x && out, "maest_patch_im2col: null pointer");
+    MAEST_REQUIRE(B > 0 && Fp > 0 && Tk > 0, "maest_patch_im2col: bad shape B=%d Fp=%d Tk=%d", B, Fp, Tk);
+    MAEST_REQUIRE((Fp - 1) * PE_S + PE_K <= F, "maest_patch_im2col: Fp=%d does not fit F=%d", Fp, F);
+    MAEST_REQUIRE(T >= PE_K, "maest_patch_im2col: T=%d too short", T);
+    MAEST_REQUIRE((perm == nullptr) == (lam == nullptr), "maest_patch_im2col: perm and lam go together");
+    MAEST_REQUIRE(t_idx != nullptr || (Tk - 1) * PE_S + PE_K <= T, "maest_patch_im2col: Tk=%d does not fit T=%d", Tk, T);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_patch_im2col: bad dtype");
+    const int64_t total = (int64_t)B * Fp * Tk * PE_K;
+    hipLaunchKernelGGL(patch_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, B, F, T, perm, lam, t_idx, Fp, Tk, out, dtype);
+    return check_launch("maest_patch_im2col");
+}
+
+extern "C" int maest_token_assemble(const float* patches, const float* cls_token, const float* dist_token,
+                                    const float* new_pos, const float* freq_pos, const float* time_pos, int Tt,
+                                    int toffset, const int32_t* t_idx, int B, int Fp, int Tk, float* x0,
+                                    void* stream) {
+    MAEST_REQUIRE(patches && cls_token && dist_token && new_pos && freq_pos && time_pos && x0,
+                  "maest_token_assemble: null pointer");
+    MAEST_REQUIRE(B > 0 && Fp > 0 && Tk > 0 && Tt > 0 && toffset >= 0, "maest_token_assemble: bad shape");
+    const int64_t total = (int64_t)B * (2 + Fp * Tk) * (PE_D / 4);
+    hipLaunchKernelGGL(token_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, patches, cls_token, dist_token, new_pos, freq_pos, time_pos, Tt, toffset,
+                       t_idx, B, Fp, Tk, x0);
+    return check_launch("maest_token_assemble");
+}
+
+extern "C" int maest_token_assemble_bwd(const float* dx0, int B, int Fp, int Tk, int Tt, int toffset,
+                                        const int32_t* t_idx, void* dpatches, int dtype, float* d_cls, float* d_dist,
+                                        float* d_new_pos, float* d_freq_pos, float* d_time_pos, void* stream) {
+    MAEST_REQUIRE(dx0 && d_cls && d_dist && d_new_pos && d_freq_pos && d_time_pos,
+                  "maest_token_assemble_bwd: null pointer");
+    MAEST_REQUIRE(B > 0 && Fp > 0 && Tk > 0 && Tt > 0, "maest_token_assemble_bwd: bad shape");
+    hipLaunchKernelGGL(token_assemble_bwd_kernel, dim3(2 + Fp * Tk, PE_D / 256), dim3(256), 0, (hipStream_t)stream,
+                       dx0, B, Fp, Tk, Tt, toffset, t_idx, dpatches, dtype, d_cls, d_dist, d_new_pos, d_freq_pos,
+                       d_time_pos);
+    return check_launch("maest_token_assemble_bwd");
+}
+
+extern "C" int maest_spec_mask(float* x, int B, int F, int T, const int32_t* t_stripes, int n_t,
+                               const int32_t* f_stripes, int n_f, void* stream) {
+    MAEST_REQUIRE(x, "maest_spec_mask: null pointer");
+    MAEST_REQUIRE(n_t >= 0 && n_f >= 0 && (n_t == 0 || t_stripes) && (n_f == 0 || f_stripes),
+                  "maest_spec_mask: bad stripe lists");
+    if (n_t + n_f == 0) return MAEST_OK;
+    hipLaunchKernelGGL(spec_mask_kernel, dim3(B, n_t + n_f), dim3(256), 0, (hipStream_t)stream, x, F, T, t_stripes,
+                       n_t, f_stripes, n_f);
+    return check_launch("maest_spec_mask");
+}

@@ -1,0 +1,197 @@
+// Small HBM-bound helpers around the GEMMs: operand transposes for wgrad, parameter casts,
+// bias-gradient column sums, BCE-with-logits (+ fused label mixup), predict_labels tail.
+// (reference: F.binary_cross_entropy_with_logits models/module.py:90,299-301; label mixup :84-86;
+//  predict_labels sigmoid/mean models/maest.py:937-938.)
+#include "common.h"
+
+namespace maest {
+
+// ---- tiled transpose through LDS: dst[c][r] = src[r][c]; dst row pitch ld_dst >= rows, pad zeroed.
+// 64x64 element tiles, 256 threads.  LDS tile rows are padded by one 4-byte word.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, int64_t ld_src,
+                                                        T* __restrict__ dst, int64_t ld_dst, int rows, int cols) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* tile = reinterpret_cast<T*>(smem);  // [64][64 + PAD]
+    constexpr int PAD = 4 / (int)sizeof(T);
+    constexpr int LD = 64 + PAD;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + i * 4 + ty, c = c0 + tx;
+        T v = (T)0;
+        if (r < rows && c < cols) v = src[(int64_t)r * ld_src + c];
+        tile[(i * 4 + ty) * LD + tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + i * 4 + ty, r = r0 + tx;
+        if (c < cols && r < ld_dst) dst[(int64_t)c * ld_dst + r] = tile[tx * LD + i * 4 + ty];
+    }
+}
+
+// ---- fp32 parameters -> operand dtype, plus optional transposed copy (one pass over the source)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_weights_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                           T* __restrict__ dst_t, int rows, int cols) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);  // [64][65]
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + i * 4 + ty, c = c0 + tx;
+        float v = 0.0f;
+        if (r < rows && c < cols) {
+            v = src[(int64_t)r * cols + c];
+            if (dst != nullptr) dst[(int64_t)r * cols + c] = elem_traits<T>::from_f32(v);
+        }
+        tile[(i * 4 + ty) * 65 + tx] = v;
+    }
+    if (dst_t == nullptr) return;  // uniform
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + i * 4 + ty, r = r0 + tx;
+        if (c < cols && r < rows) dst_t[(int64_t)c * rows + r] = elem_traits<T>::from_f32(tile[tx * 65 + i * 4 + ty]);
+    }
+}
+
+// ---- out[c] += sum_r src[r][c]; grid (ceil(cols/256), row chunks of 512)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ src, int64_t ld, int rows, int cols,
+                                                     float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int r_begin = blockIdx.y * 512;
+    int r_end = r_begin + 512;
+    if (r_end > rows) r_end = rows;
+    float s = 0.0f;
+    for (int r = r_begin; r < r_end; ++r) s += elem_traits<T>::to_f32(src[(int64_t)r * ld + c]);
+    unsafeAtomicAdd(out + c, s);
+}
+
+// ---- BCE with logits (mean), optional label mixup; loss accumulated with one atomic per block
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ z, const float* __restrict__ y,
+                                                         const int32_t* __restrict__ perm,
+                                                         const float* __restrict__ lam, int rows, int cols,
+                                                         float weight, float* __restrict__ loss,
+                                                         float* __restrict__ dlogits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);
+    const int64_t total = (int64_t)rows * cols;
+    const float inv = 1.0f / (float)total;
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        float t = y[i];
+        if (lam != nullptr) {
+            const float l = lam[r];
+            t = t * l + y[(int64_t)perm[r] * cols + c] * (1.0f - l);
+        }
+        const float v = z[i];
+        // max(z,0) - z*y + log1p(exp(-|z|))   (ATen's numerically stable form)
+        acc += fmaxf(v, 0.0f) - v * t + log1pf(expf(-fabsf(v)));
+        if (dlogits != nullptr) {
+            const float sg = 1.0f / (1.0f + expf(-v));
+            dlogits[i] = weight * (sg - t) * inv;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, weight * (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+
+__global__ __launch_bounds__(256) void sigmoid_mean_kernel(const float* __restrict__ z, int rows, int cols,
+                                                           float* __restrict__ act) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.0f;
+    for (int r = 0; r < rows; ++r) s += 1.0f / (1.0f + expf(-z[(int64_t)r * cols + c]));
+    act[c] = s / (float)rows;
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64_t n, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= alpha;
+}
+
+}  // namespace maest
+
+using namespace maest;
+
+extern "C" int maest_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols,
+                               int dtype, void* stream) {
+    MAEST_REQUIRE(src && dst, "maest_transpose: null pointer");
+    MAEST_REQUIRE(rows > 0 && cols > 0 && ld_dst >= rows && ld_src >= cols, "maest_transpose: bad shape");
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_transpose: bad dtype");
+    dim3 grid((unsigned)((ld_dst + 63) / 64), (cols + 63) / 64);
+    if (dtype == MAEST_BF16)
+        hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 64 * 66 * 2, (hipStream_t)stream,
+                           (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols);
+    else
+        hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 64 * 65 * 4, (hipStream_t)stream,
+                           (const float*)src, ld_src, (float*)dst, ld_dst, rows, cols);
+    return check_launch("maest_transpose");
+}
+
+extern "C" int maest_cast_weights(const float* src, void* dst, void* dst_t, int rows, int cols, int dtype,
+                                  void* stream) {
+    MAEST_REQUIRE(src && (dst || dst_t), "maest_cast_weights: null pointer");
+    MAEST_REQUIRE(rows > 0 && cols > 0, "maest_cast_weights: bad shape");
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_cast_weights: bad dtype");
+    dim3 grid((rows + 63) / 64, (cols + 63) / 64);
+    if (dtype == MAEST_BF16)
+        hipLaunchKernelGGL(cast_weights_kernel<bf16_t>, grid, dim3(256), 64 * 65 * 4, (hipStream_t)stream, src,
+                           (bf16_t*)dst, (bf16_t*)dst_t, rows, cols);
+    else
+        hipLaunchKernelGGL(cast_weights_kernel<float>, grid, dim3(256), 64 * 65 * 4, (hipStream_t)stream, src,
+                           (float*)dst, (float*)dst_t, rows, cols);
+    return check_launch("maest_cast_weights");
+}
+
+extern "C" int maest_colsum(const void* src, int64_t ld, int rows, int cols, int dtype, float* out, void* stream) {
+    MAEST_REQUIRE(src && out, "maest_colsum: null pointer");
+    MAEST_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "maest_colsum: bad shape");
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_colsum: bad dtype");
+    dim3 grid((cols + 255) / 256, (rows + 511) / 512);
+    if (dtype == MAEST_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld,
+                           rows, cols, out);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, ld, rows,
+                           cols, out);
+    return check_launch("maest_colsum");
+}
+
+extern "C" int maest_bce_logits(const float* z, const float* y, const int32_t* perm, const float* lam, int rows,
+                                int cols, float weight, float* loss, float* dlogits, void* stream) {
+    MAEST_REQUIRE(z && y && loss, "maest_bce_logits: null pointer");
+    MAEST_REQUIRE(rows > 0 && cols > 0, "maest_bce_logits: bad shape");
+    MAEST_REQUIRE((perm == nullptr) == (lam == nullptr), "maest_bce_logits: perm and lam go together");
+    const int64_t total = (int64_t)rows * cols;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(blocks), dim3(256), 64, (hipStream_t)stream, z, y, perm, lam, rows,
+                       cols, weight, loss, dlogits);
+    return check_launch("maest_bce_logits");
+}
+
+extern "C" int maest_sigmoid_mean(const float* z, int rows, int cols, float* act, void* stream) {
+    MAEST_REQUIRE(z && act, "maest_sigmoid_mean: null pointer");
+    MAEST_REQUIRE(rows > 0 && cols > 0, "maest_sigmoid_mean: bad shape");
+    hipLaunchKernelGGL(sigmoid_mean_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, z, rows,
+                       cols, act);
+    return check_launch("maest_sigmoid_mean");
+}
+
+extern "C" int maest_scale_f32(float* x, int64_t n, float alpha, void* stream) {
+    MAEST_REQUIRE(x && n >= 0, "maest_scale_f32: bad arguments");
+    if (n == 0) return MAEST_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, alpha);
+    return check_launch("maest_scale_f32");
+}

@@ -1,0 +1,254 @@
+"""Tensor-level wrappers over the C ABI (include/maest_hip.h).  PyTorch is used here only as the
+owner of device memory and of the HIP stream; every computation happens in libmaest_hip.so."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_ATOMIC, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F32, call
+
+DT = {torch.float32: F32, torch.bfloat16: BF16}
+HEADS = 12
+HEAD_DIM = 64
+EMBED = 768
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda or _lib.host_emulation()):
+            raise _lib.MaestHipError(
+                f"maest_amd kernels need tensors on a HIP device, got {t.device}; there is no CPU fallback")
+        if not t.is_contiguous():
+            raise _lib.MaestHipError("maest_amd kernels need contiguous tensors")
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _s(t):
+    if _lib.host_emulation():
+        return None
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------ GEMM
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+            out: Optional[torch.Tensor] = None, out_dtype=None, epi: int = EPI_NONE,
+            aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
+            split_k: int = 1, M: Optional[int] = None, N: Optional[int] = None,
+            K: Optional[int] = None) -> torch.Tensor:
+    """out[M,N] = epi(a[M,K] @ b[N,K]^T + bias).  a/b may carry padded leading dims (2-D views of
+    bigger buffers): lda/ldb are taken from stride(0)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    M = a.shape[0] if M is None else M
+    N = b.shape[0] if N is None else N
+    K = a.shape[1] if K is None else K
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
+    assert out.stride(1) == 1
+    ld_aux = 0
+    for x in (aux_in, aux_out):
+        if x is not None:
+            assert x.stride(1) == 1
+            ld_aux = x.stride(0)
+    for t in (a, b, out, aux_in, aux_out):
+        if t is not None and not (t.is_cuda or _lib.host_emulation()):
+            raise _lib.MaestHipError("maest_amd kernels need tensors on a HIP device; there is no CPU fallback")
+    _chk(bias)
+    call("maest_gemm_nt", _p(a), a.stride(0), _p(b), b.stride(0), DT[a.dtype], _p(out), out.stride(0),
+         DT[out.dtype], M, N, K, _p(bias), epi, _p(aux_in), _p(aux_out), ld_aux, split_k, _s(a))
+    return out
+
+
+def transpose(src: torch.Tensor, ld_dst: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[c, r] = src[r, c]; out has shape [cols, ld_dst] with the pad columns zeroed."""
+    assert src.dim() == 2 and src.stride(1) == 1
+    rows, cols = src.shape
+    ld_dst = ld_dst or rows
+    if out is None:
+        out = torch.empty((cols, ld_dst), dtype=src.dtype, device=src.device)
+    _chk(out)
+    call("maest_transpose", _p(src), src.stride(0), _p(out), ld_dst, rows, cols, DT[src.dtype], _s(src))
+    return out
+
+
+def cast_weights(src: torch.Tensor, dtype, want=True, want_t=False):
+    """fp32 parameter -> (operand copy [rows, cols], transposed operand copy [cols, rows])."""
+    _chk(src)
+    assert src.dtype == torch.float32
+    w2 = src.reshape(src.shape[0], -1)
+    rows, cols = w2.shape
+    dst = torch.empty((rows, cols), dtype=dtype, device=src.device) if want else None
+    dst_t = torch.empty((cols, rows), dtype=dtype, device=src.device) if want_t else None
+    call("maest_cast_weights", _p(w2), _p(dst), _p(dst_t), rows, cols, DT[dtype], _s(src))
+    return dst, dst_t
+
+
+def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype, save_stats=False):
+    """x fp32 [rows, 768] -> y (out_dtype), optionally (mean, rstd)."""
+    _chk(x, gamma, beta)
+    assert x.dtype == torch.float32 and x.dim() == 2
+    rows, cols = x.shape
+    y = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    call("maest_layernorm_fwd", _p(x), x.stride(0), _p(gamma), _p(beta), _p(y), cols, DT[out_dtype], _p(mean),
+         _p(rstd), rows, cols, eps, _s(x))
+    return (y, mean, rstd) if save_stats else y
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, lp_dtype=None, want_fp32=True):
+    """-> (dx fp32 or None, dx in lp_dtype or None); dgamma/dbeta accumulated in place."""
+    _chk(dy, x, gamma, mean, rstd, dres, dgamma, dbeta)
+    rows, cols = x.shape
+    dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device) if want_fp32 else None
+    dx_lp = torch.empty((rows, cols), dtype=lp_dtype, device=x.device) if lp_dtype is not None else None
+    call("maest_layernorm_bwd", _p(dy), dy.stride(0), DT[dy.dtype], _p(x), x.stride(0), _p(gamma), _p(mean),
+         _p(rstd), _p(dres), _p(dx), _p(dx_lp), DT[lp_dtype] if lp_dtype is not None else 0, _p(dgamma), _p(dbeta),
+         rows, cols, _s(x))
+    return dx, dx_lp
+
+
+def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False):
+    _chk(qkv)
+    assert qkv.shape == (B * N, 3 * EMBED)
+    out = torch.empty((B * N, EMBED), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device) if save_lse else None
+    call("maest_attn_fwd", _p(qkv), _p(out), _p(lse), B, N, DT[qkv.dtype], scale, _s(qkv))
+    return (out, lse) if save_lse else out
+
+
+def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float):
+    _chk(qkv, out, dout, lse)
+    assert dout.dtype == qkv.dtype and out.dtype == qkv.dtype
+    delta = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device)
+    dqkv = torch.empty_like(qkv)
+    call("maest_attn_bwd", _p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, N, DT[qkv.dtype], scale,
+         _s(qkv))
+    return dqkv
+
+
+def patch_im2col(x: torch.Tensor, Fp: int, Tk: int, dtype, t_idx=None, perm=None, lam=None):
+    """x fp32 [B, F, T] -> im2col operand [B*Fp*Tk, 256] (mixup and patchout fused)."""
+    _chk(x, t_idx, perm, lam)
+    assert x.dtype == torch.float32 and x.dim() == 3
+    B, F, T = x.shape
+    out = torch.empty((B * Fp * Tk, 256), dtype=dtype, device=x.device)
+    call("maest_patch_im2col", _p(x), B, F, T, _p(perm), _p(lam), _p(t_idx), Fp, Tk, _p(out), DT[dtype], _s(x))
+    return out
+
+
+def token_assemble(patches, cls_token, dist_token, new_pos, freq_pos, time_pos, toffset, t_idx, B, Fp, Tk):
+    _chk(patches, cls_token, dist_token, new_pos, freq_pos, time_pos, t_idx)
+    Tt = time_pos.shape[-1]
+    x0 = torch.empty((B, 2 + Fp * Tk, EMBED), dtype=torch.float32, device=patches.device)
+    call("maest_token_assemble", _p(patches), _p(cls_token), _p(dist_token), _p(new_pos), _p(freq_pos),
+         _p(time_pos), Tt, toffset, _p(t_idx), B, Fp, Tk, _p(x0), _s(patches))
+    return x0
+
+
+def token_assemble_bwd(dx0, B, Fp, Tk, Tt, toffset, t_idx, dtype, d_cls, d_dist, d_new_pos, d_freq_pos,
+                       d_time_pos, want_dpatches=True):
+    _chk(dx0, t_idx, d_cls, d_dist, d_new_pos, d_freq_pos, d_time_pos)
+    dp = torch.empty((B * Fp * Tk, EMBED), dtype=dtype, device=dx0.device) if want_dpatches else None
+    call("maest_token_assemble_bwd", _p(dx0), B, Fp, Tk, Tt, toffset, _p(t_idx), _p(dp), DT[dtype], _p(d_cls),
+         _p(d_dist), _p(d_new_pos), _p(d_freq_pos), _p(d_time_pos), _s(dx0))
+    return dp
+
+
+def head_pool_fwd(x: torch.Tensor, gamma, beta, eps: float, save_stats=False):
+    """x fp32 [B, N, 768] -> cls, dist, feat (fp32 [B,768]) [, mean, rstd fp32 [B,2]]."""
+    _chk(x, gamma, beta)
+    B, N, _ = x.shape
+    cls = torch.empty((B, EMBED), dtype=torch.float32, device=x.device)
+    dist = torch.empty_like(cls)
+    feat = torch.empty_like(cls)
+    mean = torch.empty((B, 2), dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty((B, 2), dtype=torch.float32, device=x.device) if save_stats else None
+    call("maest_head_pool_fwd", _p(x), B, N, _p(gamma), _p(beta), eps, _p(cls), _p(dist), _p(feat), _p(mean),
+         _p(rstd), _s(x))
+    return (cls, dist, feat, mean, rstd) if save_stats else (cls, dist, feat)
+
+
+def head_pool_bwd(d_cls, d_dist, d_feat, x, gamma, mean, rstd, dgamma, dbeta):
+    _chk(d_cls, d_dist, d_feat, x, gamma, mean, rstd, dgamma, dbeta)
+    B, N, _ = x.shape
+    dx = torch.empty_like(x)
+    call("maest_head_pool_bwd", _p(d_cls), _p(d_dist), _p(d_feat), _p(x), B, N, _p(gamma), _p(mean), _p(rstd),
+         _p(dx), _p(dgamma), _p(dbeta), _s(x))
+    return dx
+
+
+def embed_pool(x: torch.Tensor):
+    _chk(x)
+    B, N, _ = x.shape
+    emb = torch.empty((B, 3 * EMBED), dtype=torch.float32, device=x.device)
+    call("maest_embed_pool", _p(x), B, N, _p(emb), _s(x))
+    return emb
+
+
+def bce_logits(z, y, weight=1.0, perm=None, lam=None, loss=None, want_grad=True):
+    """loss (fp32 scalar tensor, accumulated) and dlogits."""
+    _chk(z, y, perm, lam, loss)
+    rows, cols = z.shape
+    if loss is None:
+        loss = torch.zeros((), dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z) if want_grad else None
+    call("maest_bce_logits", _p(z), _p(y), _p(perm), _p(lam), rows, cols, weight, _p(loss), _p(dz), _s(z))
+    return loss, dz
+
+
+def sigmoid_mean(z: torch.Tensor):
+    _chk(z)
+    rows, cols = z.shape
+    act = torch.empty(cols, dtype=torch.float32, device=z.device)
+    call("maest_sigmoid_mean", _p(z), rows, cols, _p(act), _s(z))
+    return act
+
+
+def colsum(src: torch.Tensor, out: torch.Tensor):
+    _chk(out)
+    rows, cols = src.shape
+    call("maest_colsum", _p(src), src.stride(0), rows, cols, DT[src.dtype], _p(out), _s(src))
+    return out
+
+
+def spec_mask_(x: torch.Tensor, t_stripes=None, f_stripes=None):
+    """in place; x fp32 [B, F, T]; stripes int32 [B, n, 2] = (start, width)."""
+    _chk(x, t_stripes, f_stripes)
+    B, F, T = x.shape
+    n_t = 0 if t_stripes is None else t_stripes.shape[1]
+    n_f = 0 if f_stripes is None else f_stripes.shape[1]
+    call("maest_spec_mask", _p(x), B, F, T, _p(t_stripes), n_t, _p(f_stripes), n_f, _s(x))
+    return x
+
+
+def logmel(wave: torch.Tensor, consts) -> torch.Tensor:
+    """wave fp32 [B, S] -> [B, 96, 1 + S // 256].  `consts` = melspectrogram.MelConstants on wave.device."""
+    _chk(wave)
+    assert wave.dtype == torch.float32 and wave.dim() == 2
+    B, S = wave.shape
+    T = 1 + S // 256
+    out = torch.empty((B, 96, T), dtype=torch.float32, device=wave.device)
+    call("maest_logmel", _p(wave), B, S, _p(consts.window), _p(consts.twiddle), _p(consts.fb_start),
+         _p(consts.fb_len), _p(consts.fb_w), consts.fb_stride, consts.log_scale, consts.norm_mean,
+         consts.norm_2std, _p(out), _s(wave))
+    return out
+
+
+def scale_(x: torch.Tensor, alpha: float):
+    _chk(x)
+    assert x.dtype == torch.float32
+    call("maest_scale_f32", _p(x), x.numel(), alpha, _s(x))
+    return x

@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+@pytest.fixture
+def emu():
+    """Bind the host SIMT-emulator build of the kernel sources for the duration of one test."""
+    from tests.emu import build_emu
+    from maest_amd import _lib
+    if not build_emu.available():
+        pytest.skip("host clang for the emulator build is not available")
+    path = build_emu.build()
+    _lib._testing_override(path)
+    yield "cpu"
+    _lib._testing_restore()

@@ -1,0 +1,283 @@
+"""Kernel-level parity cases shared by the emulator tests (CPU, tiny shapes) and the GPU tests.
+
+Every case runs ONE C-ABI entry point through maest_amd.ops and compares it with the oracle
+(oracle/maest_oracle.py) or with the one-line torch definition of the op, in fp32 on the CPU.
+Tolerances: fp32 ("parity") mode 2e-5 relative unless stated; bf16 mode is checked against the
+same math evaluated on bf16-ROUNDED operands (so the only difference is accumulation order).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from maest_amd import ops
+from oracle import maest_oracle as O
+
+
+def rnd(shape, seed, scale=1.0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * np.float32(scale))
+
+
+def close(a, b, rtol, atol, what):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    lim = atol + rtol * b.abs()
+    bad = err > lim
+    assert not bool(bad.any()), (
+        f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; max err {err.max().item():.3e} "
+        f"(ref max {b.abs().max().item():.3e}); first bad index {tuple(int(i) for i in bad.nonzero()[0])}")
+
+
+def tol(dtype):
+    return (2e-5, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def case_gemm(dev, dtype, M, N, K, seed=0):
+    a = rnd((M, K), seed).to(dtype)
+    b = rnd((N, K), seed + 1).to(dtype)
+    bias = rnd((N,), seed + 2)
+    ref = a.float() @ b.float().t() + bias
+    rt, at = (1e-5, 1e-4) if dtype == torch.float32 else (1e-5, 1e-3)
+    c = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_dtype=torch.float32)
+    close(c, ref, rt, at * math.sqrt(K / 64), "gemm none")
+    # asymmetric A = I check of the output orientation
+    if M >= K and dtype == torch.float32:
+        eye = torch.zeros(M, K)
+        eye[:K, :K] = torch.eye(K)
+        c = ops.gemm_nt(eye.to(dev), b.to(dev), None, out_dtype=torch.float32)
+        close(c[:K], b.float().t(), 0, 1e-6, "gemm identity (transpose-detecting)")
+    # GELU epilogue with aux_out
+    aux = torch.empty((M, N), dtype=dtype, device=dev)
+    g = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_dtype=dtype, epi=ops.EPI_GELU, aux_out=aux)
+    rt2, at2 = tol(dtype)
+    close(aux, ref, rt2, at2 * math.sqrt(K / 64), "gemm gelu aux")
+    close(g, F.gelu(ref), rt2, at2 * math.sqrt(K / 64), "gemm gelu")
+    # residual epilogue
+    res = rnd((M, N), seed + 3)
+    c = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_dtype=torch.float32, epi=ops.EPI_RESIDUAL,
+                    aux_in=res.to(dev))
+    close(c, ref + res, rt, at * math.sqrt(K / 64), "gemm residual")
+    # dgelu epilogue
+    pre = rnd((M, N), seed + 4).to(dtype)
+    c = ops.gemm_nt(a.to(dev), b.to(dev), None, out_dtype=dtype, epi=ops.EPI_DGELU, aux_in=pre.to(dev))
+    x = pre.float().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    close(c, (ref - bias) * x.grad, rt2, at2 * math.sqrt(K / 64), "gemm dgelu")
+    # split-K atomic accumulate
+    acc = torch.zeros((M, N), dtype=torch.float32, device=dev)
+    ops.gemm_nt(a.to(dev), b.to(dev), None, out=acc, epi=ops.EPI_ATOMIC, split_k=3)
+    close(acc, ref - bias, rt, at * math.sqrt(K / 64), "gemm split-k")
+
+
+# ------------------------------------------------------------------------------------- transposes
+def case_transpose(dev, dtype, rows, cols):
+    src = rnd((rows, cols), 5).to(dtype)
+    ld = ops.round_up(rows, 64)
+    out = ops.transpose(src.to(dev), ld)
+    assert out.shape == (cols, ld)
+    close(out[:, :rows], src.t(), 0, 0, "transpose")
+    assert float(out[:, rows:].float().abs().sum()) == 0.0, "transpose pad must be zero"
+    w = rnd((rows, cols), 6)
+    d, dt_ = ops.cast_weights(w.to(dev), dtype, want=True, want_t=True)
+    close(d, w.to(dtype), 0, 0, "cast")
+    close(dt_, w.to(dtype).t(), 0, 0, "cast transposed")
+
+
+# --------------------------------------------------------------------------------------- LayerNorm
+def case_layernorm(dev, dtype, rows):
+    x = rnd((rows, 768), 7, 2.0) + 0.3
+    g = 1.0 + rnd((768,), 8, 0.1)
+    b = rnd((768,), 9, 0.1)
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev), 1e-6, dtype, save_stats=True)
+    ref = F.layer_norm(x, (768,), g, b, 1e-6)
+    rt, at = (1e-5, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    close(y, ref, rt, at, "layernorm fwd")
+    close(mean, x.mean(1), 1e-5, 1e-6, "layernorm mean")
+    close(rstd, 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-6), 1e-5, 1e-6, "layernorm rstd")
+    # backward
+    dy = rnd((rows, 768), 10).to(dtype)
+    dres = rnd((rows, 768), 11)
+    xr = x.clone().requires_grad_(True)
+    gr = g.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    F.layer_norm(xr, (768,), gr, br, 1e-6).backward(dy.float())
+    dg = torch.zeros(768, device=dev)
+    db = torch.zeros(768, device=dev)
+    dx, dx_lp = ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), mean, rstd, dres.to(dev), dg, db, lp_dtype=dtype)
+    close(dx, xr.grad + dres, 1e-4, 1e-5, "layernorm dx")
+    close(dx_lp, xr.grad + dres, *( (1e-4, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)), "layernorm dx_lp")
+    close(dg, gr.grad, 1e-4, 1e-4 * math.sqrt(rows), "layernorm dgamma")
+    close(db, br.grad, 1e-4, 1e-4 * math.sqrt(rows), "layernorm dbeta")
+
+
+# --------------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, B, N, scale):
+    q, k, v = qkv.reshape(B, N, 3, 12, 64).permute(2, 0, 3, 1, 4)
+    att = ((q @ k.transpose(-2, -1)) * scale).softmax(-1)
+    return (att @ v).transpose(1, 2).reshape(B * N, 768), torch.logsumexp((q @ k.transpose(-2, -1)) * scale, -1)
+
+
+def case_attention(dev, dtype, B, N, seed=20, spike=False):
+    qkv = rnd((B * N, 2304), seed, 1.0).to(dtype)
+    if spike:  # force a large running-max jump at a late key tile (online-softmax rescale branch)
+        qf = qkv.float().clone()
+        key = min(N - 1, 70)
+        qf[key, 768:768 + 64] = qf[3, 0:64] * 6.0
+        qkv = qf.to(dtype)
+    scale = 0.125
+    out, lse = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
+    x = qkv.float().requires_grad_(True)
+    ref, ref_lse = _attn_ref(x, B, N, scale)
+    rt, at = (2e-5, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+    close(out, ref, rt, at, "attention fwd")
+    close(lse, ref_lse, 1e-4, 1e-4 if dtype == torch.float32 else 2e-2, "attention lse")
+    # backward (the oracle's autograd on the same rounded operands)
+    dout = rnd((B * N, 768), seed + 1).to(dtype)
+    ref.backward(dout.float())
+    out_ref_lp = ref.detach().to(dtype)
+    dqkv = ops.attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
+    rt, at = (1e-4, 1e-4) if dtype == torch.float32 else (3e-2, 3e-2)
+    g = x.grad
+    close(dqkv[:, 1536:], g[:, 1536:], rt, at, "attention dV")
+    close(dqkv[:, 768:1536], g[:, 768:1536], rt, at, "attention dK")
+    close(dqkv[:, :768], g[:, :768], rt, at, "attention dQ")
+
+
+# ----------------------------------------------------------------------------- patch embed pieces
+def case_patch_embed(dev, dtype, B, T, patchout=0, mix=False, seed=30):
+    Fdim = 96
+    x = rnd((B, Fdim, T), seed)
+    Tp = (T - 16) // 10 + 1
+    Fp = 9
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    keep = np.sort(rng.permutation(Tp)[: Tp - patchout]).astype(np.int32) if patchout else None
+    Tk = Tp - patchout
+    t_idx = torch.from_numpy(keep).to(dev) if keep is not None else None
+    perm = lam = None
+    xm = x
+    if mix:
+        perm = torch.from_numpy(rng.permutation(B).astype(np.int32))
+        lam = torch.from_numpy(rng.random(B).astype(np.float32))
+        xm = O.mixup(x, perm.long(), lam)
+    cols = ops.patch_im2col(x.to(dev), Fp, Tk, dtype, t_idx=t_idx,
+                            perm=None if perm is None else perm.to(dev), lam=None if lam is None else lam.to(dev))
+    ref = F.unfold(xm.unsqueeze(1), kernel_size=16, stride=10)          # [B, 256, Fp*Tp]
+    ref = ref.reshape(B, 256, Fp, Tp)
+    if keep is not None:
+        ref = ref[:, :, :, torch.from_numpy(keep).long()]
+    ref = ref.permute(0, 2, 3, 1).reshape(B * Fp * Tk, 256)
+    close(cols, ref.to(dtype), 0, 1e-6 if dtype == torch.float32 else 0, "im2col")
+    # token assembly vs oracle.tokens_from_patches
+    Tt = 62 if T <= 640 else T // 10
+    sd = {"cls_token": rnd((1, 1, 768), 40, .02), "dist_token": rnd((1, 1, 768), 41, .02),
+          "new_pos_embed": rnd((1, 2, 768), 42, .02), "freq_new_pos_embed": rnd((1, 768, Fp, 1), 43, .02),
+          "time_new_pos_embed": rnd((1, 768, 1, Tt), 44, .02)}
+    toff = 0 if patchout == 0 else min(1, Tt - Tp)
+    conv = rnd((B, 768, Fp, Tp), 45)
+    want = O.tokens_from_patches(conv, sd, toffset=toff, t_keep=None if keep is None else keep.tolist())
+    convk = conv if keep is None else conv[:, :, :, torch.from_numpy(keep).long()]
+    patches = convk.permute(0, 2, 3, 1).reshape(B * Fp * Tk, 768).contiguous()
+    x0 = ops.token_assemble(patches.to(dev), sd["cls_token"].reshape(768).to(dev), sd["dist_token"].reshape(768).to(dev),
+                            sd["new_pos_embed"].reshape(2, 768).contiguous().to(dev),
+                            sd["freq_new_pos_embed"].reshape(768, Fp).contiguous().to(dev),
+                            sd["time_new_pos_embed"].reshape(768, Tt).contiguous().to(dev), toff, t_idx, B, Fp, Tk)
+    close(x0, want, 0, 1e-6, "token assemble")
+    # backward of token assembly
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    convg = conv.clone().requires_grad_(True)
+    dx0 = rnd(tuple(want.shape), 46)
+    O.tokens_from_patches(convg, sdg, toffset=toff, t_keep=None if keep is None else keep.tolist()).backward(dx0)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    d_cls, d_dist, d_np, d_fp, d_tp = z(768), z(768), z(2, 768), z(768, Fp), z(768, Tt)
+    dp = ops.token_assemble_bwd(dx0.to(dev), B, Fp, Tk, Tt, toff, t_idx, dtype, d_cls, d_dist, d_np, d_fp, d_tp)
+    gk = convg.grad if keep is None else convg.grad[:, :, :, torch.from_numpy(keep).long()]
+    close(dp, gk.permute(0, 2, 3, 1).reshape(B * Fp * Tk, 768), *((0, 1e-6) if dtype == torch.float32 else (1e-2, 1e-2)), "dpatches")
+    close(d_cls, sdg["cls_token"].grad.reshape(768), 1e-5, 1e-5, "d cls")
+    close(d_dist, sdg["dist_token"].grad.reshape(768), 1e-5, 1e-5, "d dist")
+    close(d_np, sdg["new_pos_embed"].grad.reshape(2, 768), 1e-5, 1e-5, "d new_pos")
+    close(d_fp, sdg["freq_new_pos_embed"].grad.reshape(768, Fp), 1e-4, 1e-4, "d freq_pos")
+    close(d_tp, sdg["time_new_pos_embed"].grad.reshape(768, Tt), 1e-4, 1e-4, "d time_pos")
+
+
+# ------------------------------------------------------------------------------------------- head
+def case_head(dev, B, N):
+    x = rnd((B, N, 768), 50, 1.5)
+    g = 1.0 + rnd((768,), 51, 0.1)
+    b = rnd((768,), 52, 0.1)
+    cls, dist, feat, mean, rstd = ops.head_pool_fwd(x.to(dev), g.to(dev), b.to(dev), 1e-6, save_stats=True)
+    xr = x.clone().requires_grad_(True)
+    gr = g.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    xn = F.layer_norm(xr, (768,), gr, br, 1e-6)
+    close(cls, xn[:, 0], 1e-5, 1e-5, "head cls")
+    close(dist, xn[:, 1], 1e-5, 1e-5, "head dist")
+    close(feat, (xn[:, 0] + xn[:, 1]) / 2, 1e-5, 1e-5, "head feat")
+    dc, dd, df = rnd((B, 768), 53), rnd((B, 768), 54), rnd((B, 768), 55)
+    ((xn[:, 0] * dc).sum() + (xn[:, 1] * dd).sum() + (((xn[:, 0] + xn[:, 1]) / 2) * df).sum()).backward()
+    dg = torch.zeros(768, device=dev)
+    db = torch.zeros(768, device=dev)
+    dx = ops.head_pool_bwd(dc.to(dev), dd.to(dev), df.to(dev), x.to(dev), g.to(dev), mean, rstd, dg, db)
+    close(dx, xr.grad, 1e-4, 1e-5, "head dx")
+    close(dg, gr.grad, 1e-4, 1e-4, "head dgamma")
+    close(db, br.grad, 1e-4, 1e-4, "head dbeta")
+    emb = ops.embed_pool(x.to(dev))
+    close(emb, torch.cat([x[:, 0], x[:, 1], x[:, 2:].mean(1)], 1), 1e-5, 1e-5, "embed pool")
+
+
+def case_loss(dev, rows, cols):
+    z = rnd((rows, cols), 60, 2.0)
+    rng = np.random.Generator(np.random.PCG64(61))
+    y = torch.from_numpy((rng.random((rows, cols)) < 0.1).astype(np.float32))
+    perm = torch.from_numpy(rng.permutation(rows).astype(np.int32))
+    lam = torch.from_numpy(rng.random(rows).astype(np.float32))
+    zr = z.clone().requires_grad_(True)
+    ym = O.mixup(y, perm.long(), lam)
+    ref = F.binary_cross_entropy_with_logits(zr, ym)
+    ref.backward()
+    loss, dz = ops.bce_logits(z.to(dev), y.to(dev), 1.0, perm.to(dev), lam.to(dev))
+    close(loss, ref.detach(), 1e-5, 1e-6, "bce loss")
+    close(dz, zr.grad, 1e-4, 1e-8, "bce dlogits")
+    loss2, _ = ops.bce_logits(z.to(dev), y.to(dev), 0.5)
+    close(loss2, 0.5 * F.binary_cross_entropy_with_logits(z, y), 1e-5, 1e-6, "bce weighted")
+    act = ops.sigmoid_mean(z.to(dev))
+    close(act, torch.sigmoid(z).mean(0), 1e-5, 1e-6, "sigmoid mean")
+    src = rnd((rows, cols), 62)
+    out = torch.zeros(cols, device=dev)
+    ops.colsum(src.to(dev), out)
+    close(out, src.sum(0), 1e-4, 1e-4, "colsum")
+    srcb = src.to(torch.bfloat16)
+    out = torch.zeros(cols, device=dev)
+    ops.colsum(srcb.to(dev), out)
+    close(out, srcb.float().sum(0), 1e-4, 1e-4, "colsum bf16")
+    v = rnd((1000,), 63)
+    w = ops.scale_(v.clone().to(dev), 0.25)
+    close(w, v * 0.25, 0, 0, "scale")
+
+
+def case_spec_mask(dev, B, T):
+    x = rnd((B, 96, T), 70)
+    rng = np.random.Generator(np.random.PCG64(71))
+    ts = np.stack([rng.integers(0, T - 8, (B, 5)), rng.integers(0, 8, (B, 5))], -1).astype(np.int32)
+    fs = np.stack([rng.integers(0, 96 - 5, (B, 3)), rng.integers(0, 5, (B, 3))], -1).astype(np.int32)
+    want = torch.stack([O.spec_masking(x[b], [tuple(p) for p in ts[b]], [tuple(p) for p in fs[b]]) for b in range(B)])
+    got = ops.spec_mask_(x.clone().to(dev), torch.from_numpy(ts).to(dev), torch.from_numpy(fs).to(dev))
+    close(got, want, 0, 0, "spec mask")
+
+
+def case_mel(dev, B, S, seed=80):
+    from maest_amd.melspectrogram import MelSpectrogram
+    rng = np.random.Generator(np.random.PCG64(seed))
+    w = torch.from_numpy((rng.random((B, S), dtype=np.float32) * 2 - 1) * 0.5)
+    mel = MelSpectrogram()
+    got = mel(w.to(dev))
+    want = O.logmel(w)
+    assert got.shape == want.shape == (B, 96, 1 + S // 256)
+    # north_star tolerance for floating point: 1e-3 relative (values are O(1) after log compression)
+    close(got, want, 1e-3, 1e-3, "logmel")
+    err = (got.cpu() - want).abs().max().item()
+    assert err < 2e-4, f"logmel max abs err {err}"

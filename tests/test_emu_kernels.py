@@ -1,0 +1,59 @@
+"""CPU (`-m "not gpu"`): run the SAME kernel sources under the SIMT lockstep emulator (tests/emu) at
+tiny shapes and compare with the oracle.  Checks index arithmetic, LDS layouts, MFMA fragment
+bookkeeping, tail masking and barrier placement -- not timing."""
+import pytest
+import torch
+
+from tests import kernel_cases as KC
+
+DT = [torch.float32, torch.bfloat16]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_emu_gemm(emu, dtype):
+    K = 64 if dtype == torch.float32 else 128
+    KC.case_gemm(emu, dtype, 150, 200, K)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_emu_transpose(emu, dtype):
+    KC.case_transpose(emu, dtype, 70, 130)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_emu_layernorm(emu, dtype):
+    KC.case_layernorm(emu, dtype, 11)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_emu_attention(emu, dtype):
+    KC.case_attention(emu, dtype, 1, 75)
+
+
+def test_emu_attention_multi_tile_spike(emu):
+    KC.case_attention(emu, torch.float32, 1, 140, spike=True)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_emu_patch_embed(emu, dtype):
+    KC.case_patch_embed(emu, dtype, 2, 66, patchout=2, mix=True)
+
+
+def test_emu_patch_embed_eval(emu):
+    KC.case_patch_embed(emu, torch.float32, 1, 56)
+
+
+def test_emu_head(emu):
+    KC.case_head(emu, 3, 7)
+
+
+def test_emu_loss(emu):
+    KC.case_loss(emu, 6, 50)
+
+
+def test_emu_spec_mask(emu):
+    KC.case_spec_mask(emu, 2, 40)
+
+
+def test_emu_mel(emu):
+    KC.case_mel(emu, 1, 2560)

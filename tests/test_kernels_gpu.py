@@ -1,0 +1,62 @@
+"""GPU (`-m gpu`): every C-ABI kernel vs the oracle on a real MI355X, at the shapes the model uses."""
+import pytest
+import torch
+
+from tests import kernel_cases as KC
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float32, torch.bfloat16]
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(1120, 2304, 768), (562, 768, 3072), (300, 400, 768), (2 * 9 * 32, 768, 256)])
+def test_gemm(dtype, shape):
+    KC.case_gemm(DEV, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_transpose(dtype):
+    KC.case_transpose(DEV, dtype, 1121, 768)
+    KC.case_transpose(DEV, dtype, 562, 3072)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_layernorm(dtype):
+    KC.case_layernorm(DEV, dtype, 1123)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("BN", [(2, 560), (3, 281), (1, 875), (1, 64), (1, 129)])
+def test_attention(dtype, BN):
+    KC.case_attention(DEV, dtype, *BN)
+
+
+def test_attention_rescale_branch():
+    KC.case_attention(DEV, torch.float32, 1, 290, spike=True)
+    KC.case_attention(DEV, torch.bfloat16, 1, 290, spike=True)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_patch_embed(dtype):
+    KC.case_patch_embed(DEV, dtype, 3, 626, patchout=30, mix=True)
+    KC.case_patch_embed(DEV, dtype, 2, 625)
+
+
+def test_head():
+    KC.case_head(DEV, 5, 281)
+
+
+def test_loss():
+    KC.case_loss(DEV, 64, 400)
+    KC.case_loss(DEV, 7, 519)
+
+
+def test_spec_mask():
+    KC.case_spec_mask(DEV, 4, 626)
+
+
+def test_mel():
+    KC.case_mel(DEV, 2, 160000)
+    KC.case_mel(DEV, 1, 480000, seed=81)
+    KC.case_mel(DEV, 1, 5000, seed=82)
