@@ -1,0 +1,637 @@
+"""MAEST (patchout audio-spectrogram transformer) with the reference's Python surface and an
+MI355X-native execution engine underneath.
+
+Drop-in surface (reference file:line, paths relative to palonso/MAEST):
+  * ``get_maest(arch, ...)``                      models/maest.py:1467-1569
+  * ``MAEST.forward(x, transformer_block=-1, return_self_attention=False,
+                    melspectrogram_input=False)``  models/maest.py:831-933
+  * ``MAEST.predict_labels(x)``                   models/maest.py:935-939
+  * state_dict names / shapes                     models/maest.py:516-530, 537-553, 570-582
+  * exception contract                            models/maest.py:855-861, 664-668, 1530
+
+What is different: no tensor op of the hot path is dispatched to torch.  ``forward`` drives the
+hand-written gfx950 kernels of libmaest_hip.so (C ABI: include/maest_hip.h) through ctypes;
+PyTorch only owns the device memory, the stream and -- in training -- the autograd edge
+(one ``torch.autograd.Function`` spanning the whole network, whose backward runs the hand-written
+backward kernels and hands fp32 parameter gradients to the optimizer).
+
+Numeric modes (``model.precision``):
+  "fp32"  parity mode: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere; matches the reference's
+          fp32 CPU path to ~1e-5 (gate: 1e-3 relative, identical top-k labels);
+  "bf16"  perf mode: bf16 MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm /
+          softmax / GELU (the reference trains under fp16 autocast, ex_maest.py:51);
+  "auto"  (default) fp32 when ``model.training`` is False, bf16 when it is True.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import warnings
+from functools import partial
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .labels import discogs_400labels, discogs_519labels
+from .melspectrogram import MelSpectrogram
+
+_logger = logging.getLogger("MAEST")
+
+EMBED_DIM = 768
+DEPTH = 12
+NUM_HEADS = 12
+PATCH = 16
+
+
+# --------------------------------------------------------------------------------------
+# parameter containers (same module tree / state_dict keys as the reference; these modules
+# only HOLD parameters -- their torch forward() is never called on the hot path)
+# --------------------------------------------------------------------------------------
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=12, qkv_bias=True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, eps=1e-6):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+
+class PatchEmbed(nn.Module):
+    """Parameter holder + geometry of the 16x16 / stride-10 patch embedding (maest.py:214-256)."""
+
+    def __init__(self, img_size, patch_size=16, stride=10, in_chans=1, embed_dim=768):
+        super().__init__()
+        self.img_size = tuple(img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.stride = tuple(stride) if isinstance(stride, (tuple, list)) else (stride, stride)
+        self.grid_size = (img_size[0] // self.stride[0], img_size[1] // self.stride[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.flatten = False
+        self.embed_dim = embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.stride)
+
+
+def _init_vit_weights(module: nn.Module):
+    """maest.py:942-976 as reached through ``self.apply`` (name == ""): trunc-normal(.02) Linear
+    weights (the head included), zero biases, LayerNorm ones/zeros, Conv2d left at torch default."""
+    if isinstance(module, nn.Linear):
+        nn.init.trunc_normal_(module.weight, std=0.02, a=-2.0, b=2.0)
+        if module.bias is not None:
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, nn.LayerNorm):
+        nn.init.zeros_(module.bias)
+        nn.init.ones_(module.weight)
+
+
+# --------------------------------------------------------------------------------------
+# the execution engine
+# --------------------------------------------------------------------------------------
+class _Weights:
+    """Operand-dtype copies of the fp32 master parameters (and their transposes for dgrad),
+    rebuilt only when a parameter's version counter moves (i.e. after an optimizer step)."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, p: torch.Tensor, dtype, transposed=False, pad_cols_to: int = 0):
+        key = (id(p), dtype, transposed, pad_cols_to)
+        ver = p._version
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == ver and hit[1].device == p.device:
+            return hit[1]
+        src = p.detach()
+        w2 = src.reshape(src.shape[0], -1)
+        if not transposed:
+            if dtype == torch.float32:
+                out = w2
+            else:
+                out, _ = ops.cast_weights(w2, dtype, want=True, want_t=False)
+        else:
+            if pad_cols_to:
+                lp = w2 if dtype == torch.float32 else ops.cast_weights(w2, dtype)[0]
+                out = ops.transpose(lp, ops.round_up(w2.shape[0], pad_cols_to))
+            else:
+                _, out = ops.cast_weights(w2, dtype, want=False, want_t=True)
+        self._cache[key] = (ver, out)
+        return out
+
+    def clear(self):
+        self._cache.clear()
+
+
+def _split_k(n_out: int, k_out: int, mpad: int) -> int:
+    tiles = math.ceil(n_out / 128) * math.ceil(k_out / 128)
+    return max(1, min(1024 // tiles, mpad // 64))
+
+
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int) -> torch.Tensor:
+    """dW[n_out, k_out] = dy[M, n_out]^T @ x[M, k_out]  (fp32) via transposed operands + split-K."""
+    M = dy.shape[0]
+    mpad = ops.round_up(M, 64)
+    dyt = ops.transpose(dy, mpad)
+    xt = ops.transpose(x, mpad)
+    dw = torch.zeros((n_out, k_out), dtype=torch.float32, device=dy.device)
+    ops.gemm_nt(dyt, xt, None, out=dw, epi=ops.EPI_ATOMIC, split_k=_split_k(n_out, k_out, mpad), M=n_out, N=k_out,
+                K=mpad)
+    return dw
+
+
+def _bias_grad(dy: torch.Tensor, n: int) -> torch.Tensor:
+    g = torch.zeros(n, dtype=torch.float32, device=dy.device)
+    ops.colsum(dy, g)
+    return g
+
+
+class _Engine:
+    """Forward / backward of the whole network as a fixed sequence of C-ABI kernel launches."""
+
+    def __init__(self, model: "MAEST"):
+        self.m = model
+        self.w = _Weights()
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, x3: torch.Tensor, dt, *, toffset: int, t_idx: Optional[torch.Tensor], perm, lam,
+                stop_block: int = -1, return_self_attention: bool = False, save: bool = False):
+        """x3: fp32 [B, F, T] on the device.  Returns (outputs, ctx)."""
+        m, W = self.m, self.w
+        B, F, T = x3.shape
+        Fp = (F - PATCH) // m.patch_embed.stride[0] + 1
+        Tp = (T - PATCH) // m.patch_embed.stride[1] + 1
+        Tk = Tp if t_idx is None else int(t_idx.numel())
+        N = 2 + Fp * Tk
+        M = B * N
+        ctx = {"B": B, "N": N, "Fp": Fp, "Tk": Tk, "toffset": toffset, "t_idx": t_idx, "dt": dt} if save else None
+
+        cols = ops.patch_im2col(x3, Fp, Tk, dt, t_idx=t_idx, perm=perm, lam=lam)
+        patches = ops.gemm_nt(cols, W.get(m.patch_embed.proj.weight, dt), m.patch_embed.proj.bias,
+                              out_dtype=torch.float32)
+        Tt = m.time_new_pos_embed.shape[-1]
+        x = ops.token_assemble(patches, m.cls_token.reshape(-1), m.dist_token.reshape(-1),
+                               m.new_pos_embed.reshape(2, EMBED_DIM), m.freq_new_pos_embed.reshape(EMBED_DIM, -1),
+                               m.time_new_pos_embed.reshape(EMBED_DIM, Tt), toffset, t_idx, B, Fp, Tk)
+        x = x.reshape(M, EMBED_DIM)
+        if save:
+            ctx["cols"] = cols
+            ctx["blocks"] = []
+        scale = m.blocks[0].attn.scale
+        nblocks = len(m.blocks) if stop_block < 0 else stop_block + 1
+        for i in range(nblocks):
+            blk = m.blocks[i]
+            r = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, dt, save_stats=save)
+            ln1, mean1, rstd1 = r if save else (r, None, None)
+            qkv = ops.gemm_nt(ln1, W.get(blk.attn.qkv.weight, dt), blk.attn.qkv.bias, out_dtype=dt)
+            r = ops.attn_fwd(qkv, B, N, scale, save_lse=save)
+            ao, lse = r if save else (r, None)
+            if i == stop_block and return_self_attention:
+                # Block.forward(..., return_self_attention=True) returns attn(norm1(x)) (maest.py:414-416)
+                a = ops.gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=torch.float32)
+                return ops.embed_pool(a.reshape(B, N, EMBED_DIM)), None
+            x1 = ops.gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=torch.float32,
+                             epi=ops.EPI_RESIDUAL, aux_in=x)
+            r = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save_stats=save)
+            ln2, mean2, rstd2 = r if save else (r, None, None)
+            h = torch.empty((M, blk.mlp.fc1.out_features), dtype=dt, device=x.device) if save else None
+            g = ops.gemm_nt(ln2, W.get(blk.mlp.fc1.weight, dt), blk.mlp.fc1.bias, out_dtype=dt, epi=ops.EPI_GELU,
+                            aux_out=h)
+            x2 = ops.gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=torch.float32,
+                             epi=ops.EPI_RESIDUAL, aux_in=x1)
+            if save:
+                ctx["blocks"].append(dict(x=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse, x1=x1,
+                                          mean2=mean2, rstd2=rstd2, ln2=ln2, h=h, g=g))
+            x = x2
+        xb = x.reshape(B, N, EMBED_DIM)
+        if stop_block >= 0:
+            return ops.embed_pool(xb), None
+        r = ops.head_pool_fwd(xb, m.norm.weight, m.norm.bias, m.norm.eps, save_stats=save)
+        cls, dist, feat = r[:3]
+        hn, hw = m.head[0], m.head[1]
+        if m.distilled_type == "mean":
+            r2 = ops.layernorm_fwd(feat, hn.weight, hn.bias, hn.eps, dt, save_stats=save)
+            hl, hmean, hrstd = r2 if save else (r2, None, None)
+            logits = ops.gemm_nt(hl, W.get(hw.weight, dt), hw.bias, out_dtype=torch.float32)
+            outs = (logits, feat)
+        elif m.distilled_type == "separated":
+            r2 = ops.layernorm_fwd(cls, hn.weight, hn.bias, hn.eps, dt, save_stats=save)
+            hl, hmean, hrstd = r2 if save else (r2, None, None)
+            logits = ops.gemm_nt(hl, W.get(hw.weight, dt), hw.bias, out_dtype=torch.float32)
+            dlp = dist if dt == torch.float32 else ops.cast_weights(dist, dt)[0]
+            logits_d = ops.gemm_nt(dlp, W.get(m.head_dist.weight, dt), m.head_dist.bias, out_dtype=torch.float32)
+            outs = (logits, logits_d, feat)
+            if save:
+                ctx["dist_lp"] = dlp
+        else:
+            raise NotImplementedError(f"distilled_type={m.distilled_type!r}")
+        if save:
+            ctx.update(x_final=xb, fmean=r[3], frstd=r[4], cls=cls, dist=dist, feat=feat, hl=hl, hmean=hmean,
+                       hrstd=hrstd)
+        return outs, ctx
+
+    # ---- backward ---------------------------------------------------------------------------
+    def backward(self, ctx, grads_out):
+        """grads_out: gradients w.r.t. the forward outputs (same tuple structure, entries may be None).
+        Returns {parameter name: fp32 gradient}."""
+        m, W = self.m, self.w
+        dt, B, N, Fp, Tk = ctx["dt"], ctx["B"], ctx["N"], ctx["Fp"], ctx["Tk"]
+        M = B * N
+        dev = ctx["x_final"].device
+        G = {}
+        zeros = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        C = m.head[1].out_features
+        cpad = ops.round_up(C, 64)
+        hn, hw = m.head[0], m.head[1]
+
+        def lp_padded(d):  # fp32 [B, C] -> operand dtype [B, cpad], zero padded (K of the dgrad GEMM)
+            buf = torch.zeros((B, cpad), dtype=dt, device=dev)
+            buf[:, :C] = d
+            return buf
+
+        def head_linear_bwd(dlogits, inp_lp, lin, prefix):
+            dl = lp_padded(dlogits)
+            G[prefix + ".weight"] = _wgrad(dl[:, :C], inp_lp, C, EMBED_DIM)
+            G[prefix + ".bias"] = _bias_grad(dlogits, C)
+            wt = W.get(lin.weight, dt, transposed=True, pad_cols_to=64)          # [768, cpad]
+            return ops.gemm_nt(dl, wt, None, out_dtype=dt, M=B, N=EMBED_DIM, K=cpad)
+
+        d_cls = d_dist = None
+        G["head.0.weight"], G["head.0.bias"] = zeros(EMBED_DIM), zeros(EMBED_DIM)
+        if m.distilled_type == "mean":
+            dlogits, dfeat_out = grads_out
+            dfeat = None
+            if dlogits is not None:
+                dhl = head_linear_bwd(dlogits.contiguous(), ctx["hl"], hw, "head.1")
+                dres = None if dfeat_out is None else dfeat_out.contiguous()
+                dfeat, _ = ops.layernorm_bwd(dhl, ctx["feat"], hn.weight, ctx["hmean"], ctx["hrstd"], dres,
+                                             G["head.0.weight"], G["head.0.bias"])
+            elif dfeat_out is not None:
+                dfeat = dfeat_out.contiguous()
+        else:
+            dlogits, dlogits_d, dfeat_out = grads_out
+            dfeat = None if dfeat_out is None else dfeat_out.contiguous()
+            if dlogits is not None:
+                dhl = head_linear_bwd(dlogits.contiguous(), ctx["hl"], hw, "head.1")
+                d_cls, _ = ops.layernorm_bwd(dhl, ctx["cls"], hn.weight, ctx["hmean"], ctx["hrstd"], None,
+                                             G["head.0.weight"], G["head.0.bias"])
+            if dlogits_d is not None:
+                dd = head_linear_bwd(dlogits_d.contiguous(), ctx["dist_lp"], m.head_dist, "head_dist")
+                d_dist = dd if dt == torch.float32 else dd.float()
+        G["norm.weight"], G["norm.bias"] = zeros(EMBED_DIM), zeros(EMBED_DIM)
+        dx = ops.head_pool_bwd(d_cls, d_dist, dfeat, ctx["x_final"], m.norm.weight, ctx["fmean"], ctx["frstd"],
+                               G["norm.weight"], G["norm.bias"]).reshape(M, EMBED_DIM)
+        dx_lp = dx if dt == torch.float32 else ops.cast_weights(dx, dt)[0]
+
+        for i in reversed(range(len(m.blocks))):
+            blk, s = m.blocks[i], ctx["blocks"][i]
+            p = f"blocks.{i}."
+            H = blk.mlp.fc1.out_features
+            # fc2 (+ residual):  x2 = x1 + g W2^T + b2
+            G[p + "mlp.fc2.bias"] = _bias_grad(dx_lp, EMBED_DIM)
+            G[p + "mlp.fc2.weight"] = _wgrad(dx_lp, s["g"], EMBED_DIM, H)
+            dh = ops.gemm_nt(dx_lp, W.get(blk.mlp.fc2.weight, dt, transposed=True), None, out_dtype=dt,
+                             epi=ops.EPI_DGELU, aux_in=s["h"])
+            # fc1
+            G[p + "mlp.fc1.bias"] = _bias_grad(dh, H)
+            G[p + "mlp.fc1.weight"] = _wgrad(dh, s["ln2"], H, EMBED_DIM)
+            dln2 = ops.gemm_nt(dh, W.get(blk.mlp.fc1.weight, dt, transposed=True), None, out_dtype=dt)
+            G[p + "norm2.weight"], G[p + "norm2.bias"] = zeros(EMBED_DIM), zeros(EMBED_DIM)
+            dx1, dx1_lp = ops.layernorm_bwd(dln2, s["x1"], blk.norm2.weight, s["mean2"], s["rstd2"], dx,
+                                            G[p + "norm2.weight"], G[p + "norm2.bias"],
+                                            lp_dtype=None if dt == torch.float32 else dt)
+            if dt == torch.float32:
+                dx1_lp = dx1
+            # proj (+ residual)
+            G[p + "attn.proj.bias"] = _bias_grad(dx1_lp, EMBED_DIM)
+            G[p + "attn.proj.weight"] = _wgrad(dx1_lp, s["ao"], EMBED_DIM, EMBED_DIM)
+            dao = ops.gemm_nt(dx1_lp, W.get(blk.attn.proj.weight, dt, transposed=True), None, out_dtype=dt)
+            dqkv = ops.attn_bwd(s["qkv"], s["ao"], dao, s["lse"], B, N, blk.attn.scale)
+            G[p + "attn.qkv.bias"] = _bias_grad(dqkv, 3 * EMBED_DIM)
+            G[p + "attn.qkv.weight"] = _wgrad(dqkv, s["ln1"], 3 * EMBED_DIM, EMBED_DIM)
+            dln1 = ops.gemm_nt(dqkv, W.get(blk.attn.qkv.weight, dt, transposed=True), None, out_dtype=dt)
+            G[p + "norm1.weight"], G[p + "norm1.bias"] = zeros(EMBED_DIM), zeros(EMBED_DIM)
+            dx, dx_lp = ops.layernorm_bwd(dln1, s["x"], blk.norm1.weight, s["mean1"], s["rstd1"], dx1,
+                                          G[p + "norm1.weight"], G[p + "norm1.bias"],
+                                          lp_dtype=None if dt == torch.float32 else dt)
+            if dt == torch.float32:
+                dx_lp = dx
+            s.clear()  # release this block's activations
+
+        Tt = m.time_new_pos_embed.shape[-1]
+        d_cls_t, d_dist_t, d_np = zeros(EMBED_DIM), zeros(EMBED_DIM), zeros(2, EMBED_DIM)
+        d_fp, d_tp = zeros(EMBED_DIM, Fp), zeros(EMBED_DIM, Tt)
+        dpatch = ops.token_assemble_bwd(dx, B, Fp, Tk, Tt, ctx["toffset"], ctx["t_idx"], dt, d_cls_t, d_dist_t, d_np,
+                                        d_fp, d_tp)
+        G["cls_token"] = d_cls_t.reshape(1, 1, EMBED_DIM)
+        G["dist_token"] = d_dist_t.reshape(1, 1, EMBED_DIM)
+        G["new_pos_embed"] = d_np.reshape(1, 2, EMBED_DIM)
+        G["freq_new_pos_embed"] = d_fp.reshape(1, EMBED_DIM, Fp, 1)
+        G["time_new_pos_embed"] = d_tp.reshape(1, EMBED_DIM, 1, Tt)
+        G["patch_embed.proj.bias"] = _bias_grad(dpatch, EMBED_DIM)
+        G["patch_embed.proj.weight"] = _wgrad(dpatch, ctx["cols"], EMBED_DIM, PATCH * PATCH).reshape(
+            m.patch_embed.proj.weight.shape)
+        return G
+
+
+class _MaestFn(torch.autograd.Function):
+    """The single autograd edge: forward = _Engine.forward(save=True); backward = _Engine.backward."""
+
+    @staticmethod
+    def forward(ctx, model, x3, dt, kw, names, *params):
+        outs, saved = model._engine.forward(x3, dt, save=True, **kw)
+        ctx.saved = saved
+        ctx.model = model
+        ctx.names = names
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gout):
+        if ctx.saved is None:
+            raise RuntimeError("maest_amd: backward called twice (activations are released after the first pass)")
+        G = ctx.model._engine.backward(ctx.saved, gout)
+        ctx.saved = None
+        grads = []
+        for n, p in zip(ctx.names, ctx.model._param_list):
+            g = G.get(n)
+            if g is not None and g.shape != p.shape:
+                g = g.reshape(p.shape)
+            grads.append(g)
+        return (None, None, None, None, None, *grads)
+
+
+class MAEST(nn.Module):
+    """Music Audio Efficient Spectrogram Transformer (reference class: models/maest.py:423-939)."""
+
+    def __init__(self, u_patchout=0, s_patchout_t=0, s_patchout_f=0, s_patchout_f_indices=(),
+                 s_patchout_f_interleaved=0, s_patchout_t_indices=(), s_patchout_t_interleaved=0,
+                 img_size=(96, 625), patch_size=16, stride=10, in_chans=1, num_classes=400, embed_dim=768,
+                 depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True, distilled=True, distilled_type="mean",
+                 precision="auto"):
+        super().__init__()
+        if embed_dim != EMBED_DIM or num_heads != NUM_HEADS or patch_size != PATCH or in_chans != 1:
+            raise NotImplementedError("maest_amd kernels are specialised for the MAEST geometry: "
+                                      "embed_dim=768, 12 heads x 64, 16x16 patches, mono input")
+        if not distilled:
+            raise NotImplementedError("every MAEST architecture is DeiT-distilled (cls + dist tokens)")
+        for name, v in (("u_patchout", u_patchout), ("s_patchout_f", s_patchout_f),
+                        ("s_patchout_f_indices", s_patchout_f_indices),
+                        ("s_patchout_f_interleaved", s_patchout_f_interleaved),
+                        ("s_patchout_t_indices", s_patchout_t_indices),
+                        ("s_patchout_t_interleaved", s_patchout_t_interleaved)):
+            if v:
+                raise NotImplementedError(
+                    f"{name}: only structured TIME patchout (s_patchout_t) is implemented in maest_amd; "
+                    "none of the reference's named configs uses the other variants")
+        self.num_classes = num_classes
+        self.u_patchout = u_patchout
+        self.img_size = tuple(img_size)
+        self.s_patchout_t = s_patchout_t
+        self.s_patchout_f = s_patchout_f
+        self.s_patchout_f_indices = s_patchout_f_indices
+        self.s_patchout_f_interleaved = s_patchout_f_interleaved
+        self.s_patchout_t_indices = s_patchout_t_indices
+        self.s_patchout_t_interleaved = s_patchout_t_interleaved
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 2
+        self.distilled_type = distilled_type
+        self.precision = precision
+        if num_classes == 400:
+            self.labels = discogs_400labels
+        elif num_classes == 519:
+            self.labels = discogs_519labels
+
+        stride = tuple(stride) if isinstance(stride, (tuple, list)) else (stride, stride)
+        if stride != (10, 10):
+            raise NotImplementedError("maest_amd kernels are specialised for patch stride (10, 10)")
+        self.patch_embed = PatchEmbed(img_size=self.img_size, patch_size=patch_size, stride=stride,
+                                      in_chans=in_chans, embed_dim=embed_dim)
+        self.num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.new_pos_embed = nn.Parameter(torch.zeros(1, self.num_tokens, embed_dim))
+        self.freq_new_pos_embed = nn.Parameter(torch.zeros(1, embed_dim, self.patch_embed.grid_size[0], 1))
+        self.time_new_pos_embed = nn.Parameter(torch.zeros(1, embed_dim, 1, self.patch_embed.grid_size[1]))
+        self.blocks = nn.Sequential(*[Block(embed_dim, num_heads, mlp_ratio, qkv_bias, eps=1e-6)
+                                      for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.pre_logits = nn.Identity()
+        self.head = nn.Sequential(nn.LayerNorm(self.num_features),
+                                  nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity())
+        self.head_dist = nn.Linear(self.embed_dim, self.num_classes) if num_classes > 0 else nn.Identity()
+        self.init_weights()
+        self.melspectrogram = MelSpectrogram()
+        self._engine = _Engine(self)
+        self._param_names = None
+        self._param_list = None
+
+    # ---- reference API odds and ends --------------------------------------------------------
+    def init_weights(self, mode=""):
+        assert mode in ("jax", "jax_nlhb", "nlhb", "")
+        for p in (self.new_pos_embed, self.freq_new_pos_embed, self.time_new_pos_embed, self.dist_token,
+                  self.cls_token):
+            nn.init.trunc_normal_(p, std=0.02, a=-2.0, b=2.0)
+        self.apply(_init_vit_weights)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"new_pos_embed", "freq_new_pos_embed", "time_new_pos_embed", "cls_token", "dist_token"}
+
+    def get_classifier(self):
+        return self.head, self.head_dist
+
+    def _compute_dtype(self):
+        p = self.precision
+        if p == "auto":
+            p = "bf16" if self.training else "fp32"
+        if p in ("fp32", "float32"):
+            return torch.float32
+        if p in ("bf16", "bfloat16"):
+            return torch.bfloat16
+        raise ValueError(f"precision must be 'auto', 'fp32' or 'bf16', got {self.precision!r}")
+
+    # ---- input handling (maest.py:855-895) --------------------------------------------------
+    def _prepare_input(self, x, melspectrogram_input):
+        assert isinstance(x, torch.Tensor), "Input must be a torch.Tensor"
+        assert x.nelement() > 0, "Input tensor must not be empty"
+        if len(x.shape) == 1:
+            assert melspectrogram_input is False, (
+                "Input is 1D, but melspectrogram_input is True. This is not supported.")
+            self._check_audio_len(x.shape[-1], chunked=True)
+            x = self.melspectrogram(x)
+            if x.shape[1] >= self.img_size[1]:
+                trim = x.shape[1] % self.img_size[1]
+                if trim:
+                    x = x[:, :-trim]
+                x = x.reshape(self.img_size[0], 1, -1, self.img_size[1])
+                x = torch.swapaxes(x, 0, 2)
+            else:
+                x = x.reshape(1, 1, x.shape[0], x.shape[1])
+        elif len(x.shape) == 2 and melspectrogram_input:
+            trim = x.shape[1] % self.img_size[1]
+            if trim:
+                x = x[:, :-trim]
+            x = x.reshape(self.img_size[0], 1, -1, self.img_size[1])
+            x = torch.swapaxes(x, 0, 2)
+        elif len(x.shape) == 2 and not melspectrogram_input:
+            self._check_audio_len(x.shape[-1], chunked=False)
+            x = self.melspectrogram(x)
+            x.unsqueeze_(1)
+        elif len(x.shape) == 3:
+            x.unsqueeze_(1)  # in place, like the reference (maest.py:895): the caller's tensor becomes 4-D
+        return x
+
+    def _check_patches_fit(self, T):
+        Tp = (T - PATCH) // self.patch_embed.stride[1] + 1
+        table = self.time_new_pos_embed.shape[-1]
+        if Tp > table:
+            raise Exception(
+                f"the patches shape:{(EMBED_DIM, self.patch_embed.grid_size[0], Tp)} are larger than the expected "
+                f"time encodings {tuple(self.time_new_pos_embed.shape)}, please reduce the input duration.")
+        return Tp
+
+    def _check_audio_len(self, S, chunked):
+        # Same exception the reference raises from forward_features (maest.py:664-668), detected before
+        # any device work: un-chunked audio whose mel is longer than the time positional table.
+        if not chunked:
+            self._check_patches_fit(1 + S // MelSpectrogram.hop_len)
+
+    def _draw_train_indices(self, Tp):
+        """The reference's RNG draws, same generators, same order (maest.py:648-650, 684-686)."""
+        table = self.time_new_pos_embed.shape[-1]
+        toffset = torch.randint(1 + table - Tp, (1,)).item()
+        t_idx = None
+        if self.s_patchout_t:
+            t_idx = torch.randperm(Tp)[: Tp - self.s_patchout_t].sort().values
+        return toffset, t_idx
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, x, transformer_block: int = -1, return_self_attention: bool = False,
+                melspectrogram_input: bool = False, *, _mixup=None, _patchout=None
+                ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+        """Same contract as the reference's ``MAEST.forward`` (maest.py:831-933).
+
+        ``_mixup=(perm, lam)`` and ``_patchout=(toffset, t_idx)`` are private hooks used by
+        ``maest_amd.module.Module.training_step`` (fused mixup) and by the parity tests (pinned draws)."""
+        x = self._prepare_input(x, melspectrogram_input)
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise Exception(f"expected input of shape [B, 1, F, T], got {tuple(x.shape)}")
+        B, _, F, T = x.shape
+        Tp = self._check_patches_fit(T)
+        if not x.is_cuda and not ops._lib.host_emulation():
+            raise ops._lib.MaestHipError(
+                f"maest_amd runs on MI355X only: input is on {x.device}. Move the model and the input to a HIP "
+                "device (model.cuda(); x.cuda()). There is no CPU fallback.")
+        x3 = x.reshape(B, F, T)
+        if x3.dtype != torch.float32:
+            x3 = x3.float()
+        x3 = x3.contiguous()
+        dt = self._compute_dtype()
+
+        toffset, t_idx = 0, None
+        if _patchout is not None:
+            toffset, t_idx = _patchout
+        elif self.training:
+            toffset, t_idx = self._draw_train_indices(Tp)
+        if t_idx is not None:
+            t_idx = torch.as_tensor(t_idx).to(device=x3.device, dtype=torch.int32).contiguous()
+        perm = lam = None
+        if _mixup is not None:
+            perm, lam = _mixup
+            perm = perm.to(device=x3.device, dtype=torch.int32).contiguous()
+            lam = lam.to(device=x3.device, dtype=torch.float32).contiguous()
+        kw = dict(toffset=int(toffset), t_idx=t_idx, perm=perm, lam=lam)
+
+        if transformer_block != -1:
+            with torch.no_grad():
+                emb, _ = self._engine.forward(x3, dt, stop_block=transformer_block,
+                                              return_self_attention=return_self_attention, **kw)
+            return None, emb
+
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if need_grad:
+            if self._param_names is None:
+                named = list(self.named_parameters())
+                self._param_names = [n for n, _ in named]
+                self._param_list = [p for _, p in named]
+            outs = _MaestFn.apply(self, x3, dt, kw, self._param_names, *self._param_list)
+        else:
+            with torch.no_grad():
+                outs, _ = self._engine.forward(x3, dt, **kw)
+        return outs
+
+    def predict_labels(self, x):
+        logits = self.forward(x)[0]
+        activations = ops.sigmoid_mean(logits.detach().contiguous())
+        return activations.cpu().numpy(), self.labels
+
+
+# --------------------------------------------------------------------------------------
+# architecture registry + factory (models/maest.py:1151-1388, 1467-1569)
+# --------------------------------------------------------------------------------------
+_ARCH_DEFAULT_T = {
+    "passt_deit_bd_p16_384": 998,
+    "passt_s_swa_p16_128_ap476": 998,
+    "discogs-maest-10s-fs-129e": 625,
+    "discogs-maest-10s-pw-129e": 625,
+    "discogs-maest-10s-dw-75e": 625,
+    "discogs-maest-5s-pw-129e": 312,
+    "discogs-maest-20s-pw-129e": 1250,
+    "discogs-maest-30s-pw-129e": 1875,
+    "discogs-maest-30s-pw-73e-ts": 1875,
+    "discogs-maest-30s-pw-129e-519l": 1875,
+}
+
+
+def get_maest(arch, pretrained: bool = True, n_classes: int = 400, in_channels: int = 1, stride_f: int = 10,
+              stride_t: int = 10, input_f: int = 96, input_t: int = None, u_patchout: int = 0, s_patchout_t: int = 0,
+              s_patchout_f: int = 0, s_patchout_f_indices: tuple = (), s_patchout_f_interleaved: int = 0,
+              s_patchout_t_indices: tuple = (), s_patchout_t_interleaved: int = 0, distilled_type: str = "mean",
+              checkpoint: str = None, checkpoint_swa_weigts: bool = True, checkpoint_discard_head: bool = False,
+              precision: str = "auto"):
+    """Same signature and semantics as the reference factory (models/maest.py:1467-1569), plus
+    ``precision`` (see the module docstring).  Returns the model in train mode, like the reference."""
+    if arch not in _ARCH_DEFAULT_T:
+        raise NotImplementedError(f"model {arch} not implemented")
+    if pretrained:
+        raise RuntimeError(
+            "pretrained=True downloads release checkpoints over the network (reference: timm load_pretrained, "
+            "models/helpers/vit_helpers.py:257-267), which this build does not do. Use pretrained=False and "
+            "checkpoint=<local .ckpt>.")
+    if not input_t:
+        input_t = _ARCH_DEFAULT_T[arch]
+    if (stride_f, stride_t) != (10, 10):
+        warnings.warn(f"This model was pre-trained with strides {(10, 10)}, but now you set (fstride,tstride) "
+                      f"to {(stride_f, stride_t)}.")
+    if arch == "discogs-maest-30s-pw-129e-519l" and n_classes != 519:
+        _logger.debug("Forcing `num_classes` to 519")
+        n_classes = 519
+    model = MAEST(u_patchout=u_patchout, s_patchout_t=s_patchout_t, s_patchout_f=s_patchout_f,
+                  s_patchout_f_indices=s_patchout_f_indices, s_patchout_f_interleaved=s_patchout_f_interleaved,
+                  s_patchout_t_indices=s_patchout_t_indices, s_patchout_t_interleaved=s_patchout_t_interleaved,
+                  img_size=(input_f, input_t), patch_size=16, stride=(stride_f, stride_t), in_chans=in_channels,
+                  num_classes=n_classes, embed_dim=768, depth=12, num_heads=12, distilled=True,
+                  distilled_type=distilled_type, precision=precision)
+    if checkpoint:
+        state_dict = torch.load(checkpoint, map_location="cpu")["state_dict"]
+        replace_str = "net_swa." if checkpoint_swa_weigts else ""
+        state_dict = {k.replace(replace_str, ""): v for k, v in state_dict.items()}
+        if checkpoint_discard_head:
+            state_dict = {k: v for k, v in state_dict.items() if "head" not in k}
+        model.load_state_dict(state_dict, strict=False)
+    return model

@@ -1,0 +1,93 @@
+"""Training harness for the hot path: the tensor work of the reference's Lightning module
+(models/module.py:44-102 ``Module``, :279-316 ``TeacherStudentModule``) without Lightning/Sacred.
+
+``training_step(batch, batch_idx) -> loss`` keeps the reference contract (a scalar tensor with a grad
+edge; the caller runs ``loss.backward()`` and ``optimizer.step()``), but executes as:
+mixup draw on the host (same RNG calls as helpers/mixup.py) -> mixup of x fused into the
+patch-embedding operand kernel -> HIP forward -> BCE-with-logits kernel with the label mixup fused
+(emits dlogits) -> HIP backward.  AdamW / LR schedule stay in PyTorch (north_star: optimizer glue).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .maest import get_maest
+from .mixup import my_mixup
+
+
+class _BCEWithLogitsFn(torch.autograd.Function):
+    """F.binary_cross_entropy_with_logits(z, mix(y)) (mean) on the device (csrc/misc.hip)."""
+
+    @staticmethod
+    def forward(ctx, z, y, perm, lam, weight):
+        z = z.contiguous()
+        loss, dz = ops.bce_logits(z, y, weight, perm, lam, want_grad=True)
+        ctx.dz = dz
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dz = ctx.dz
+        ctx.dz = None
+        return dz * g, None, None, None, None
+
+
+def bce_with_logits(z, y, perm=None, lam=None, weight=1.0):
+    y = y.to(device=z.device, dtype=torch.float32).contiguous()
+    if perm is not None:
+        perm = perm.to(device=z.device, dtype=torch.int32).contiguous()
+        lam = lam.to(device=z.device, dtype=torch.float32).contiguous()
+    return _BCEWithLogitsFn.apply(z, y, perm, lam, weight)
+
+
+class Module(nn.Module):
+    """Mirror of ``models.module.Module`` (reference models/module.py:44-102, optimizer :237-254)."""
+
+    def __init__(self, net=None, mixup_alpha=0.3, lr=2e-5, weight_decay=1e-4, **maest_kwargs):
+        super().__init__()
+        self.mixup_alpha = mixup_alpha
+        self.lr = lr
+        self.weight_decay = weight_decay
+        self.net = net if net is not None else get_maest(**maest_kwargs)
+        self.last_mixup = None
+
+    def forward(self, batch, transformer_block=-1, **kw):
+        # the reference hard-codes transformer_block=-1 here (models/module.py:68-71)
+        return self.net.forward(batch, transformer_block=-1, return_self_attention=False, **kw)
+
+    def _mixup(self, batch_size):
+        if self.mixup_alpha > 0:
+            rn_indices, lam = my_mixup(batch_size, self.mixup_alpha)
+            self.last_mixup = (rn_indices, lam)
+            return rn_indices, lam
+        self.last_mixup = None
+        return None
+
+    def training_step(self, batch, batch_idx=0, *, _mixup=None, _patchout=None):
+        x, f, y = batch
+        batch_size = len(y)
+        mix = _mixup if _mixup is not None else self._mixup(batch_size)
+        y_hat, embed = self.forward(x, _mixup=mix, _patchout=_patchout)
+        perm, lam = mix if mix is not None else (None, None)
+        return bce_with_logits(y_hat, y, perm, lam)
+
+    def configure_optimizers(self):
+        return torch.optim.AdamW(self.parameters(), lr=self.lr, betas=(0.9, 0.999), eps=1e-08,
+                                 weight_decay=self.weight_decay, amsgrad=False)
+
+
+class TeacherStudentModule(Module):
+    """Mirror of ``TeacherStudentModule.training_step`` (reference models/module.py:280-316):
+    ``distilled_type="separated"`` net, loss = (BCE(cls head, y) + BCE(dist head, y_teacher)) / 2."""
+
+    def training_step(self, batch, batch_idx=0, *, _mixup=None, _patchout=None):
+        x, f, y, y_teacher = batch
+        batch_size = len(y)
+        mix = _mixup if _mixup is not None else self._mixup(batch_size)
+        y_hat, y_hat_teacher, _ = self.forward(x, _mixup=mix, _patchout=_patchout)
+        perm, lam = mix if mix is not None else (None, None)
+        loss_standard = bce_with_logits(y_hat, y, perm, lam, weight=0.5)
+        loss_teacher = bce_with_logits(y_hat_teacher, y_teacher, perm, lam, weight=0.5)
+        return loss_standard + loss_teacher

@@ -42,7 +42,8 @@ def case_gemm(dev, dtype, M, N, K, seed=0):
     b = rnd((N, K), seed + 1).to(dtype)
     bias = rnd((N,), seed + 2)
     ref = a.float() @ b.float().t() + bias
-    rt, at = (1e-5, 1e-4) if dtype == torch.float32 else (1e-5, 1e-3)
+    # fp32 accumulation-order noise of a K-term dot product of N(0,1) operands: ~ 4e-7 * K absolute
+    rt, at = 1e-5, 4e-7 * K / math.sqrt(K / 64)
     c = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_dtype=torch.float32)
     close(c, ref, rt, at * math.sqrt(K / 64), "gemm none")
     # asymmetric A = I check of the output orientation
@@ -54,7 +55,7 @@ def case_gemm(dev, dtype, M, N, K, seed=0):
     # GELU epilogue with aux_out
     aux = torch.empty((M, N), dtype=dtype, device=dev)
     g = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_dtype=dtype, epi=ops.EPI_GELU, aux_out=aux)
-    rt2, at2 = tol(dtype)
+    rt2, at2 = (1e-5, at) if dtype == torch.float32 else (1e-2, 1e-2)
     close(aux, ref, rt2, at2 * math.sqrt(K / 64), "gemm gelu aux")
     close(g, F.gelu(ref), rt2, at2 * math.sqrt(K / 64), "gemm gelu")
     # residual epilogue
@@ -122,7 +123,7 @@ def _attn_ref(qkv, B, N, scale):
     return (att @ v).transpose(1, 2).reshape(B * N, 768), torch.logsumexp((q @ k.transpose(-2, -1)) * scale, -1)
 
 
-def case_attention(dev, dtype, B, N, seed=20, spike=False):
+def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2):
     qkv = rnd((B * N, 2304), seed, 1.0).to(dtype)
     if spike:  # force a large running-max jump at a late key tile (online-softmax rescale branch)
         qf = qkv.float().clone()
@@ -141,7 +142,7 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False):
     ref.backward(dout.float())
     out_ref_lp = ref.detach().to(dtype)
     dqkv = ops.attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
-    rt, at = (1e-4, 1e-4) if dtype == torch.float32 else (3e-2, 3e-2)
+    rt, at = (1e-4, 1e-4) if dtype == torch.float32 else (bf16_tol, bf16_tol)
     g = x.grad
     close(dqkv[:, 1536:], g[:, 1536:], rt, at, "attention dV")
     close(dqkv[:, 768:1536], g[:, 768:1536], rt, at, "attention dK")

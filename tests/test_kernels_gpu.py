@@ -34,7 +34,7 @@ def test_attention(dtype, BN):
 
 def test_attention_rescale_branch():
     KC.case_attention(DEV, torch.float32, 1, 290, spike=True)
-    KC.case_attention(DEV, torch.bfloat16, 1, 290, spike=True)
+    KC.case_attention(DEV, torch.bfloat16, 1, 290, spike=True, bf16_tol=8e-2)
 
 
 @pytest.mark.parametrize("dtype", DT)
