@@ -69,7 +69,7 @@ __device__ __forceinline__ void tile_load(TileRegs<T>& t, const T* base, int64_t
         if (r < nrows) {
             t.c[p] = *reinterpret_cast<const chunk16*>(base + (int64_t)r * row_stride + c * C::EPC);
         } else {
-            t.c[p].w[0] = 0; t.c[p].w[1] = 0; t.c[p].w[2] = 0; t.c[p].w[3] = 0;
+            t.c[p][0] = 0; t.c[p][1] = 0; t.c[p][2] = 0; t.c[p][3] = 0;
         }
     }
 }
@@ -94,13 +94,13 @@ __device__ __forceinline__ void tile_store_transposed(const TileRegs<T>& t, char
         if constexpr (C::ELT == 2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const uint16_t v = (uint16_t)(t.c[p].w[e >> 1] >> ((e & 1) * 16));
+                const uint16_t v = (uint16_t)(t.c[p][e >> 1] >> ((e & 1) * 16));
                 *reinterpret_cast<uint16_t*>(lds_t + (c * 8 + e) * C::PITCH_T + r * 2) = v;
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                *reinterpret_cast<uint32_t*>(lds_t + (c * 4 + e) * C::PITCH_T + r * 4) = t.c[p].w[e];
+                *reinterpret_cast<uint32_t*>(lds_t + (c * 4 + e) * C::PITCH_T + r * 4) = t.c[p][e];
         }
     }
 }
@@ -150,8 +150,8 @@ __device__ __forceinline__ void store4(T* dst, float a, float b, float c, float 
 template <>
 __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, float a, float b, float c, float d) {
     chunk8 v;
-    v.w[0] = pack_bf2(a, b);
-    v.w[1] = pack_bf2(c, d);
+    v[0] = pack_bf2(a, b);
+    v[1] = pack_bf2(c, d);
     *reinterpret_cast<chunk8*>(dst) = v;
 }
 template <>

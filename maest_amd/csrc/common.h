@@ -30,12 +30,13 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 }
 
 // A 16-byte MFMA operand chunk: 8 bf16 or 4 fp32, as loaded from LDS / global.
-struct __attribute__((aligned(16))) chunk16 {
-    uint32_t w[4];
-};
-struct __attribute__((aligned(8))) chunk8 {
-    uint32_t w[2];
-};
+// (native vector types, not structs-with-arrays: the latter were left in scratch memory by hipcc)
+typedef __attribute__((ext_vector_type(4))) uint32_t chunk16;
+typedef __attribute__((ext_vector_type(2))) uint32_t chunk8;
+// bit casts always go through by-value scalars: __builtin_bit_cast applied directly to a
+// vector-element lvalue miscompiles (observed with this clang on both host and gfx950).
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 template <typename T>
 struct elem_traits;
@@ -69,8 +70,7 @@ template <>
 __device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const chunk16& a, const chunk16& b) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w[q]),
-                                                   __builtin_bit_cast(float, b.w[q]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(a[q]), u2f(b[q]), acc, 0, 0, 0);
 }
 
 // C/D fragment map of every 32x32 MFMA on gfx950: register r of lane l holds
@@ -87,7 +87,7 @@ template <>
 __device__ __forceinline__ chunk16 acc_to_chunk<bf16_t>(const f32x16_t& p, int s) {
     chunk16 c;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c.w[j] = pack_bf2(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
+    for (int j = 0; j < 4; ++j) c[j] = pack_bf2(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
     return c;
 }
 template <>
@@ -95,8 +95,7 @@ __device__ __forceinline__ chunk16 acc_to_chunk<float>(const f32x16_t& p, int s)
     chunk16 c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float v = p[4 * s + j];  // by-value copy first: never bit_cast a vector-element lvalue
-        c.w[j] = __builtin_bit_cast(uint32_t, v);
+        c[j] = f2u(p[4 * s + j]);
     }
     return c;
 }
@@ -111,7 +110,7 @@ __device__ __forceinline__ chunk16 read_transposed_chunk<bf16_t>(const char* row
     const chunk8 lo = *reinterpret_cast<const chunk8*>(row_ptr + (rho0 + 16 * s + 4 * h) * 2);
     const chunk8 hi = *reinterpret_cast<const chunk8*>(row_ptr + (rho0 + 16 * s + 8 + 4 * h) * 2);
     chunk16 c;
-    c.w[0] = lo.w[0]; c.w[1] = lo.w[1]; c.w[2] = hi.w[0]; c.w[3] = hi.w[1];
+    c[0] = lo[0]; c[1] = lo[1]; c[2] = hi[0]; c[3] = hi[1];
     return c;
 }
 template <>

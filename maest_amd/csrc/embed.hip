@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
         chunk16 c0, c1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            c0.w[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
-            c1.w[i] = pack_bf2(v[8 + 2 * i], v[8 + 2 * i + 1]);
+            c0[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+            c1[i] = pack_bf2(v[8 + 2 * i], v[8 + 2 * i + 1]);
         }
         dst[0] = c0;
         dst[1] = c1;

@@ -33,8 +33,8 @@ __device__ __forceinline__ void ln_stats(const float (&v)[12], float eps, float&
 __device__ __forceinline__ void store_row4(void* y, int dtype, int64_t off, float a, float b, float c, float d) {
     if (dtype == MAEST_BF16) {
         chunk8 o;
-        o.w[0] = pack_bf2(a, b);
-        o.w[1] = pack_bf2(c, d);
+        o[0] = pack_bf2(a, b);
+        o[1] = pack_bf2(c, d);
         *reinterpret_cast<chunk8*>(reinterpret_cast<bf16_t*>(y) + off) = o;
     } else {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + off) = make_float4(a, b, c, d);
@@ -43,8 +43,8 @@ __device__ __forceinline__ void store_row4(void* y, int dtype, int64_t off, floa
 __device__ __forceinline__ void load_row4(const void* y, int dtype, int64_t off, float (&o)[4]) {
     if (dtype == MAEST_BF16) {
         const chunk8 t = *reinterpret_cast<const chunk8*>(reinterpret_cast<const bf16_t*>(y) + off);
-        o[0] = bf2f((bf16_t)(t.w[0] & 0xffffu)); o[1] = bf2f((bf16_t)(t.w[0] >> 16));
-        o[2] = bf2f((bf16_t)(t.w[1] & 0xffffu)); o[3] = bf2f((bf16_t)(t.w[1] >> 16));
+        o[0] = bf2f((bf16_t)(t[0] & 0xffffu)); o[1] = bf2f((bf16_t)(t[0] >> 16));
+        o[2] = bf2f((bf16_t)(t[1] & 0xffffu)); o[3] = bf2f((bf16_t)(t[1] >> 16));
     } else {
         const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(y) + off);
         o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;

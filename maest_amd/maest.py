@@ -143,20 +143,22 @@ def _split_k(n_out: int, k_out: int, mpad: int) -> int:
     return max(1, min(1024 // tiles, mpad // 64))
 
 
-def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int) -> torch.Tensor:
-    """dW[n_out, k_out] = dy[M, n_out]^T @ x[M, k_out]  (fp32) via transposed operands + split-K."""
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int, out=None) -> torch.Tensor:
+    """dW[n_out, k_out] = dy[M, n_out]^T @ x[M, k_out]  (fp32) via transposed operands + split-K.
+    `out` (pre-zeroed fp32, any shape with n_out*k_out elements) receives the result if given."""
     M = dy.shape[0]
     mpad = ops.round_up(M, 64)
     dyt = ops.transpose(dy, mpad)
     xt = ops.transpose(x, mpad)
-    dw = torch.zeros((n_out, k_out), dtype=torch.float32, device=dy.device)
+    dw = (torch.zeros((n_out, k_out), dtype=torch.float32, device=dy.device) if out is None
+          else out.view(n_out, k_out))
     ops.gemm_nt(dyt, xt, None, out=dw, epi=ops.EPI_ATOMIC, split_k=_split_k(n_out, k_out, mpad), M=n_out, N=k_out,
                 K=mpad)
     return dw
 
 
-def _bias_grad(dy: torch.Tensor, n: int) -> torch.Tensor:
-    g = torch.zeros(n, dtype=torch.float32, device=dy.device)
+def _bias_grad(dy: torch.Tensor, n: int, out=None) -> torch.Tensor:
+    g = torch.zeros(n, dtype=torch.float32, device=dy.device) if out is None else out.view(n)
     ops.colsum(dy, g)
     return g
 
@@ -246,33 +248,46 @@ class _Engine:
         return outs, ctx
 
     # ---- backward ---------------------------------------------------------------------------
-    def backward(self, ctx, grads_out):
+    def backward(self, ctx, grads_out, sink=None):
         """grads_out: gradients w.r.t. the forward outputs (same tuple structure, entries may be None).
-        Returns {parameter name: fp32 gradient}."""
+        Returns {parameter name: fp32 gradient}.  With a `sink` (maest_amd.dist.GradReducer) every
+        gradient is written straight into the sink's flat bucket view and reported as soon as it is
+        complete, so the RCCL all-reduce of a bucket overlaps with the rest of the backward."""
         m, W = self.m, self.w
         dt, B, N, Fp, Tk = ctx["dt"], ctx["B"], ctx["N"], ctx["Fp"], ctx["Tk"]
         M = B * N
         dev = ctx["x_final"].device
         G = {}
-        zeros = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+
+        def buf(name, *shape):
+            v = sink.grad_buffer(name) if sink is not None else None
+            if v is not None:
+                return v.view(*shape)          # zeroed by sink.reset()
+            return torch.zeros(*shape, dtype=torch.float32, device=dev)
+
+        def done(name, g):
+            G[name] = g
+            if sink is not None:
+                sink.on_grad(name)
+
         C = m.head[1].out_features
         cpad = ops.round_up(C, 64)
         hn, hw = m.head[0], m.head[1]
 
         def lp_padded(d):  # fp32 [B, C] -> operand dtype [B, cpad], zero padded (K of the dgrad GEMM)
-            buf = torch.zeros((B, cpad), dtype=dt, device=dev)
-            buf[:, :C] = d
-            return buf
+            b = torch.zeros((B, cpad), dtype=dt, device=dev)
+            b[:, :C] = d
+            return b
 
         def head_linear_bwd(dlogits, inp_lp, lin, prefix):
             dl = lp_padded(dlogits)
-            G[prefix + ".weight"] = _wgrad(dl[:, :C], inp_lp, C, EMBED_DIM)
-            G[prefix + ".bias"] = _bias_grad(dlogits, C)
+            done(prefix + ".weight", _wgrad(dl[:, :C], inp_lp, C, EMBED_DIM, buf(prefix + ".weight", C, EMBED_DIM)))
+            done(prefix + ".bias", _bias_grad(dlogits, C, buf(prefix + ".bias", C)))
             wt = W.get(lin.weight, dt, transposed=True, pad_cols_to=64)          # [768, cpad]
             return ops.gemm_nt(dl, wt, None, out_dtype=dt, M=B, N=EMBED_DIM, K=cpad)
 
         d_cls = d_dist = None
-        G["head.0.weight"], G["head.0.bias"] = zeros(EMBED_DIM), zeros(EMBED_DIM)
+        g_h0w, g_h0b = buf("head.0.weight", EMBED_DIM), buf("head.0.bias", EMBED_DIM)
         if m.distilled_type == "mean":
             dlogits, dfeat_out = grads_out
             dfeat = None
@@ -280,7 +295,7 @@ class _Engine:
                 dhl = head_linear_bwd(dlogits.contiguous(), ctx["hl"], hw, "head.1")
                 dres = None if dfeat_out is None else dfeat_out.contiguous()
                 dfeat, _ = ops.layernorm_bwd(dhl, ctx["feat"], hn.weight, ctx["hmean"], ctx["hrstd"], dres,
-                                             G["head.0.weight"], G["head.0.bias"])
+                                             g_h0w, g_h0b)
             elif dfeat_out is not None:
                 dfeat = dfeat_out.contiguous()
         else:
@@ -289,13 +304,17 @@ class _Engine:
             if dlogits is not None:
                 dhl = head_linear_bwd(dlogits.contiguous(), ctx["hl"], hw, "head.1")
                 d_cls, _ = ops.layernorm_bwd(dhl, ctx["cls"], hn.weight, ctx["hmean"], ctx["hrstd"], None,
-                                             G["head.0.weight"], G["head.0.bias"])
+                                             g_h0w, g_h0b)
             if dlogits_d is not None:
                 dd = head_linear_bwd(dlogits_d.contiguous(), ctx["dist_lp"], m.head_dist, "head_dist")
                 d_dist = dd if dt == torch.float32 else dd.float()
-        G["norm.weight"], G["norm.bias"] = zeros(EMBED_DIM), zeros(EMBED_DIM)
+        done("head.0.weight", g_h0w)
+        done("head.0.bias", g_h0b)
+        g_nw, g_nb = buf("norm.weight", EMBED_DIM), buf("norm.bias", EMBED_DIM)
         dx = ops.head_pool_bwd(d_cls, d_dist, dfeat, ctx["x_final"], m.norm.weight, ctx["fmean"], ctx["frstd"],
-                               G["norm.weight"], G["norm.bias"]).reshape(M, EMBED_DIM)
+                               g_nw, g_nb).reshape(M, EMBED_DIM)
+        done("norm.weight", g_nw)
+        done("norm.bias", g_nb)
         dx_lp = dx if dt == torch.float32 else ops.cast_weights(dx, dt)[0]
 
         for i in reversed(range(len(m.blocks))):
@@ -303,49 +322,55 @@ class _Engine:
             p = f"blocks.{i}."
             H = blk.mlp.fc1.out_features
             # fc2 (+ residual):  x2 = x1 + g W2^T + b2
-            G[p + "mlp.fc2.bias"] = _bias_grad(dx_lp, EMBED_DIM)
-            G[p + "mlp.fc2.weight"] = _wgrad(dx_lp, s["g"], EMBED_DIM, H)
+            done(p + "mlp.fc2.bias", _bias_grad(dx_lp, EMBED_DIM, buf(p + "mlp.fc2.bias", EMBED_DIM)))
+            done(p + "mlp.fc2.weight", _wgrad(dx_lp, s["g"], EMBED_DIM, H, buf(p + "mlp.fc2.weight", EMBED_DIM, H)))
             dh = ops.gemm_nt(dx_lp, W.get(blk.mlp.fc2.weight, dt, transposed=True), None, out_dtype=dt,
                              epi=ops.EPI_DGELU, aux_in=s["h"])
             # fc1
-            G[p + "mlp.fc1.bias"] = _bias_grad(dh, H)
-            G[p + "mlp.fc1.weight"] = _wgrad(dh, s["ln2"], H, EMBED_DIM)
+            done(p + "mlp.fc1.bias", _bias_grad(dh, H, buf(p + "mlp.fc1.bias", H)))
+            done(p + "mlp.fc1.weight", _wgrad(dh, s["ln2"], H, EMBED_DIM, buf(p + "mlp.fc1.weight", H, EMBED_DIM)))
             dln2 = ops.gemm_nt(dh, W.get(blk.mlp.fc1.weight, dt, transposed=True), None, out_dtype=dt)
-            G[p + "norm2.weight"], G[p + "norm2.bias"] = zeros(EMBED_DIM), zeros(EMBED_DIM)
-            dx1, dx1_lp = ops.layernorm_bwd(dln2, s["x1"], blk.norm2.weight, s["mean2"], s["rstd2"], dx,
-                                            G[p + "norm2.weight"], G[p + "norm2.bias"],
+            gw, gb = buf(p + "norm2.weight", EMBED_DIM), buf(p + "norm2.bias", EMBED_DIM)
+            dx1, dx1_lp = ops.layernorm_bwd(dln2, s["x1"], blk.norm2.weight, s["mean2"], s["rstd2"], dx, gw, gb,
                                             lp_dtype=None if dt == torch.float32 else dt)
+            done(p + "norm2.weight", gw)
+            done(p + "norm2.bias", gb)
             if dt == torch.float32:
                 dx1_lp = dx1
             # proj (+ residual)
-            G[p + "attn.proj.bias"] = _bias_grad(dx1_lp, EMBED_DIM)
-            G[p + "attn.proj.weight"] = _wgrad(dx1_lp, s["ao"], EMBED_DIM, EMBED_DIM)
+            done(p + "attn.proj.bias", _bias_grad(dx1_lp, EMBED_DIM, buf(p + "attn.proj.bias", EMBED_DIM)))
+            done(p + "attn.proj.weight", _wgrad(dx1_lp, s["ao"], EMBED_DIM, EMBED_DIM,
+                                                buf(p + "attn.proj.weight", EMBED_DIM, EMBED_DIM)))
             dao = ops.gemm_nt(dx1_lp, W.get(blk.attn.proj.weight, dt, transposed=True), None, out_dtype=dt)
             dqkv = ops.attn_bwd(s["qkv"], s["ao"], dao, s["lse"], B, N, blk.attn.scale)
-            G[p + "attn.qkv.bias"] = _bias_grad(dqkv, 3 * EMBED_DIM)
-            G[p + "attn.qkv.weight"] = _wgrad(dqkv, s["ln1"], 3 * EMBED_DIM, EMBED_DIM)
+            done(p + "attn.qkv.bias", _bias_grad(dqkv, 3 * EMBED_DIM, buf(p + "attn.qkv.bias", 3 * EMBED_DIM)))
+            done(p + "attn.qkv.weight", _wgrad(dqkv, s["ln1"], 3 * EMBED_DIM, EMBED_DIM,
+                                               buf(p + "attn.qkv.weight", 3 * EMBED_DIM, EMBED_DIM)))
             dln1 = ops.gemm_nt(dqkv, W.get(blk.attn.qkv.weight, dt, transposed=True), None, out_dtype=dt)
-            G[p + "norm1.weight"], G[p + "norm1.bias"] = zeros(EMBED_DIM), zeros(EMBED_DIM)
-            dx, dx_lp = ops.layernorm_bwd(dln1, s["x"], blk.norm1.weight, s["mean1"], s["rstd1"], dx1,
-                                          G[p + "norm1.weight"], G[p + "norm1.bias"],
+            gw, gb = buf(p + "norm1.weight", EMBED_DIM), buf(p + "norm1.bias", EMBED_DIM)
+            dx, dx_lp = ops.layernorm_bwd(dln1, s["x"], blk.norm1.weight, s["mean1"], s["rstd1"], dx1, gw, gb,
                                           lp_dtype=None if dt == torch.float32 else dt)
+            done(p + "norm1.weight", gw)
+            done(p + "norm1.bias", gb)
             if dt == torch.float32:
                 dx_lp = dx
             s.clear()  # release this block's activations
 
         Tt = m.time_new_pos_embed.shape[-1]
-        d_cls_t, d_dist_t, d_np = zeros(EMBED_DIM), zeros(EMBED_DIM), zeros(2, EMBED_DIM)
-        d_fp, d_tp = zeros(EMBED_DIM, Fp), zeros(EMBED_DIM, Tt)
+        d_cls_t, d_dist_t = buf("cls_token", EMBED_DIM), buf("dist_token", EMBED_DIM)
+        d_np = buf("new_pos_embed", 2, EMBED_DIM)
+        d_fp, d_tp = buf("freq_new_pos_embed", EMBED_DIM, Fp), buf("time_new_pos_embed", EMBED_DIM, Tt)
         dpatch = ops.token_assemble_bwd(dx, B, Fp, Tk, Tt, ctx["toffset"], ctx["t_idx"], dt, d_cls_t, d_dist_t, d_np,
                                         d_fp, d_tp)
-        G["cls_token"] = d_cls_t.reshape(1, 1, EMBED_DIM)
-        G["dist_token"] = d_dist_t.reshape(1, 1, EMBED_DIM)
-        G["new_pos_embed"] = d_np.reshape(1, 2, EMBED_DIM)
-        G["freq_new_pos_embed"] = d_fp.reshape(1, EMBED_DIM, Fp, 1)
-        G["time_new_pos_embed"] = d_tp.reshape(1, EMBED_DIM, 1, Tt)
-        G["patch_embed.proj.bias"] = _bias_grad(dpatch, EMBED_DIM)
-        G["patch_embed.proj.weight"] = _wgrad(dpatch, ctx["cols"], EMBED_DIM, PATCH * PATCH).reshape(
-            m.patch_embed.proj.weight.shape)
+        done("cls_token", d_cls_t.view(1, 1, EMBED_DIM))
+        done("dist_token", d_dist_t.view(1, 1, EMBED_DIM))
+        done("new_pos_embed", d_np.view(1, 2, EMBED_DIM))
+        done("freq_new_pos_embed", d_fp.view(1, EMBED_DIM, Fp, 1))
+        done("time_new_pos_embed", d_tp.view(1, EMBED_DIM, 1, Tt))
+        done("patch_embed.proj.bias", _bias_grad(dpatch, EMBED_DIM, buf("patch_embed.proj.bias", EMBED_DIM)))
+        done("patch_embed.proj.weight",
+             _wgrad(dpatch, ctx["cols"], EMBED_DIM, PATCH * PATCH,
+                    buf("patch_embed.proj.weight", EMBED_DIM, PATCH * PATCH)).view(m.patch_embed.proj.weight.shape))
         return G
 
 
@@ -364,8 +389,11 @@ class _MaestFn(torch.autograd.Function):
     def backward(ctx, *gout):
         if ctx.saved is None:
             raise RuntimeError("maest_amd: backward called twice (activations are released after the first pass)")
-        G = ctx.model._engine.backward(ctx.saved, gout)
+        sink = ctx.model._grad_sink
+        G = ctx.model._engine.backward(ctx.saved, gout, sink)
         ctx.saved = None
+        if sink is not None:   # the sink (maest_amd.dist.GradReducer) installs param.grad itself
+            return (None, None, None, None, None, *([None] * len(ctx.names)))
         grads = []
         for n, p in zip(ctx.names, ctx.model._param_list):
             g = G.get(n)
@@ -439,6 +467,7 @@ class MAEST(nn.Module):
         self._engine = _Engine(self)
         self._param_names = None
         self._param_list = None
+        self._grad_sink = None   # set to a maest_amd.dist.GradReducer for data-parallel training
 
     # ---- reference API odds and ends --------------------------------------------------------
     def init_weights(self, mode=""):

@@ -11,6 +11,50 @@ from . import _lib
 from ._lib import BF16, EPI_ATOMIC, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F32, call
 
 DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+class KernelTimer:
+    """HIP-event timing of C-ABI launches on the stream they are enqueued on (bench.py roofline).
+    Usage: ``with ops.KernelTimer(kinds={"maest_gemm_nt"}) as t: ...; t.summary()``."""
+
+    def __init__(self, kinds=None):
+        self.kinds = kinds
+        self.records = []   # (name, start_event, end_event, work)
+
+    def __enter__(self):
+        global _TIMER
+        _TIMER = self
+        return self
+
+    def __exit__(self, *a):
+        global _TIMER
+        _TIMER = None
+
+    def summary(self):
+        """-> {name: {"launches": n, "ms": total, "work": total algorithmic flops}} (syncs)."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, work in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["work"] += work
+        return out
+
+
+_TIMER = None
+
+
+def _timed_call(name, work, *args):
+    t = _TIMER
+    if t is None or (t.kinds is not None and name not in t.kinds):
+        return call(name, *args)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call(name, *args)
+    e1.record()
+    t.records.append((name, e0, e1, work))
 HEADS = 12
 HEAD_DIM = 64
 EMBED = 768
@@ -66,8 +110,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
         if t is not None and not (t.is_cuda or _lib.host_emulation()):
             raise _lib.MaestHipError("maest_amd kernels need tensors on a HIP device; there is no CPU fallback")
     _chk(bias)
-    call("maest_gemm_nt", _p(a), a.stride(0), _p(b), b.stride(0), DT[a.dtype], _p(out), out.stride(0),
-         DT[out.dtype], M, N, K, _p(bias), epi, _p(aux_in), _p(aux_out), ld_aux, split_k, _s(a))
+    _timed_call("maest_gemm_nt", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), DT[a.dtype], _p(out),
+                out.stride(0), DT[out.dtype], M, N, K, _p(bias), epi, _p(aux_in), _p(aux_out), ld_aux, split_k, _s(a))
     return out
 
 
@@ -79,7 +123,7 @@ def transpose(src: torch.Tensor, ld_dst: Optional[int] = None, out: Optional[tor
     if out is None:
         out = torch.empty((cols, ld_dst), dtype=src.dtype, device=src.device)
     _chk(out)
-    call("maest_transpose", _p(src), src.stride(0), _p(out), ld_dst, rows, cols, DT[src.dtype], _s(src))
+    _timed_call("maest_transpose", 0.0, _p(src), src.stride(0), _p(out), ld_dst, rows, cols, DT[src.dtype], _s(src))
     return out
 
 
@@ -91,7 +135,7 @@ def cast_weights(src: torch.Tensor, dtype, want=True, want_t=False):
     rows, cols = w2.shape
     dst = torch.empty((rows, cols), dtype=dtype, device=src.device) if want else None
     dst_t = torch.empty((cols, rows), dtype=dtype, device=src.device) if want_t else None
-    call("maest_cast_weights", _p(w2), _p(dst), _p(dst_t), rows, cols, DT[dtype], _s(src))
+    _timed_call("maest_cast_weights", 0.0, _p(w2), _p(dst), _p(dst_t), rows, cols, DT[dtype], _s(src))
     return dst, dst_t
 
 
@@ -103,7 +147,7 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype, save_stat
     y = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
-    call("maest_layernorm_fwd", _p(x), x.stride(0), _p(gamma), _p(beta), _p(y), cols, DT[out_dtype], _p(mean),
+    _timed_call("maest_layernorm_fwd", 0.0, _p(x), x.stride(0), _p(gamma), _p(beta), _p(y), cols, DT[out_dtype], _p(mean),
          _p(rstd), rows, cols, eps, _s(x))
     return (y, mean, rstd) if save_stats else y
 
@@ -114,7 +158,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, lp_dtype=None, 
     rows, cols = x.shape
     dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device) if want_fp32 else None
     dx_lp = torch.empty((rows, cols), dtype=lp_dtype, device=x.device) if lp_dtype is not None else None
-    call("maest_layernorm_bwd", _p(dy), dy.stride(0), DT[dy.dtype], _p(x), x.stride(0), _p(gamma), _p(mean),
+    _timed_call("maest_layernorm_bwd", 0.0, _p(dy), dy.stride(0), DT[dy.dtype], _p(x), x.stride(0), _p(gamma), _p(mean),
          _p(rstd), _p(dres), _p(dx), _p(dx_lp), DT[lp_dtype] if lp_dtype is not None else 0, _p(dgamma), _p(dbeta),
          rows, cols, _s(x))
     return dx, dx_lp
@@ -125,7 +169,8 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False):
     assert qkv.shape == (B * N, 3 * EMBED)
     out = torch.empty((B * N, EMBED), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device) if save_lse else None
-    call("maest_attn_fwd", _p(qkv), _p(out), _p(lse), B, N, DT[qkv.dtype], scale, _s(qkv))
+    _timed_call("maest_attn_fwd", 4.0 * B * HEADS * N * N * HEAD_DIM, _p(qkv), _p(out), _p(lse), B, N,
+                DT[qkv.dtype], scale, _s(qkv))
     return (out, lse) if save_lse else out
 
 
@@ -134,8 +179,8 @@ def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float):
     assert dout.dtype == qkv.dtype and out.dtype == qkv.dtype
     delta = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device)
     dqkv = torch.empty_like(qkv)
-    call("maest_attn_bwd", _p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, N, DT[qkv.dtype], scale,
-         _s(qkv))
+    _timed_call("maest_attn_bwd", 10.0 * B * HEADS * N * N * HEAD_DIM, _p(qkv), _p(out), _p(dout), _p(lse),
+                _p(delta), _p(dqkv), B, N, DT[qkv.dtype], scale, _s(qkv))
     return dqkv
 
 
@@ -220,7 +265,7 @@ def sigmoid_mean(z: torch.Tensor):
 def colsum(src: torch.Tensor, out: torch.Tensor):
     _chk(out)
     rows, cols = src.shape
-    call("maest_colsum", _p(src), src.stride(0), rows, cols, DT[src.dtype], _p(out), _s(src))
+    _timed_call("maest_colsum", 0.0, _p(src), src.stride(0), rows, cols, DT[src.dtype], _p(out), _s(src))
     return out
 
 
