@@ -57,6 +57,15 @@ int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int in
                   const float* bias, int epi, const void* aux_in, void* aux_out, int64_t ld_aux,
                   int split_k, void* stream);
 
+/* ---- wgrad + bias grad, no transposed copies ("TN": both operands token-major as they sit in HBM) ----
+ *   C[M,N] (fp32, ACCUMULATED: zero it first) += sum_k A[k,m] * B[k,n]      A:[K,M] lda, B:[K,N] ldb
+ *   colsum[m] (fp32, ACCUMULATED, may be NULL) += sum_k A[k,m]              (= the bias gradient)
+ * dW = dY^T X of nn.Linear backward with A = dY [tokens, out], B = X [tokens, in].  Any K (the token
+ * tail is zero-filled in LDS); rows of A / B must be 16-byte multiples (lda / ldb) and may be wider
+ * than M / N.  split_k partials are combined with fp32 atomics. */
+int maest_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C,
+                  int64_t ldc, int M, int N, int K, float* colsum, int split_k, void* stream);
+
 /* ---- 2-D transpose with zero padding: dst[c, r] = src[r, c], dst rows padded to ld_dst ----------
  * (operand preparation for the wgrad GEMMs: dW = dY^T X needs both operands token-contiguous). */
 int maest_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols,

@@ -138,29 +138,20 @@ class _Weights:
         self._cache.clear()
 
 
-def _split_k(n_out: int, k_out: int, mpad: int) -> int:
+def _split_k(n_out: int, k_out: int, tokens: int) -> int:
+    """K splits of a wgrad so that ~1024 workgroups are in flight (4 per CU) whatever the weight shape."""
     tiles = math.ceil(n_out / 128) * math.ceil(k_out / 128)
-    return max(1, min(1024 // tiles, mpad // 64))
+    return max(1, min(1024 // tiles, math.ceil(tokens / 64)))
 
 
-def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int, out=None) -> torch.Tensor:
-    """dW[n_out, k_out] = dy[M, n_out]^T @ x[M, k_out]  (fp32) via transposed operands + split-K.
-    `out` (pre-zeroed fp32, any shape with n_out*k_out elements) receives the result if given."""
-    M = dy.shape[0]
-    mpad = ops.round_up(M, 64)
-    dyt = ops.transpose(dy, mpad)
-    xt = ops.transpose(x, mpad)
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int, out=None, bias_out=None) -> torch.Tensor:
+    """dW[n_out, k_out] = dy[M, n_out]^T @ x[M, k_out] (fp32) and, fused in the same kernel,
+    db[n_out] = dy.sum(0): token-major operands are consumed in place (csrc/gemm.hip: gemm_tn_kernel).
+    `out` / `bias_out` (pre-zeroed fp32) receive the results if given."""
     dw = (torch.zeros((n_out, k_out), dtype=torch.float32, device=dy.device) if out is None
           else out.view(n_out, k_out))
-    ops.gemm_nt(dyt, xt, None, out=dw, epi=ops.EPI_ATOMIC, split_k=_split_k(n_out, k_out, mpad), M=n_out, N=k_out,
-                K=mpad)
+    ops.gemm_tn(dy, x, dw, colsum=bias_out, split_k=_split_k(n_out, k_out, dy.shape[0]), M=n_out, N=k_out)
     return dw
-
-
-def _bias_grad(dy: torch.Tensor, n: int, out=None) -> torch.Tensor:
-    g = torch.zeros(n, dtype=torch.float32, device=dy.device) if out is None else out.view(n)
-    ops.colsum(dy, g)
-    return g
 
 
 class _Engine:
@@ -281,8 +272,9 @@ class _Engine:
 
         def head_linear_bwd(dlogits, inp_lp, lin, prefix):
             dl = lp_padded(dlogits)
-            done(prefix + ".weight", _wgrad(dl[:, :C], inp_lp, C, EMBED_DIM, buf(prefix + ".weight", C, EMBED_DIM)))
-            done(prefix + ".bias", _bias_grad(dlogits, C, buf(prefix + ".bias", C)))
+            gb = buf(prefix + ".bias", C)
+            done(prefix + ".weight", _wgrad(dl, inp_lp, C, EMBED_DIM, buf(prefix + ".weight", C, EMBED_DIM), gb))
+            done(prefix + ".bias", gb)
             wt = W.get(lin.weight, dt, transposed=True, pad_cols_to=64)          # [768, cpad]
             return ops.gemm_nt(dl, wt, None, out_dtype=dt, M=B, N=EMBED_DIM, K=cpad)
 
@@ -322,13 +314,15 @@ class _Engine:
             p = f"blocks.{i}."
             H = blk.mlp.fc1.out_features
             # fc2 (+ residual):  x2 = x1 + g W2^T + b2
-            done(p + "mlp.fc2.bias", _bias_grad(dx_lp, EMBED_DIM, buf(p + "mlp.fc2.bias", EMBED_DIM)))
-            done(p + "mlp.fc2.weight", _wgrad(dx_lp, s["g"], EMBED_DIM, H, buf(p + "mlp.fc2.weight", EMBED_DIM, H)))
+            gb = buf(p + "mlp.fc2.bias", EMBED_DIM)
+            done(p + "mlp.fc2.weight", _wgrad(dx_lp, s["g"], EMBED_DIM, H, buf(p + "mlp.fc2.weight", EMBED_DIM, H), gb))
+            done(p + "mlp.fc2.bias", gb)
             dh = ops.gemm_nt(dx_lp, W.get(blk.mlp.fc2.weight, dt, transposed=True), None, out_dtype=dt,
                              epi=ops.EPI_DGELU, aux_in=s["h"])
             # fc1
-            done(p + "mlp.fc1.bias", _bias_grad(dh, H, buf(p + "mlp.fc1.bias", H)))
-            done(p + "mlp.fc1.weight", _wgrad(dh, s["ln2"], H, EMBED_DIM, buf(p + "mlp.fc1.weight", H, EMBED_DIM)))
+            gb = buf(p + "mlp.fc1.bias", H)
+            done(p + "mlp.fc1.weight", _wgrad(dh, s["ln2"], H, EMBED_DIM, buf(p + "mlp.fc1.weight", H, EMBED_DIM), gb))
+            done(p + "mlp.fc1.bias", gb)
             dln2 = ops.gemm_nt(dh, W.get(blk.mlp.fc1.weight, dt, transposed=True), None, out_dtype=dt)
             gw, gb = buf(p + "norm2.weight", EMBED_DIM), buf(p + "norm2.bias", EMBED_DIM)
             dx1, dx1_lp = ops.layernorm_bwd(dln2, s["x1"], blk.norm2.weight, s["mean2"], s["rstd2"], dx, gw, gb,
@@ -338,14 +332,16 @@ class _Engine:
             if dt == torch.float32:
                 dx1_lp = dx1
             # proj (+ residual)
-            done(p + "attn.proj.bias", _bias_grad(dx1_lp, EMBED_DIM, buf(p + "attn.proj.bias", EMBED_DIM)))
+            gb = buf(p + "attn.proj.bias", EMBED_DIM)
             done(p + "attn.proj.weight", _wgrad(dx1_lp, s["ao"], EMBED_DIM, EMBED_DIM,
-                                                buf(p + "attn.proj.weight", EMBED_DIM, EMBED_DIM)))
+                                                buf(p + "attn.proj.weight", EMBED_DIM, EMBED_DIM), gb))
+            done(p + "attn.proj.bias", gb)
             dao = ops.gemm_nt(dx1_lp, W.get(blk.attn.proj.weight, dt, transposed=True), None, out_dtype=dt)
             dqkv = ops.attn_bwd(s["qkv"], s["ao"], dao, s["lse"], B, N, blk.attn.scale)
-            done(p + "attn.qkv.bias", _bias_grad(dqkv, 3 * EMBED_DIM, buf(p + "attn.qkv.bias", 3 * EMBED_DIM)))
+            gb = buf(p + "attn.qkv.bias", 3 * EMBED_DIM)
             done(p + "attn.qkv.weight", _wgrad(dqkv, s["ln1"], 3 * EMBED_DIM, EMBED_DIM,
-                                               buf(p + "attn.qkv.weight", 3 * EMBED_DIM, EMBED_DIM)))
+                                               buf(p + "attn.qkv.weight", 3 * EMBED_DIM, EMBED_DIM), gb))
+            done(p + "attn.qkv.bias", gb)
             dln1 = ops.gemm_nt(dqkv, W.get(blk.attn.qkv.weight, dt, transposed=True), None, out_dtype=dt)
             gw, gb = buf(p + "norm1.weight", EMBED_DIM), buf(p + "norm1.bias", EMBED_DIM)
             dx, dx_lp = ops.layernorm_bwd(dln1, s["x"], blk.norm1.weight, s["mean1"], s["rstd1"], dx1, gw, gb,
@@ -367,10 +363,11 @@ class _Engine:
         done("new_pos_embed", d_np.view(1, 2, EMBED_DIM))
         done("freq_new_pos_embed", d_fp.view(1, EMBED_DIM, Fp, 1))
         done("time_new_pos_embed", d_tp.view(1, EMBED_DIM, 1, Tt))
-        done("patch_embed.proj.bias", _bias_grad(dpatch, EMBED_DIM, buf("patch_embed.proj.bias", EMBED_DIM)))
+        gb = buf("patch_embed.proj.bias", EMBED_DIM)
         done("patch_embed.proj.weight",
              _wgrad(dpatch, ctx["cols"], EMBED_DIM, PATCH * PATCH,
-                    buf("patch_embed.proj.weight", EMBED_DIM, PATCH * PATCH)).view(m.patch_embed.proj.weight.shape))
+                    buf("patch_embed.proj.weight", EMBED_DIM, PATCH * PATCH), gb).view(m.patch_embed.proj.weight.shape))
+        done("patch_embed.proj.bias", gb)
         return G
 
 

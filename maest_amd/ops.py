@@ -115,6 +115,23 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, colsum: Optional[torch.Tensor] = None,
+            split_k: int = 1, M: Optional[int] = None, N: Optional[int] = None) -> torch.Tensor:
+    """out[M,N] (fp32, pre-zeroed) += a[K,M]^T @ b[K,N];  colsum[M] (fp32, pre-zeroed) += a.sum(0)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype and a.shape[0] == b.shape[0]
+    assert a.stride(1) == 1 and b.stride(1) == 1 and out.dtype == torch.float32
+    K = a.shape[0]
+    M = a.shape[1] if M is None else M
+    N = b.shape[1] if N is None else N
+    out2 = out.view(M, N)
+    for t in (a, b, out, colsum):
+        if t is not None and not (t.is_cuda or _lib.host_emulation()):
+            raise _lib.MaestHipError("maest_amd kernels need tensors on a HIP device; there is no CPU fallback")
+    _timed_call("maest_gemm_tn", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), DT[a.dtype], _p(out2),
+                out2.stride(0), M, N, K, _p(colsum), split_k, _s(a))
+    return out
+
+
 def transpose(src: torch.Tensor, ld_dst: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[c, r] = src[r, c]; out has shape [cols, ld_dst] with the pad columns zeroed."""
     assert src.dim() == 2 and src.stride(1) == 1

@@ -37,3 +37,10 @@ bench("transpose [M,768] bf16", lambda: ops.transpose(x, M), 0)
 g = torch.zeros(3072, device=dev)
 x = mk(M, 3072)
 bench("colsum [M,3072]", lambda: ops.colsum(x, g), 0)
+print("---- TN wgrad (token-major operands)")
+for (nm, N, K) in [("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]:
+    dy = mk(M, N); xx = mk(M, K)
+    dw = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
+    tiles = math.ceil(N/128)*math.ceil(K/128)
+    for sk in (max(1, 512//tiles), max(1, 1024 // tiles), max(1, 2048//tiles)):
+        bench(f"{nm} TN wgrad+bias splitk={sk}", lambda: ops.gemm_tn(dy, xx, dw, colsum=db, split_k=sk), 2.0*M*N*K)

@@ -159,6 +159,24 @@ static inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, i
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_f32_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_f32_16x16x4f32
 
+// ds_read_b64_tr_b16 (gfx950), semantics probed on hardware (scratch/probe/tr_probe.hip): within each
+// 16-lane group, lane q supplies the address of 4 contiguous b16 of row q/4 (column chunk q%4) of a
+// 4x16 block (any row stride); it receives column q of rows 0..3: out[j] = loaded[lane 4j + q/4][q%4].
+typedef short emu_v4i16 __attribute__((ext_vector_type(4)));
+static inline emu_v4i16 emu_ds_read_tr16_b64(const void* p) {
+    emu::Wave& W = emu::wave();
+    const int l = emu::lane();
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(p);
+    for (int e = 0; e < 4; ++e) W.A[l][e] = (float)src[e];   // b16 payload fits a float exactly
+    emu::wave_sync();
+    const int g = l & ~15, q = l & 15;
+    emu_v4i16 r;
+    for (int j = 0; j < 4; ++j) r[j] = (short)(uint16_t)W.A[g + 4 * j + (q >> 2)][q & 3];
+    emu::wave_sync();
+    return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void*)(uintptr_t)(p))
+
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
     static_assert(sizeof(T) == 4, "emu shuffle: 32-bit types only");

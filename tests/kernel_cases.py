@@ -75,6 +75,30 @@ def case_gemm(dev, dtype, M, N, K, seed=0):
     close(acc, ref - bias, rt, at * math.sqrt(K / 64), "gemm split-k")
 
 
+def case_gemm_tn(dev, dtype, K, M, N, seed=3, lda_pad=0):
+    """wgrad form: out[M,N] += a[K,M]^T b[K,N], colsum[M] += a.sum(0); ragged K (token tail)."""
+    a_full = rnd((K, M + lda_pad), seed).to(dtype)
+    a = a_full[:, :M]
+    b = rnd((K, N), seed + 1).to(dtype)
+    ref = a.float().t() @ b.float()
+    ref_cs = a.float().sum(0)
+    at = 4e-7 * K + (0 if dtype == torch.float32 else 1e-3)
+    for sk in (1, 3):
+        out = torch.zeros((M, N), dtype=torch.float32, device=dev)
+        cs = torch.zeros(M, dtype=torch.float32, device=dev)
+        a_dev = a_full.to(dev)[:, :M]
+        ops.gemm_tn(a_dev, b.to(dev), out, colsum=cs, split_k=sk, M=M, N=N)
+        close(out, ref, 1e-5, at, f"gemm_tn split_k={sk}")
+        close(cs, ref_cs, 1e-5, at, f"gemm_tn colsum split_k={sk}")
+    # transpose-detecting: A = [I | 0] picks rows of B
+    if dtype == torch.float32 and K >= M:
+        eye = torch.zeros(K, M)
+        eye[:M, :M] = torch.eye(M)
+        out = torch.zeros((M, N), dtype=torch.float32, device=dev)
+        ops.gemm_tn(eye.to(dev), b.to(dev), out)
+        close(out, b.float()[:M], 0, 1e-6, "gemm_tn identity")
+
+
 # ------------------------------------------------------------------------------------- transposes
 def case_transpose(dev, dtype, rows, cols):
     src = rnd((rows, cols), 5).to(dtype)

@@ -16,6 +16,18 @@ def test_emu_gemm(emu, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_emu_gemm_ragged_n_scalar_epilogue(emu, dtype):
+    K = 32 if dtype == torch.float32 else 64
+    KC.case_gemm(emu, dtype, 70, 51, K)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_emu_gemm_tn(emu, dtype):
+    KC.case_gemm_tn(emu, dtype, 150, 136, 200)
+    KC.case_gemm_tn(emu, dtype, 40, 24, 72, lda_pad=8)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_emu_transpose(emu, dtype):
     KC.case_transpose(emu, dtype, 70, 130)
 

@@ -16,6 +16,21 @@ def test_gemm(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(1121, 768, 3072), (2300, 2304, 768), (64, 400, 768), (7, 519 + 57, 768), (5184, 768, 256)])
+def test_gemm_tn(dtype, shape):
+    K, M, N = shape
+    if M == 519 + 57:
+        KC.case_gemm_tn(DEV, dtype, K, 519, N, lda_pad=57)
+    else:
+        KC.case_gemm_tn(DEV, dtype, K, M, N)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_ragged_n(dtype):
+    KC.case_gemm(DEV, dtype, 300, 519, 768)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_transpose(dtype):
     KC.case_transpose(DEV, dtype, 1121, 768)
     KC.case_transpose(DEV, dtype, 562, 3072)
