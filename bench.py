@@ -145,7 +145,7 @@ def main():
         for _ in range(args.steps):
             step()
     else:
-        with ops.KernelTimer(kinds={"maest_gemm_nt", "maest_attn_fwd", "maest_attn_bwd"}) as timer:
+        with ops.KernelTimer(kinds={"maest_gemm_nt", "maest_gemm_tn", "maest_attn_fwd", "maest_attn_bwd"}) as timer:
             for _ in range(args.steps):
                 step()
     torch.cuda.synchronize()

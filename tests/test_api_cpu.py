@@ -1,0 +1,160 @@
+"""CPU: the drop-in surface and host logic (no kernel launches): C-ABI exports, exception contract
+(reference tests/test_maest.py:13-29), state_dict compatibility, loud failure without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import maest_amd
+from maest_amd import _lib, get_maest
+from oracle import maest_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model():
+    return get_maest(arch="discogs-maest-30s-pw-129e", pretrained=False)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "maest_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(maest_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_lib.SIGNATURES) | {"maest_version", "maest_last_error"}
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libmaest_hip.so not built here (run __graft_entry__.build())")
+    import ctypes
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/maest_hip.h but not exported"
+    lib.maest_version.restype = ctypes.c_int
+    assert lib.maest_version() == 1
+
+
+def test_argument_validation_returns_status_and_message():
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    lib = _lib.load()
+    rc = lib.maest_gemm_nt(None, 0, None, 0, 1, None, 0, 1, 4, 4, 64, None, 0, None, None, 0, 1, None)
+    assert rc == 1 and b"null operand" in lib.maest_last_error()
+    rc = lib.maest_layernorm_fwd(1, 768, 1, 1, 1, 768, 0, None, None, 4, 512, 1e-6, None)
+    assert rc == 1 and b"768" in lib.maest_last_error()
+
+
+def test_numpy_input(model):
+    with pytest.raises(Exception):
+        model(np.random.rand(128, 128))
+
+
+def test_empty_input(model):
+    with pytest.raises(Exception):
+        model(torch.empty([]))
+
+
+def test_long_2d_input(model):
+    # 40 s of audio into the 30 s model: rejected (reference maest.py:664-668) before any device work
+    with pytest.raises(Exception, match="reduce the input duration"):
+        model(torch.rand(2, 40 * 16000).float())
+
+
+def test_1d_with_melspectrogram_flag_asserts(model):
+    with pytest.raises(AssertionError):
+        model(torch.rand(16000), melspectrogram_input=True)
+
+
+def test_cpu_tensor_fails_loudly_no_fallback(model):
+    with pytest.raises(_lib.MaestHipError, match="no CPU fallback"):
+        model(torch.rand(1, 96, 1875))
+
+
+def test_unknown_arch_and_pretrained():
+    with pytest.raises(NotImplementedError):
+        get_maest("not-a-model", pretrained=False)
+    with pytest.raises(RuntimeError, match="network"):
+        get_maest("discogs-maest-10s-pw-129e")          # pretrained defaults to True like the reference
+
+
+def test_unimplemented_patchout_variants_are_explicit():
+    with pytest.raises(NotImplementedError, match="s_patchout_t"):
+        get_maest("discogs-maest-10s-pw-129e", pretrained=False, u_patchout=10)
+
+
+def test_state_dict_matches_reference_layout():
+    m = get_maest("discogs-maest-10s-pw-129e", pretrained=False)
+    sd = m.state_dict()
+    spec = O.state_dict_spec(625, 400)
+    assert list(sd.keys()) == [n for n, _ in spec]
+    for n, shape in spec:
+        assert tuple(sd[n].shape) == tuple(shape), n
+    assert sum(p.numel() for p in m.parameters()) == 85927712
+    assert m.training, "get_maest returns the model in train mode like the reference (maest.py:1552)"
+    m.load_state_dict(O.make_state_dict(625), strict=True)
+    assert m.no_weight_decay() == {"new_pos_embed", "freq_new_pos_embed", "time_new_pos_embed", "cls_token",
+                                   "dist_token"}
+
+
+@pytest.mark.parametrize("arch,t,c", [("discogs-maest-5s-pw-129e", 312, 400), ("discogs-maest-20s-pw-129e", 1250, 400),
+                                      ("discogs-maest-30s-pw-129e-519l", 1875, 519),
+                                      ("passt_s_swa_p16_128_ap476", 998, 400)])
+def test_arch_registry(arch, t, c):
+    m = get_maest(arch, pretrained=False)
+    assert m.img_size == (96, t) and m.num_classes == c
+    assert m.time_new_pos_embed.shape == (1, 768, 1, t // 10)
+    assert m.patch_embed.grid_size == (9, t // 10)
+    assert len(m.labels) == c
+    assert len(m.blocks) == 12
+
+
+def test_init_distribution():
+    torch.manual_seed(0)
+    m = get_maest("discogs-maest-10s-pw-129e", pretrained=False)
+    w = m.blocks[3].mlp.fc1.weight
+    assert abs(float(w.std()) - 0.02) < 2e-3 and float(w.abs().max()) <= 2.0
+    assert float(m.head[1].weight.std()) > 0.01          # head is trunc-normal too (maest.py:600 via apply)
+    assert float(m.blocks[0].attn.qkv.bias.abs().max()) == 0.0
+    assert float((m.norm.weight - 1).abs().max()) == 0.0
+    assert abs(float(m.time_new_pos_embed.std()) - 0.02) < 3e-3
+
+
+def test_maest_alias_package():
+    from maest import get_maest as g2
+    assert g2 is get_maest
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "maest_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(root, f), encoding="utf-8").read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_mixup_draw_semantics():
+    from maest_amd.mixup import my_mixup
+    torch.manual_seed(0)
+    np.random.seed(0)
+    perm, lam = my_mixup(64, 0.3)
+    assert sorted(perm.tolist()) == list(range(64))
+    assert lam.dtype == torch.float32 and float(lam.min()) >= 0.5 and float(lam.max()) <= 1.0
+
+
+def test_spec_masking_draw_ranges():
+    from maest_amd.spec_masking import SpecMasking
+    torch.manual_seed(0)
+    t, f = SpecMasking().draw(8, 96, 625)
+    assert t.shape == (8, 20, 2) and f.shape == (8, 8, 2)
+    assert int(t[..., 1].max()) < 8 and int(f[..., 1].max()) < 5
+    assert int((t[..., 0] + t[..., 1]).max()) <= 625 and int((f[..., 0] + f[..., 1]).max()) <= 96
+
+
+def test_train_rng_draws_match_reference_order(model):
+    """toffset is drawn before the kept-column permutation, from torch's global CPU generator."""
+    m = get_maest("discogs-maest-10s-pw-129e", pretrained=False, s_patchout_t=30)
+    torch.manual_seed(42)
+    toff, keep = m._draw_train_indices(61)
+    torch.manual_seed(42)
+    want_off = torch.randint(1 + 62 - 61, (1,)).item()
+    want_keep = torch.randperm(61)[:31].sort().values
+    assert toff == want_off and torch.equal(keep, want_keep)

@@ -1,0 +1,81 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient exchange host logic (maest_amd/dist.py) --
+bucket partition in backward order, async all-reduce per completed bucket, averaging, grad views."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from maest_amd.dist import GradReducer, backward_order, broadcast_parameters, init_from_env
+    r, _, w = init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(rank)
+    names = ["cls_token", "patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.0.attn.qkv.bias",
+             "blocks.1.mlp.fc1.weight", "blocks.1.mlp.fc1.bias", "norm.weight", "head.1.weight", "head_dist.weight"]
+    shapes = [(1, 1, 8), (8, 1, 4, 4), (24, 8), (24,), (32, 8), (32,), (8,), (5, 8), (5, 8)]
+    params = [(n, torch.nn.Parameter(torch.randn(s))) for n, s in zip(names, shapes)]
+    mod = torch.nn.ParameterList([p for _, p in params])
+    broadcast_parameters(mod, 0)
+    red = GradReducer(params, bucket_mb=0.0008, skip=("head_dist.weight",))   # ~200 floats per bucket
+    order = backward_order([n for n in names if n != "head_dist.weight"])
+    assert order[0] in ("norm.weight", "head.1.weight") and order[-1] in ("cls_token", "patch_embed.proj.weight")
+    assert order.index("blocks.1.mlp.fc1.weight") < order.index("blocks.0.attn.qkv.weight")
+    assert len(red.buckets) >= 2
+    for step in range(2):
+        red.reset()
+        for n in red.order:
+            red.grad_buffer(n).add_(float(rank + 1) * (step + 1))      # "kernel" writes the gradient
+            red.on_grad(n)
+        red.finish()
+        want = (1 + 2) / 2 * (step + 1)
+        for n, p in params:
+            if n == "head_dist.weight":
+                assert p.grad is None
+            else:
+                assert torch.allclose(p.grad, torch.full_like(p, want)), (n, p.grad.flatten()[:3], want)
+                assert p.grad.data_ptr() == red.grad_buffer(n).data_ptr()    # a view, not a copy
+    w0 = [p.detach().clone() for _, p in params]
+    gathered = [torch.zeros_like(w0[2]) for _ in range(world)]
+    dist.all_gather(gathered, w0[2])
+    assert torch.equal(gathered[0], gathered[1]), "broadcast_parameters must make replicas identical"
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, "worker failed"
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, "ok"), (1, "ok")]
+
+
+def test_grad_reducer_incomplete_bucket_is_an_error():
+    from maest_amd.dist import GradReducer
+    params = [("blocks.0.mlp.fc1.weight", torch.nn.Parameter(torch.zeros(4, 4))),
+              ("norm.weight", torch.nn.Parameter(torch.zeros(4)))]
+    red = GradReducer(params)
+    red.reset()
+    red.on_grad("norm.weight")
+    with pytest.raises(RuntimeError, match="never completed"):
+        red.finish()

@@ -258,3 +258,30 @@ def test_waveform_path_matches_oracle_fp32():
     got, gf = net(w.to(DEV))
     assert got.shape == (4, 400) and gf.shape == (4, 768)
     assert rel_err(got, want) < 1e-3 and rel_err(gf, wf) < 1e-3
+
+
+def test_grad_sink_path_equals_autograd_path():
+    """The data-parallel gradient sink (maest_amd.dist.GradReducer: flat bucket views written directly
+    by the backward kernels) must give the same gradients as the plain autograd path (world size 1)."""
+    from maest_amd.dist import GradReducer
+    g = np.load(os.path.join(GOLD, "g5_train_step.npz"))
+    net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision="fp32").train()
+    mod = Module(net=net, mixup_alpha=0.3)
+    x, y, mix, po = _g5_batch(g)
+    mod.training_step((x, None, y), 0, _mixup=mix, _patchout=po).backward()
+    ref = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad(set_to_none=True)
+    red = GradReducer(net.named_parameters(), bucket_mb=32, skip=("head_dist.weight", "head_dist.bias"))
+    assert len(red.buckets) > 3
+    net._grad_sink = red
+    red.reset()
+    mod.training_step((x, None, y), 0, _mixup=mix, _patchout=po).backward()
+    red.finish()
+    net._grad_sink = None
+    for n, p in net.named_parameters():
+        if n.startswith("head_dist"):
+            assert p.grad is None
+            continue
+        assert p.grad.data_ptr() == red.grad_buffer(n).data_ptr()
+        d = (p.grad - ref[n]).abs().max().item()
+        assert d <= 1e-5 * max(ref[n].abs().max().item(), 1e-6) + 1e-7, (n, d)   # atomics: order-only noise
