@@ -39,9 +39,9 @@ extern "C" {
 
 /* GEMM epilogues */
 #define MAEST_EPI_NONE 0     /* C = acc + bias                                           */
-#define MAEST_EPI_GELU 1     /* aux_out = acc + bias (optional) ; C = gelu_erf(acc+bias) */
+#define MAEST_EPI_GELU 1     /* C = gelu_erf(acc+bias) ; aux_out (optional) = gelu_erf'(acc+bias), saved for backward */
 #define MAEST_EPI_RESIDUAL 2 /* C(fp32) = acc + bias + aux_in(fp32)                      */
-#define MAEST_EPI_DGELU 3    /* C = acc * gelu_erf'(aux_in)     (aux_in in out_dtype)    */
+#define MAEST_EPI_MUL 3      /* C = acc * aux_in   (aux_in in out_dtype; dgrad through GELU)  */
 #define MAEST_EPI_ATOMIC 4   /* C(fp32) += acc   (split-K accumulate, C pre-zeroed)      */
 
 int maest_version(void);
@@ -50,7 +50,8 @@ const char* maest_last_error(void);
 /* ---- K8, K10-K12, K13 head, K4 (im2col form) and their dgrad / wgrad ---------------------------
  * nn.Linear: models/maest.py:353,355,361,376 ; :197-199,203-206 ; :572,579 ; nn.Conv2d :238-240.
  *   C[M,N] = epilogue( sum_k A[m,k] * B[n,k] )      A:[M,K] lda, B:[N,K] ldb (both k-contiguous)
- * in_dtype = dtype of A and B; out_dtype = dtype of C / aux_out (and aux_in for DGELU).
+ * in_dtype = dtype of A and B; out_dtype = dtype of C / aux_out (and aux_in for MUL).
+ * GELU uses libm erf in fp32 mode and the Abramowitz-Stegun 7.1.26 erf (|err| <= 1.5e-7) in bf16 mode.
  * K must be a multiple of 64 (bf16) / 32 (fp32): callers zero-pad.  bias: fp32 [N] or NULL. */
 int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int in_dtype,
                   void* C, int64_t ldc, int out_dtype, int M, int N, int K,

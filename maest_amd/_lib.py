@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmaest_hip.so")
 
 F32 = 0
 BF16 = 1
-EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_ATOMIC = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_MUL, EPI_ATOMIC = 0, 1, 2, 3, 4
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 

@@ -136,6 +136,27 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// GELU value and derivative together (one erf, one exp).  EXACT = true: libm erff (fp32 parity mode);
+// EXACT = false: Abramowitz-Stegun 7.1.26 erf (|err| <= 1.5e-7, far below bf16 resolution; bf16 perf mode).
+template <bool EXACT>
+__device__ __forceinline__ void gelu_pair(float x, float& g, float& dg) {
+    const float u = x * 0.70710678118654752f;
+    const float e = __expf(-u * u);                       // = exp(-x^2 / 2)
+    float erfu;
+    if (EXACT) {
+        erfu = erff(u);
+    } else {
+        const float au = fabsf(u);
+        const float t = 1.0f / (1.0f + 0.3275911f * au);
+        const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+        const float ea = 1.0f - poly * e;
+        erfu = u < 0.0f ? -ea : ea;
+    }
+    const float cdf = 0.5f * (1.0f + erfu);
+    g = x * cdf;
+    dg = cdf + x * e * 0.39894228040143268f;
+}
+
 // exact-erf GELU (nn.GELU default) and its derivative
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {

@@ -61,7 +61,8 @@ struct EpiCfg {
 };
 
 // registers -> LDS, in the output dtype.  acc[jn][im]: rows n = wn*64 + jn*32 + frag_row, col m = lane.
-template <int OSZ, bool GELU>
+// GMODE: 0 = acc + bias, 1 = gelu(acc + bias), 2 = gelu'(acc + bias)
+template <int OSZ, int GMODE, bool EXACT>
 __device__ __forceinline__ void epi_stage(char* smem, const f32x16_t (&acc)[2][2], const float* bias, int n0, int N,
                                           int wm, int wn, int lane) {
     using E = EpiCfg<OSZ>;
@@ -83,7 +84,11 @@ __device__ __forceinline__ void epi_stage(char* smem, const f32x16_t (&acc)[2][2
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = acc[jn][im][4 * g + e] + b4[e];
-                    if (GELU) v[e] = gelu_f(v[e]);
+                    if (GMODE != 0) {
+                        float gv, dv;
+                        gelu_pair<EXACT>(v[e], gv, dv);
+                        v[e] = GMODE == 1 ? gv : dv;
+                    }
                 }
                 char* dst = smem + ml * E::PITCH + nl * OSZ;
                 if (OSZ == 4) {
@@ -98,7 +103,7 @@ __device__ __forceinline__ void epi_stage(char* smem, const f32x16_t (&acc)[2][2
         }
 }
 
-// LDS -> global with 16-byte stores; MODE 0 plain, 1 += fp32 residual, 2 *= gelu'(aux) (aux in out dtype)
+// LDS -> global with 16-byte stores; MODE 0 plain, 1 += fp32 residual, 2 *= aux (aux in out dtype)
 template <int OSZ, int MODE>
 __device__ __forceinline__ void epi_drain(const char* smem, void* dst, int64_t ld, const void* aux, int64_t ld_aux,
                                           int m0, int n0, int M, int N, int tid) {
@@ -116,15 +121,15 @@ __device__ __forceinline__ void epi_drain(const char* smem, void* dst, int64_t l
         } else if (MODE == 2) {
             if (OSZ == 4) {
                 const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(aux) + (int64_t)gm * ld_aux + gn);
-                v[0] = f2u(u2f(v[0]) * gelu_grad_f(r.x)); v[1] = f2u(u2f(v[1]) * gelu_grad_f(r.y));
-                v[2] = f2u(u2f(v[2]) * gelu_grad_f(r.z)); v[3] = f2u(u2f(v[3]) * gelu_grad_f(r.w));
+                v[0] = f2u(u2f(v[0]) * r.x); v[1] = f2u(u2f(v[1]) * r.y);
+                v[2] = f2u(u2f(v[2]) * r.z); v[3] = f2u(u2f(v[3]) * r.w);
             } else {
                 const chunk16 r = *reinterpret_cast<const chunk16*>(reinterpret_cast<const bf16_t*>(aux) + (int64_t)gm * ld_aux + gn);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t vw = v[e], rw = r[e];
-                    const float lo = bf2f((bf16_t)(vw & 0xffffu)) * gelu_grad_f(bf2f((bf16_t)(rw & 0xffffu)));
-                    const float hi = bf2f((bf16_t)(vw >> 16)) * gelu_grad_f(bf2f((bf16_t)(rw >> 16)));
+                    const float lo = bf2f((bf16_t)(vw & 0xffffu)) * bf2f((bf16_t)(rw & 0xffffu));
+                    const float hi = bf2f((bf16_t)(vw >> 16)) * bf2f((bf16_t)(rw >> 16));
                     v[e] = pack_bf2(lo, hi);
                 }
             }
@@ -133,33 +138,33 @@ __device__ __forceinline__ void epi_drain(const char* smem, void* dst, int64_t l
     }
 }
 
-template <int OSZ>
+template <int OSZ, bool EXACT>
 __device__ __forceinline__ void epi_vector(char* smem, const f32x16_t (&acc)[2][2], const GemmParams& p, int m0, int n0,
                                            int wm, int wn, int lane, int tid) {
     switch (p.epi) {
         case MAEST_EPI_GELU:
             if (p.aux_out != nullptr) {
-                epi_stage<OSZ, false>(smem, acc, p.bias, n0, p.N, wm, wn, lane);
+                epi_stage<OSZ, 2, EXACT>(smem, acc, p.bias, n0, p.N, wm, wn, lane);
                 __syncthreads();
                 epi_drain<OSZ, 0>(smem, p.aux_out, p.ld_aux, nullptr, 0, m0, n0, p.M, p.N, tid);
                 __syncthreads();
             }
-            epi_stage<OSZ, true>(smem, acc, p.bias, n0, p.N, wm, wn, lane);
+            epi_stage<OSZ, 1, EXACT>(smem, acc, p.bias, n0, p.N, wm, wn, lane);
             __syncthreads();
             epi_drain<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, m0, n0, p.M, p.N, tid);
             break;
         case MAEST_EPI_RESIDUAL:
-            epi_stage<OSZ, false>(smem, acc, p.bias, n0, p.N, wm, wn, lane);
+            epi_stage<OSZ, 0, EXACT>(smem, acc, p.bias, n0, p.N, wm, wn, lane);
             __syncthreads();
             epi_drain<OSZ, 1>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, m0, n0, p.M, p.N, tid);
             break;
-        case MAEST_EPI_DGELU:
-            epi_stage<OSZ, false>(smem, acc, p.bias, n0, p.N, wm, wn, lane);
+        case MAEST_EPI_MUL:
+            epi_stage<OSZ, 0, EXACT>(smem, acc, p.bias, n0, p.N, wm, wn, lane);
             __syncthreads();
             epi_drain<OSZ, 2>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, m0, n0, p.M, p.N, tid);
             break;
         default:
-            epi_stage<OSZ, false>(smem, acc, p.bias, n0, p.N, wm, wn, lane);
+            epi_stage<OSZ, 0, EXACT>(smem, acc, p.bias, n0, p.N, wm, wn, lane);
             __syncthreads();
             epi_drain<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, m0, n0, p.M, p.N, tid);
             break;
@@ -167,6 +172,7 @@ __device__ __forceinline__ void epi_vector(char* smem, const f32x16_t (&acc)[2][
 }
 
 // element-wise fallback (ragged N / unaligned leading dims, and the split-K atomic accumulate)
+template <bool EXACT>
 __device__ __forceinline__ void epi_scalar(const f32x16_t (&acc)[2][2], const GemmParams& p, int m0, int n0, int wm,
                                            int wn, int lane, bool add_bias) {
 #pragma unroll
@@ -183,21 +189,24 @@ __device__ __forceinline__ void epi_scalar(const f32x16_t (&acc)[2][2], const Ge
                 const int64_t ci = (int64_t)row * p.ldc + col;
                 const int64_t xi = (int64_t)row * p.ld_aux + col;
                 switch (p.epi) {
-                    case MAEST_EPI_GELU:
+                    case MAEST_EPI_GELU: {
+                        float gv, dv;
+                        gelu_pair<EXACT>(v, gv, dv);
                         if (p.aux_out != nullptr) {
-                            if (p.out_dtype == MAEST_BF16) reinterpret_cast<bf16_t*>(p.aux_out)[xi] = f2bf(v);
-                            else reinterpret_cast<float*>(p.aux_out)[xi] = v;
+                            if (p.out_dtype == MAEST_BF16) reinterpret_cast<bf16_t*>(p.aux_out)[xi] = f2bf(dv);
+                            else reinterpret_cast<float*>(p.aux_out)[xi] = dv;
                         }
-                        v = gelu_f(v);
+                        v = gv;
                         break;
+                    }
                     case MAEST_EPI_RESIDUAL:
                         v += reinterpret_cast<const float*>(p.aux_in)[xi];
                         break;
-                    case MAEST_EPI_DGELU: {
-                        const float pre = (p.out_dtype == MAEST_BF16)
-                                              ? bf2f(reinterpret_cast<const bf16_t*>(p.aux_in)[xi])
-                                              : reinterpret_cast<const float*>(p.aux_in)[xi];
-                        v *= gelu_grad_f(pre);
+                    case MAEST_EPI_MUL: {
+                        const float d = (p.out_dtype == MAEST_BF16)
+                                            ? bf2f(reinterpret_cast<const bf16_t*>(p.aux_in)[xi])
+                                            : reinterpret_cast<const float*>(p.aux_in)[xi];
+                        v *= d;
                         break;
                     }
                     case MAEST_EPI_ATOMIC:
@@ -317,10 +326,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     }
 
     if (p.vec_ok && p.epi != MAEST_EPI_ATOMIC) {
-        if (p.out_dtype == MAEST_BF16) epi_vector<2>(smem, acc, p, m0, n0, wm, wn, lane, tid);
-        else epi_vector<4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+        constexpr bool EXACT = sizeof(T) == 4;   // fp32 parity mode keeps libm erf
+        if (p.out_dtype == MAEST_BF16) epi_vector<2, EXACT>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+        else epi_vector<4, EXACT>(smem, acc, p, m0, n0, wm, wn, lane, tid);
     } else {
-        epi_scalar(acc, p, m0, n0, wm, wn, lane, blockIdx.y == 0);
+        epi_scalar<sizeof(T) == 4>(acc, p, m0, n0, wm, wn, lane, blockIdx.y == 0);
     }
 }
 
@@ -507,6 +517,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmParams p) {
     }
 }
 
+int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int in_dtype, void* C, int64_t ldc,
+                   int out_dtype, int M, int N, int K, const float* bias, int epi, const void* aux_in, void* aux_out,
+                   int64_t ld_aux, hipStream_t stream);   // gemm256.hip
+
 template <typename T>
 static int launch_gemm_nt(GemmParams& p, int split_k, hipStream_t stream) {
     static bool attr_done = false;
@@ -555,7 +569,7 @@ extern "C" int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     MAEST_REQUIRE(split_k == 1 || epi == MAEST_EPI_ATOMIC, "maest_gemm_nt: split_k > 1 needs MAEST_EPI_ATOMIC");
     MAEST_REQUIRE(epi != MAEST_EPI_ATOMIC || out_dtype == MAEST_F32, "maest_gemm_nt: atomic epilogue accumulates fp32");
     MAEST_REQUIRE(epi != MAEST_EPI_RESIDUAL || (aux_in && out_dtype == MAEST_F32), "maest_gemm_nt: residual epilogue needs fp32 aux_in and fp32 out");
-    MAEST_REQUIRE(epi != MAEST_EPI_DGELU || aux_in, "maest_gemm_nt: dgelu epilogue needs aux_in");
+    MAEST_REQUIRE(epi != MAEST_EPI_MUL || aux_in, "maest_gemm_nt: mul epilogue needs aux_in");
     GemmParams p;
     p.A = (const char*)A; p.B = (const char*)B; p.C = C;
     p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.colsum = nullptr;
@@ -572,6 +586,11 @@ extern "C" int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
         vec = vec && (ld_aux % aepc == 0) && ((uintptr_t)aux_in % 16 == 0);
     }
     p.vec_ok = vec ? 1 : 0;
+    if (vec && split_k == 1) {   // large, aligned problems go to the 256x256 LDS-DMA kernel
+        const int rc = gemm_nt256_try(A, lda, B, ldb, in_dtype, C, ldc, out_dtype, M, N, K, bias, epi, aux_in, aux_out,
+                                      ld_aux, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
     p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
     const int total = K / ks;

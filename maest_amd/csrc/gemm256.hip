@@ -1,0 +1,364 @@
+// 256x256-tile NT GEMM for the large ViT linears (same contract and epilogues as gemm.hip:gemm_nt_kernel;
+// reference call sites: nn.Linear forward / dgrad, models/maest.py:353-376, 197-208).
+//
+// Why a second kernel: at 128x128 the global->LDS operand traffic per flop (0.0152 B/flop, ~11 TB/s at
+// 700 TFLOP/s) is what caps the MFMA pipe; a 256x256 tile halves it.  Structure (gfx950):
+//   * 512 threads = 8 waves as 2 (m) x 4 (n); each wave owns 128 x 64 outputs = 4 x 2 MFMA 32x32 tiles,
+//     128 fp32 accumulators per lane (one workgroup per CU, 2 waves per SIMD).
+//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction), no
+//     VGPR round trip.  K is walked in 64-BYTE slices per row (32 bf16 / 16 fp32) through a 4-deep
+//     ring of 32 KiB LDS buffers: the loads of slice s+3 are issued right after the barrier that opens
+//     slice s, and a COUNTED s_waitcnt vmcnt(8) (never 0 in the loop) retires only slice s's loads, so
+//     three slices are always in flight across the (raw) barriers and HBM/L2 latency never reaches the
+//     MFMA pipe.  One barrier per slice.
+//   * LDS-DMA writes are lane-linear (16 rows of 64 B per instruction), so the bank-conflict swizzle is
+//     applied on the SOURCE address: the 16-byte chunk that lands at position p of row r is global chunk
+//     p ^ ((r >> 2) & 3); fragment reads XOR the same value.  A 16-lane ds_read_b128 group then covers
+//     all 16 bank slots exactly once.
+//   * epilogue as in gemm.hip: weight tile is the MFMA A operand, so lanes hold 4 consecutive output
+//     columns; the C tile is staged through (the now idle) LDS in the output dtype in row groups and
+//     written with 16-byte coalesced stores with bias / GELU / residual / GELU' fused.
+#include "common.h"
+
+namespace maest {
+
+constexpr int G2_ROWB = 64;                 // bytes per row per K slice
+constexpr int G2_TILE = 256 * G2_ROWB;      // 16384: one operand tile of one slice
+constexpr int G2_STAGES = 4;
+constexpr int G2_SMEM = G2_STAGES * 2 * G2_TILE;   // 131072
+// s_waitcnt immediate (gfx9 encoding): vmcnt = N, expcnt / lgkmcnt = "no wait"
+#define MAEST_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | 0x0F70)
+
+struct Gemm256Params {
+    const char* A;
+    const char* B;
+    void* C;
+    const float* bias;
+    const void* aux_in;
+    void* aux_out;
+    int64_t lda, ldb, ldc, ld_aux;
+    int M, N, K;
+    int out_dtype, epi;
+    int tiles_m, tiles_n;
+};
+
+template <int OSZ>
+struct Epi256 {
+    static constexpr int PITCH = 256 * OSZ + 16;              // 528 / 1040
+    static constexpr int ROWS = OSZ == 2 ? 128 : 64;          // m rows staged per pass
+    static constexpr int MT = ROWS / 32;                      // wave m-tiles per pass: 4 / 2
+    static constexpr int PASSES = 256 / ROWS;                 // 2 / 4
+    static constexpr int CPR = 256 * OSZ / 16;                // chunks per row: 32 / 64
+    static constexpr int EPC = 16 / OSZ;
+};
+
+template <int OSZ, int GMODE, bool EXACT>
+__device__ __forceinline__ void stage256(char* smem, const f32x16_t (&acc)[2][4], const float* bias, int n0, int N,
+                                         int mt0, int wn, int lane) {
+    using E = Epi256<OSZ>;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = wn * 64 + nt * 32 + 8 * g + 4 * h;
+            float b4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (bias != nullptr && n0 + nl < N) {
+                const float4 t = *reinterpret_cast<const float4*>(bias + n0 + nl);
+                b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w;
+            }
+#pragma unroll
+            for (int mi = 0; mi < E::MT; ++mi) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[nt][mt0 + mi][4 * g + e] + b4[e];
+                    if (GMODE != 0) {
+                        float gv, dv;
+                        gelu_pair<EXACT>(v[e], gv, dv);
+                        v[e] = GMODE == 1 ? gv : dv;
+                    }
+                }
+                char* dst = smem + (mi * 32 + (lane & 31)) * E::PITCH + nl * OSZ;
+                if (OSZ == 4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    chunk8 o;
+                    o[0] = pack_bf2(v[0], v[1]);
+                    o[1] = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<chunk8*>(dst) = o;
+                }
+            }
+        }
+}
+
+// GELU with the derivative side output: value and derivative come out of ONE gelu_pair per element and are
+// staged together, 64 rows (2 wave m-tiles) at a time, into two LDS regions (`smem` and `smem + region`).
+template <int OSZ, bool EXACT, int NMT>
+__device__ __forceinline__ void stage256_pair(char* smem, int region, const f32x16_t (&acc)[2][4], const float* bias,
+                                              int n0, int N, int mt0, int wn, int lane) {
+    using E = Epi256<OSZ>;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = wn * 64 + nt * 32 + 8 * g + 4 * h;
+            float b4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (bias != nullptr && n0 + nl < N) {
+                const float4 t = *reinterpret_cast<const float4*>(bias + n0 + nl);
+                b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w;
+            }
+#pragma unroll
+            for (int mi = 0; mi < NMT; ++mi) {
+                float v[4], d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gelu_pair<EXACT>(acc[nt][mt0 + mi][4 * g + e] + b4[e], v[e], d[e]);
+                char* dst = smem + (mi * 32 + (lane & 31)) * E::PITCH + nl * OSZ;
+                if (OSZ == 4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dst + region) = make_float4(d[0], d[1], d[2], d[3]);
+                } else {
+                    chunk8 o, q;
+                    o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
+                    q[0] = pack_bf2(d[0], d[1]); q[1] = pack_bf2(d[2], d[3]);
+                    *reinterpret_cast<chunk8*>(dst) = o;
+                    *reinterpret_cast<chunk8*>(dst + region) = q;
+                }
+            }
+        }
+}
+
+template <int OSZ, int MODE, int ROWS = Epi256<OSZ>::ROWS>
+__device__ __forceinline__ void drain256(const char* smem, void* dst, int64_t ld, const void* aux, int64_t ld_aux,
+                                         int mbase, int n0, int M, int N, int tid) {
+    using E = Epi256<OSZ>;
+#pragma unroll 4
+    for (int c = tid; c < ROWS * E::CPR; c += 512) {
+        const int row = c / E::CPR, cc = c - row * E::CPR;
+        const int gm = mbase + row, gn = n0 + cc * E::EPC;
+        if (gm >= M || gn >= N) continue;
+        chunk16 v = *reinterpret_cast<const chunk16*>(smem + row * E::PITCH + cc * 16);
+        if (MODE == 1) {
+            const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(aux) + (int64_t)gm * ld_aux + gn);
+            v[0] = f2u(u2f(v[0]) + r.x); v[1] = f2u(u2f(v[1]) + r.y);
+            v[2] = f2u(u2f(v[2]) + r.z); v[3] = f2u(u2f(v[3]) + r.w);
+        } else if (MODE == 2) {
+            if (OSZ == 4) {
+                const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(aux) + (int64_t)gm * ld_aux + gn);
+                v[0] = f2u(u2f(v[0]) * r.x); v[1] = f2u(u2f(v[1]) * r.y);
+                v[2] = f2u(u2f(v[2]) * r.z); v[3] = f2u(u2f(v[3]) * r.w);
+            } else {
+                const chunk16 r = *reinterpret_cast<const chunk16*>(reinterpret_cast<const bf16_t*>(aux) + (int64_t)gm * ld_aux + gn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t vw = v[e], rw = r[e];
+                    const float lo = bf2f((bf16_t)(vw & 0xffffu)) * bf2f((bf16_t)(rw & 0xffffu));
+                    const float hi = bf2f((bf16_t)(vw >> 16)) * bf2f((bf16_t)(rw >> 16));
+                    v[e] = pack_bf2(lo, hi);
+                }
+            }
+        }
+        *reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ) = v;
+    }
+}
+
+template <int OSZ, bool EXACT>
+__device__ __forceinline__ void epilogue256(char* smem, const f32x16_t (&acc)[2][4], const Gemm256Params& p, int m0,
+                                            int n0, int wm, int wn, int lane, int tid) {
+    using E = Epi256<OSZ>;
+    if (p.epi == MAEST_EPI_GELU && p.aux_out != nullptr) {
+        constexpr int PR = OSZ == 2 ? 64 : 32;       // rows per pass (fp32 rows are twice as wide)
+        constexpr int PMT = PR / 32;
+        constexpr int REGION = PR * E::PITCH;        // 33792 (bf16) / 33280 (fp32); two regions per pass
+#pragma unroll
+        for (int ps = 0; ps < 256 / PR; ++ps) {
+            const int pwm = ps / (4 / PMT);
+            const int mt0 = (ps % (4 / PMT)) * PMT;
+            const int mbase = m0 + pwm * 128 + mt0 * 32;
+            if (wm == pwm) stage256_pair<OSZ, EXACT, PMT>(smem, REGION, acc, p.bias, n0, p.N, mt0, wn, lane);
+            __syncthreads();
+            drain256<OSZ, 0, PR>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
+            drain256<OSZ, 0, PR>(smem + REGION, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
+            __syncthreads();
+        }
+        return;
+    }
+#pragma unroll
+    for (int ps = 0; ps < E::PASSES; ++ps) {
+        const int pwm = ps / (4 / E::MT);
+        const int mt0 = (ps % (4 / E::MT)) * E::MT;
+        const int mbase = m0 + pwm * 128 + mt0 * 32;
+        const bool mine = (wm == pwm);   // wave-uniform
+        if (p.epi == MAEST_EPI_GELU) {
+            if (p.aux_out != nullptr) {
+                if (mine) stage256<OSZ, 2, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
+                __syncthreads();
+                drain256<OSZ, 0>(smem, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
+                __syncthreads();
+            }
+            if (mine) stage256<OSZ, 1, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
+            __syncthreads();
+            drain256<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
+        } else {
+            if (mine) stage256<OSZ, 0, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
+            __syncthreads();
+            if (p.epi == MAEST_EPI_RESIDUAL)
+                drain256<OSZ, 1>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
+            else if (p.epi == MAEST_EPI_MUL)
+                drain256<OSZ, 2>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
+            else
+                drain256<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(Gemm256Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;          // 0..7
+    const int wm = wave >> 2, wn = wave & 3;
+    const int h = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = wg / p.tiles_n;
+    const int tile_n = wg - tile_m * p.tiles_n;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+
+    constexpr int ELT = (int)sizeof(T);
+    constexpr int KS = G2_ROWB / ELT;        // 32 / 16 elements per slice
+    const int nslices = p.K / KS;
+
+    // LDS-DMA map: wave-instruction (wave, i) fills rows [(wave*2+i)*16, +16) of a tile; lane -> (row, position)
+    const char* a_src[2];
+    const char* b_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 16 + (lane >> 2);
+        const int csrc = (lane & 3) ^ ((r >> 2) & 3);        // source-side swizzle
+        int ra = m0 + r;
+        if (ra > p.M - 1) ra = p.M - 1;
+        int rb = n0 + r;
+        if (rb > p.N - 1) rb = p.N - 1;
+        a_src[i] = p.A + (int64_t)ra * p.lda * ELT + csrc * 16;
+        b_src[i] = p.B + (int64_t)rb * p.ldb * ELT + csrc * 16;
+    }
+    const int dma_off = wave * 2 * 1024;
+
+    f32x16_t acc[2][4];   // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // half h2 (0/1) of the 4 LDS-DMA instructions this wave owes to slice s: one A piece + one B piece
+    auto issue_half = [&](int s, int h2) {
+        const int sc = s < nslices ? s : nslices - 1;        // past-the-end issues re-load the last slice into a dead
+        char* la = smem + (s & (G2_STAGES - 1)) * 2 * G2_TILE + dma_off;   // buffer: keeps the vmcnt arithmetic uniform
+        char* lb = la + G2_TILE;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[h2] + (int64_t)sc * G2_ROWB),
+                                         (__attribute__((address_space(3))) void*)(la + h2 * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[h2] + (int64_t)sc * G2_ROWB),
+                                         (__attribute__((address_space(3))) void*)(lb + h2 * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int s) { issue_half(s, 0); issue_half(s, 1); };
+
+    int a_off[4], b_off[2], a_swz[4], b_swz[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int row = wm * 128 + mt * 32 + (lane & 31);
+        a_off[mt] = row * G2_ROWB;
+        a_swz[mt] = (row >> 2) & 3;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int row = wn * 64 + nt * 32 + (lane & 31);
+        b_off[nt] = row * G2_ROWB;
+        b_swz[nt] = (row >> 2) & 3;
+    }
+
+    // ---- main loop: two phases per slice, LOAD (LDS -> fragment registers, issue the DMA of slice s+3) and
+    // COMPUTE (16 MFMAs, no memory traffic), separated by raw barriers.  The second wave group (wm == 1)
+    // runs ONE BARRIER BEHIND the first, so on every SIMD one wave is in COMPUTE while its partner is in
+    // LOAD: the matrix pipe never waits for ds_read / DMA issue, and those never wait for the pipe.
+    //   barrier 2s   : A: LOAD(s)     B: COMPUTE(s-1)
+    //   barrier 2s+1 : A: COMPUTE(s)  B: LOAD(s)
+    // Slice s is resident before anybody reads it: every wave ends LOAD(s-1) with vmcnt(8) (slices s+1, s+2
+    // may still fly) and the barrier(s) in between publish that to the other group.  DMA of slice s+3
+    // overwrites buffer (s-1)&3, whose last reader (B's LOAD(s-1)) finished before barrier 2s.
+    issue(0);
+    issue(1);
+    issue(2);
+    MAEST_WAIT_VMCNT(8);
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger (wave-uniform)
+    chunk16 fa[2][4], fb[2][2];
+    for (int s = 0; s < nslices; ++s) {
+        const char* la = smem + (s & (G2_STAGES - 1)) * 2 * G2_TILE;
+        const char* lb = la + G2_TILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kc = 2 * ks + h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                fa[ks][mt] = *reinterpret_cast<const chunk16*>(la + a_off[mt] + ((kc ^ a_swz[mt]) << 4));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                fb[ks][nt] = *reinterpret_cast<const chunk16*>(lb + b_off[nt] + ((kc ^ b_swz[nt]) << 4));
+        }
+        issue(s + 3);
+        __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): slice s+1 resident, fragments in registers
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();          // un-stagger
+    MAEST_WAIT_VMCNT(0);   // drain the past-the-end loads before LDS is reused
+    __syncthreads();   // every wave is done with the operand buffers: LDS becomes the C staging area
+    if (p.out_dtype == MAEST_BF16) epilogue256<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+    else epilogue256<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+}
+
+template <typename T>
+static int launch256(Gemm256Params& p, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_nt256_kernel<T>, dim3(p.tiles_m * p.tiles_n), dim3(512), G2_SMEM, stream, p);
+    return check_launch("maest_gemm_nt(256)");
+}
+
+// Called by maest_gemm_nt for large, 16-byte-friendly problems.  Returns -1 when the shape does not qualify.
+int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int in_dtype, void* C, int64_t ldc,
+                   int out_dtype, int M, int N, int K, const float* bias, int epi, const void* aux_in, void* aux_out,
+                   int64_t ld_aux, hipStream_t stream) {
+    if (epi == MAEST_EPI_ATOMIC) return -1;
+    if (M < 512 || N < 256 || (N % 256) != 0) return -1;
+    if ((K * (in_dtype == MAEST_BF16 ? 2 : 4)) % G2_ROWB != 0) return -1;
+    Gemm256Params p;
+    p.A = (const char*)A; p.B = (const char*)B; p.C = C;
+    p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux;
+    p.M = M; p.N = N; p.K = K; p.out_dtype = out_dtype; p.epi = epi;
+    p.tiles_m = (M + 255) / 256;
+    p.tiles_n = N / 256;
+    return in_dtype == MAEST_BF16 ? launch256<bf16_t>(p, stream) : launch256<float>(p, stream);
+}
+
+}  // namespace maest

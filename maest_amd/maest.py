@@ -318,7 +318,7 @@ class _Engine:
             done(p + "mlp.fc2.weight", _wgrad(dx_lp, s["g"], EMBED_DIM, H, buf(p + "mlp.fc2.weight", EMBED_DIM, H), gb))
             done(p + "mlp.fc2.bias", gb)
             dh = ops.gemm_nt(dx_lp, W.get(blk.mlp.fc2.weight, dt, transposed=True), None, out_dtype=dt,
-                             epi=ops.EPI_DGELU, aux_in=s["h"])
+                             epi=ops.EPI_MUL, aux_in=s["h"])
             # fc1
             gb = buf(p + "mlp.fc1.bias", H)
             done(p + "mlp.fc1.weight", _wgrad(dh, s["ln2"], H, EMBED_DIM, buf(p + "mlp.fc1.weight", H, EMBED_DIM), gb))

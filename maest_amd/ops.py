@@ -8,7 +8,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_ATOMIC, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F32, call
+from ._lib import BF16, EPI_ATOMIC, EPI_MUL, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F32, call
 
 DT = {torch.float32: F32, torch.bfloat16: BF16}
 

@@ -22,6 +22,9 @@ for (nm, N, K) in [("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), (
     res = torch.randn(M, N, device=dev)
     bench(f"{nm} fwd residual->f32", lambda: ops.gemm_nt(a, w, bias, out=out32, epi=ops.EPI_RESIDUAL, aux_in=res), 2.0*M*N*K)
     bench(f"{nm} fwd gelu->bf16", lambda: ops.gemm_nt(a, w, bias, out=out_bf, epi=ops.EPI_GELU), 2.0*M*N*K)
+    aux = torch.empty(M, N, device=dev, dtype=dt)
+    bench(f"{nm} fwd gelu+aux->bf16", lambda: ops.gemm_nt(a, w, bias, out=out_bf, epi=ops.EPI_GELU, aux_out=aux), 2.0*M*N*K)
+    bench(f"{nm} mul->bf16", lambda: ops.gemm_nt(a, w, None, out=out_bf, epi=ops.EPI_MUL, aux_in=aux), 2.0*M*N*K)
 # wgrad: dW[N,K] = dY^T[N,Mpad] X^T[K,Mpad]
 for (nm, N, K) in [("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]:
     at = mk(N, M); bt = mk(K, M)

@@ -177,6 +177,14 @@ static inline emu_v4i16 emu_ds_read_tr16_b64(const void* p) {
 }
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void*)(uintptr_t)(p))
 
+// global_load_lds_dwordx4 (LDS-DMA): LDS destination = wave-uniform base + lane * size.  The emulator
+// performs the copy immediately (it cannot model the asynchrony; races are a GPU-test concern).
+static inline void emu_global_load_lds(const void* g, void* l, unsigned size, int offset, unsigned) {
+    memcpy(reinterpret_cast<char*>(l) + offset + emu::lane() * size, reinterpret_cast<const char*>(g) + offset, size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
+    emu_global_load_lds((const void*)(uintptr_t)(g), (void*)(uintptr_t)(l), size, off, aux)
+
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
     static_assert(sizeof(T) == 4, "emu shuffle: 32-bit types only");
@@ -226,4 +234,6 @@ static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
+static inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}

@@ -56,19 +56,19 @@ def case_gemm(dev, dtype, M, N, K, seed=0):
     aux = torch.empty((M, N), dtype=dtype, device=dev)
     g = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_dtype=dtype, epi=ops.EPI_GELU, aux_out=aux)
     rt2, at2 = (1e-5, at) if dtype == torch.float32 else (1e-2, 1e-2)
-    close(aux, ref, rt2, at2 * math.sqrt(K / 64), "gemm gelu aux")
+    xr = ref.clone().requires_grad_(True)
+    F.gelu(xr).sum().backward()
+    close(aux, xr.grad, rt2, max(at2 * math.sqrt(K / 64), 2e-6), "gemm gelu aux (= gelu' saved for backward)")
     close(g, F.gelu(ref), rt2, at2 * math.sqrt(K / 64), "gemm gelu")
     # residual epilogue
     res = rnd((M, N), seed + 3)
     c = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_dtype=torch.float32, epi=ops.EPI_RESIDUAL,
                     aux_in=res.to(dev))
     close(c, ref + res, rt, at * math.sqrt(K / 64), "gemm residual")
-    # dgelu epilogue
+    # mul epilogue (dgrad through GELU: acc * saved gelu')
     pre = rnd((M, N), seed + 4).to(dtype)
-    c = ops.gemm_nt(a.to(dev), b.to(dev), None, out_dtype=dtype, epi=ops.EPI_DGELU, aux_in=pre.to(dev))
-    x = pre.float().requires_grad_(True)
-    F.gelu(x).sum().backward()
-    close(c, (ref - bias) * x.grad, rt2, at2 * math.sqrt(K / 64), "gemm dgelu")
+    c = ops.gemm_nt(a.to(dev), b.to(dev), None, out_dtype=dtype, epi=ops.EPI_MUL, aux_in=pre.to(dev))
+    close(c, (ref - bias) * pre.float(), rt2, at2 * math.sqrt(K / 64), "gemm mul")
     # split-K atomic accumulate
     acc = torch.zeros((M, N), dtype=torch.float32, device=dev)
     ops.gemm_nt(a.to(dev), b.to(dev), None, out=acc, epi=ops.EPI_ATOMIC, split_k=3)

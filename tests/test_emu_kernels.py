@@ -22,6 +22,13 @@ def test_emu_gemm_ragged_n_scalar_epilogue(emu, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype):
+    """M >= 512 and N % 256 == 0 route to gemm256.hip (LDS-DMA staging, source-side swizzle)."""
+    K = 64 if dtype == torch.float32 else 128
+    KC.case_gemm(emu, dtype, 530, 256, K)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_emu_gemm_tn(emu, dtype):
     KC.case_gemm_tn(emu, dtype, 150, 136, 200)
     KC.case_gemm_tn(emu, dtype, 40, 24, 72, lda_pad=8)
