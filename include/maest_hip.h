@@ -63,7 +63,7 @@ int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int in
  *   colsum[m] (fp32, ACCUMULATED, may be NULL) += sum_k A[k,m]              (= the bias gradient)
  * dW = dY^T X of nn.Linear backward with A = dY [tokens, out], B = X [tokens, in].  Any K (the token
  * tail is zero-filled in LDS); rows of A / B must be 16-byte multiples (lda / ldb) and may be wider
- * than M / N.  split_k partials are combined with fp32 atomics. */
+ * than M / N.  split_k partials are combined with fp32 atomics; split_k = 0 picks it automatically. */
 int maest_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C,
                   int64_t ldc, int M, int N, int K, float* colsum, int split_k, void* stream);
 

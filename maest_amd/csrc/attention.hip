@@ -8,8 +8,10 @@
 //
 // MFMA scheme (wave64, 32x32 tiles, head_dim = 64).  A 32x32 MFMA leaves D with lane <-> column and
 // registers <-> rows; such a D can be fed back, register-for-register, as the B operand of a second
-// MFMA whose reduction runs over D's ROW index, provided the A operand is read with the same
-// row permutation from a TRANSPOSED LDS tile (common.h: acc_to_chunk / read_transposed_chunk).
+// MFMA whose reduction runs over D's ROW index, provided the A operand is gathered with the same
+// row permutation.  That gather is done straight from the ROW-MAJOR LDS tile by the gfx950 transpose
+// read ds_read_b64_tr_b16 (bf16; 4 consecutive rows of one column per lane) or ds_read_b32 (fp32):
+// no transposed copies of K / V / Q / dO are ever built (common.h: acc_to_chunk, frag_from_rows).
 // Hence, with "^T" meaning "keys/queries on the D-row axis":
 //   forward   S^T = K Q^T            -> softmax stats are per lane (lane = query)
 //             O^T = V^T P^T          (A = V^T tile in LDS, B = P^T registers)
@@ -128,18 +130,46 @@ __device__ __forceinline__ void mma_rows(f32x16_t& acc, const char* lds, int row
         mma_chunk<T>(acc, a, frag[s]);
     }
 }
-// acc2[d-block db][32 d x 32 cols] += sum_{rho in 32-row group rho0} At[d][rho] * P[rho][col]
+// A-operand chunk At[d][rho] = Tile[rho][d] for step s of the 32-row group rho0, d = dblk*32 + (lane&31),
+// gathered from the ROW-MAJOR tile with the row permutation of acc_to_chunk:
+//   bf16: rows 16s + 4h + (0..3) and 16s + 8 + 4h + (0..3)  -> two ds_read_b64_tr_b16
+//   fp32: rows  8s + 4h + (0..3)                            -> four ds_read_b32
+typedef short v4i16a_t __attribute__((ext_vector_type(4)));
 template <typename T>
-__device__ __forceinline__ void mma_transposed(f32x16_t (&acc)[2], const char* lds_t, int rho0, int lane,
+__device__ __forceinline__ chunk16 frag_from_rows(const char* tile, int rho0, int s, int dblk, int lane);
+template <>
+__device__ __forceinline__ chunk16 frag_from_rows<bf16_t>(const char* tile, int rho0, int s, int dblk, int lane) {
+    using C = AttnCfg<bf16_t>;
+    const int h = lane >> 5, g16 = (lane >> 4) & 1, q = lane & 15;
+    const char* p = tile + (rho0 + 16 * s + 4 * h + (q >> 2)) * C::PITCH + (dblk * 32 + 16 * g16 + 4 * (q & 3)) * 2;
+    const v4i16a_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16a_t*)(p));
+    const v4i16a_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16a_t*)(p + 8 * C::PITCH));
+    const chunk8 l2 = __builtin_bit_cast(chunk8, lo), h2 = __builtin_bit_cast(chunk8, hi);   // no repacking
+    chunk16 c;
+    c[0] = l2[0]; c[1] = l2[1]; c[2] = h2[0]; c[3] = h2[1];
+    return c;
+}
+template <>
+__device__ __forceinline__ chunk16 frag_from_rows<float>(const char* tile, int rho0, int s, int dblk, int lane) {
+    using C = AttnCfg<float>;
+    const int h = lane >> 5;
+    const char* p = tile + (rho0 + 8 * s + 4 * h) * C::PITCH + (dblk * 32 + (lane & 31)) * 4;
+    chunk16 c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = *reinterpret_cast<const uint32_t*>(p + j * C::PITCH);
+    return c;
+}
+// acc2[d-block db][32 d x 32 cols] += sum_{rho in 32-row group rho0} Tile[rho][d] * P[rho][col]
+template <typename T>
+__device__ __forceinline__ void mma_transposed(f32x16_t (&acc)[2], const char* tile, int rho0, int lane,
                                                const f32x16_t& p) {
     using C = AttnCfg<T>;
-    const int h = lane >> 5;
 #pragma unroll
     for (int s = 0; s < C::ASTEPS; ++s) {
         const chunk16 b = acc_to_chunk<T>(p, s);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-            const chunk16 a = read_transposed_chunk<T>(lds_t + (db * 32 + (lane & 31)) * C::PITCH_T, rho0, s, h);
+            const chunk16 a = frag_from_rows<T>(tile, rho0, s, db, lane);
             mma_chunk<T>(acc[db], a, b);
         }
     }
@@ -172,12 +202,12 @@ __device__ __forceinline__ void store_dT(const f32x16_t (&acc)[2], T* row_ptr, i
 
 // =================================================================================== forward
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                       float* __restrict__ lse, int N, float scale) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(const T* __restrict__ qkv,
+                                                                                T* __restrict__ out,
+                                                                                float* __restrict__ lse, int N,
+                                                                                float scale) {
     using C = AttnCfg<T>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* k_lds = smem;               // K[key][d]
-    char* vt_lds = smem + C::TILE;    // V^T[d][key]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[key][d], V[key][d] }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -202,12 +232,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     TileRegs<T> kr, vr;
     tile_load<T>(kr, kbase, QKV_LD, 0, N, tid);
     tile_load<T>(vr, vbase, QKV_LD, 0, N, tid);
+    tile_store_rows<T>(kr, smem, tid);
+    tile_store_rows<T>(vr, smem + C::TILE, tid);
+    __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();  // previous tile fully consumed
-        tile_store_rows<T>(kr, k_lds, tid);
-        tile_store_transposed<T>(vr, vt_lds, tid);
-        __syncthreads();
-        if (kt + 1 < ntiles) {
+        const char* k_lds = smem + (kt & 1) * 2 * C::TILE;
+        const char* v_lds = k_lds + C::TILE;
+        const bool more = kt + 1 < ntiles;
+        if (more) {
             tile_load<T>(kr, kbase, QKV_LD, (kt + 1) * 64, N, tid);
             tile_load<T>(vr, vbase, QKV_LD, (kt + 1) * 64, N, tid);
         }
@@ -247,9 +279,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        // O^T[d][q] += V^T[d][key] P^T[key][q]
+        // O^T[d][q] += V^T[d][key] P^T[key][q]   (V^T gathered from the row-major V tile)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) mma_transposed<T>(o, vt_lds, kb * 32, lane, s[kb]);
+        for (int kb = 0; kb < 2; ++kb) mma_transposed<T>(o, v_lds, kb * 32, lane, s[kb]);
+        if (more) {
+            char* nk = smem + ((kt + 1) & 1) * 2 * C::TILE;
+            tile_store_rows<T>(kr, nk, tid);
+            tile_store_rows<T>(vr, nk + C::TILE, tid);
+        }
+        __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -288,18 +326,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 
 // =================================================================================== dK, dV
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                            const float* __restrict__ lse,
-                                                            const float* __restrict__ delta,
-                                                            T* __restrict__ dqkv, int N, float scale) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_kernel(
+    const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, T* __restrict__ dqkv, int N, float scale) {
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* q_lds = smem;                          // Q[q][d]
-    char* do_lds = q_lds + C::TILE;              // dO[q][d]
-    char* qt_lds = do_lds + C::TILE;             // Q^T[d][q]
-    char* dot_lds = qt_lds + C::TILE_T;          // dO^T[d][q]
-    float* lse_lds = reinterpret_cast<float*>(dot_lds + C::TILE_T);  // [64] (pre-multiplied by log2e)
-    float* dl_lds = lse_lds + 64;                                    // [64]
+    // 2 x { Q[q][d], dO[q][d], lse[64] (pre-multiplied by log2e), delta[64] }
+    constexpr int BUF = 2 * C::TILE + 512;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -325,24 +358,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
 
     const int ntiles = (N + 63) / 64;
     TileRegs<T> qr, dr;
-    tile_load<T>(qr, qbase, QKV_LD, 0, N, tid);
-    tile_load<T>(dr, dobase, OUT_LD, 0, N, tid);
-    for (int qt = 0; qt < ntiles; ++qt) {
-        __syncthreads();
-        tile_store_rows<T>(qr, q_lds, tid);
-        tile_store_rows<T>(dr, do_lds, tid);
-        tile_store_transposed<T>(qr, qt_lds, tid);
-        tile_store_transposed<T>(dr, dot_lds, tid);
+    float lse_r = 0.0f, dl_r = 0.0f;
+    auto load_tile = [&](int qt) {
+        tile_load<T>(qr, qbase, QKV_LD, qt * 64, N, tid);
+        tile_load<T>(dr, dobase, OUT_LD, qt * 64, N, tid);
         if (tid < 64) {
             const int qq = qt * 64 + tid;
-            lse_lds[tid] = qq < N ? lse_b[qq] * LOG2E : 0.0f;
-            dl_lds[tid] = qq < N ? dl_b[qq] : 0.0f;
+            lse_r = qq < N ? lse_b[qq] * LOG2E : 0.0f;
+            dl_r = qq < N ? dl_b[qq] : 0.0f;
         }
-        __syncthreads();
-        if (qt + 1 < ntiles) {
-            tile_load<T>(qr, qbase, QKV_LD, (qt + 1) * 64, N, tid);
-            tile_load<T>(dr, dobase, OUT_LD, (qt + 1) * 64, N, tid);
+    };
+    auto store_tile = [&](int buf) {
+        char* base = smem + buf * BUF;
+        tile_store_rows<T>(qr, base, tid);
+        tile_store_rows<T>(dr, base + C::TILE, tid);
+        if (tid < 64) {
+            reinterpret_cast<float*>(base + 2 * C::TILE)[tid] = lse_r;
+            reinterpret_cast<float*>(base + 2 * C::TILE)[64 + tid] = dl_r;
         }
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const char* q_lds = smem + (qt & 1) * BUF;
+        const char* do_lds = q_lds + C::TILE;
+        const float* lse_lds = reinterpret_cast<const float*>(q_lds + 2 * C::TILE);
+        const float* dl_lds = lse_lds + 64;
+        const bool more = qt + 1 < ntiles;
+        if (more) load_tile(qt + 1);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16_t s, dp;
@@ -366,9 +410,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
                     dp[r] = p * (dp[r] - dvv[e]);   // dS (unscaled)
                 }
             }
-            mma_transposed<T>(dv, dot_lds, qb * 32, lane, s);   // dV^T[d][key] += dO^T[d][q] P[q][key]
-            mma_transposed<T>(dk, qt_lds, qb * 32, lane, dp);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            mma_transposed<T>(dv, do_lds, qb * 32, lane, s);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+            mma_transposed<T>(dk, q_lds, qb * 32, lane, dp);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
         }
+        if (more) store_tile((qt + 1) & 1);
+        __syncthreads();
     }
     if (key_ok) {
         T* row = dqkv + ((int64_t)b * N + key) * QKV_LD + head * HD;
@@ -379,15 +425,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
 
 // =================================================================================== dQ
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                          const float* __restrict__ lse,
-                                                          const float* __restrict__ delta,
-                                                          T* __restrict__ dqkv, int N, float scale) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kernel(
+    const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, T* __restrict__ dqkv, int N, float scale) {
     using C = AttnCfg<T>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* k_lds = smem;                 // K[key][d]
-    char* v_lds = k_lds + C::TILE;      // V[key][d]
-    char* kt_lds = v_lds + C::TILE;     // K^T[d][key]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[key][d], V[key][d] }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -416,13 +458,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     TileRegs<T> kr, vr;
     tile_load<T>(kr, kbase, QKV_LD, 0, N, tid);
     tile_load<T>(vr, vbase, QKV_LD, 0, N, tid);
+    tile_store_rows<T>(kr, smem, tid);
+    tile_store_rows<T>(vr, smem + C::TILE, tid);
+    __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
-        tile_store_rows<T>(kr, k_lds, tid);
-        tile_store_rows<T>(vr, v_lds, tid);
-        tile_store_transposed<T>(kr, kt_lds, tid);
-        __syncthreads();
-        if (kt + 1 < ntiles) {
+        const char* k_lds = smem + (kt & 1) * 2 * C::TILE;
+        const char* v_lds = k_lds + C::TILE;
+        const bool more = kt + 1 < ntiles;
+        if (more) {
             tile_load<T>(kr, kbase, QKV_LD, (kt + 1) * 64, N, tid);
             tile_load<T>(vr, vbase, QKV_LD, (kt + 1) * 64, N, tid);
         }
@@ -439,8 +482,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
                 const float p = (kk < N) ? exp2f(s[r] * c2 - lse_q) : 0.0f;
                 dp[r] = p * (dp[r] - dl_q);   // dS^T (unscaled)
             }
-            mma_transposed<T>(dq, kt_lds, kb * 32, lane, dp);   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+            mma_transposed<T>(dq, k_lds, kb * 32, lane, dp);   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
         }
+        if (more) {
+            char* nk = smem + ((kt + 1) & 1) * 2 * C::TILE;
+            tile_store_rows<T>(kr, nk, tid);
+            tile_store_rows<T>(vr, nk + C::TILE, tid);
+        }
+        __syncthreads();
     }
     if (q_ok) store_dT<T>(dq, dqkv + ((int64_t)b * N + q) * QKV_LD + head * HD, lane, scale);
 }
@@ -448,7 +497,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
 template <typename T>
 static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, hipStream_t st) {
     using C = AttnCfg<T>;
-    const int smem_bytes = C::TILE + C::TILE_T;
+    const int smem_bytes = 4 * C::TILE;
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T>),
@@ -464,8 +513,8 @@ template <typename T>
 static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                            void* dqkv, int B, int N, float scale, hipStream_t st) {
     using C = AttnCfg<T>;
-    const int smem_a = 2 * C::TILE + 2 * C::TILE_T + 512;
-    const int smem_b = 2 * C::TILE + C::TILE_T;
+    const int smem_a = 2 * (2 * C::TILE + 512);
+    const int smem_b = 4 * C::TILE;
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T>),

@@ -363,11 +363,9 @@ __device__ __forceinline__ chunk16 load_frag_tn<bf16_t>(const char* tile, int ks
     // lane receives T[kb + j][iblk + (lane & 31)], j = 0..3  (ds_read_b64_tr_b16)
     const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)(p));
     const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)(p + 4 * C::PITCH));
+    const chunk8 l2 = __builtin_bit_cast(chunk8, lo), h2 = __builtin_bit_cast(chunk8, hi);   // no repacking
     chunk16 c;
-    c[0] = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
-    c[1] = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
-    c[2] = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
-    c[3] = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    c[0] = l2[0]; c[1] = l2[1]; c[2] = h2[0]; c[3] = h2[1];
     return c;
 }
 template <>
@@ -521,6 +519,9 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
                    int out_dtype, int M, int N, int K, const float* bias, int epi, const void* aux_in, void* aux_out,
                    int64_t ld_aux, hipStream_t stream);   // gemm256.hip
 
+int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C, int64_t ldc, int M,
+                   int N, int K, float* colsum, int split_k, hipStream_t stream);   // gemm256.hip
+
 template <typename T>
 static int launch_gemm_nt(GemmParams& p, int split_k, hipStream_t stream) {
     static bool attr_done = false;
@@ -610,7 +611,15 @@ extern "C" int maest_gemm_tn(const void* A, int64_t lda, const void* B, int64_t 
     MAEST_REQUIRE(lda >= M && ldb >= N, "maest_gemm_tn: leading dims smaller than the matrix width");
     MAEST_REQUIRE((lda * elt) % 16 == 0 && (ldb * elt) % 16 == 0, "maest_gemm_tn: lda/ldb rows must be 16-byte multiples");
     MAEST_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "maest_gemm_tn: A/B must be 16-byte aligned");
-    MAEST_REQUIRE(split_k >= 1, "maest_gemm_tn: split_k must be >= 1");
+    MAEST_REQUIRE(split_k >= 0, "maest_gemm_tn: split_k must be >= 0 (0 = automatic)");
+    {   // large aligned problems go to the 256x256 LDS-DMA kernel
+        const int rc = gemm_tn256_try(A, lda, B, ldb, dtype, C, ldc, M, N, K, colsum, split_k, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
+    if (split_k == 0) {
+        const int t = ((M + 127) / 128) * ((N + 127) / 128);
+        split_k = 1024 / t > 0 ? 1024 / t : 1;
+    }
     GemmParams p;
     p.A = (const char*)A; p.B = (const char*)B; p.C = C;
     p.bias = nullptr; p.aux_in = nullptr; p.aux_out = nullptr; p.colsum = colsum;

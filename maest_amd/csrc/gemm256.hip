@@ -361,4 +361,225 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
     return in_dtype == MAEST_BF16 ? launch256<bf16_t>(p, stream) : launch256<float>(p, stream);
 }
 
+
+// ================================================================================================
+// 256x256-tile TN GEMM (wgrad + bias grad):  C[i][j] += sum_k A[k][i] * B[k][j],  colsum[i] += sum_k A[k][i]
+// Same ring / stagger structure as gemm_nt256_kernel; operands stay token-major.  A slice is 32 (bf16) /
+// 16 (fp32) token rows of 256 columns = 16 KiB per operand; one LDS-DMA instruction moves 1 KiB = 2 (bf16)
+// or 1 (fp32) whole rows.  Fragments come from ds_read_b64_tr_b16 (bf16) / ds_read_b32 (fp32).  The 4 token
+// rows of a transpose read sit 512 B apart (same banks), so the SOURCE-side swizzle XORs (row & 3) into
+// bits 2-3 of the 16-byte chunk index: the four 64-byte row segments then land on the four bank quarters.
+// Requires M % 256 == 0, N % 256 == 0 and K % slice == 0 (else the caller uses gemm_tn_kernel).
+// ================================================================================================
+template <typename T>
+struct Tn256 {
+    static constexpr int ELT = (int)sizeof(T);
+    static constexpr int RB = 256 * ELT;             // bytes per tile row: 512 / 1024
+    static constexpr int KS = G2_TILE / RB;          // token rows per slice: 32 / 16
+    static constexpr int RPI = 1024 / RB;            // rows per DMA instruction: 2 / 1
+    static constexpr int KSTEP = ELT == 2 ? 16 : 8;  // k per chunk step
+};
+
+typedef short v4i16b_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ chunk16 frag_tn256(const char* tile, int ks, int iblk, int lane);
+template <>
+__device__ __forceinline__ chunk16 frag_tn256<bf16_t>(const char* tile, int ks, int iblk, int lane) {
+    const int h = lane >> 5, g16 = (lane >> 4) & 1, q = lane & 15;
+    const int row = ks * 16 + 8 * h + (q >> 2);                 // row & 3 == (q >> 2) & 3 for both reads
+    const int cb = (iblk + 16 * g16 + 4 * (q & 3)) * 2;         // logical byte column
+    const int pb = ((((cb >> 4) ^ ((row & 3) << 2))) << 4) | (cb & 15);
+    const char* p = tile + row * 512 + pb;
+    const v4i16b_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16b_t*)(p));
+    const v4i16b_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16b_t*)(p + 4 * 512));
+    const chunk8 l2 = __builtin_bit_cast(chunk8, lo), h2 = __builtin_bit_cast(chunk8, hi);   // no repacking
+    chunk16 c;
+    c[0] = l2[0]; c[1] = l2[1]; c[2] = h2[0]; c[3] = h2[1];
+    return c;
+}
+template <>
+__device__ __forceinline__ chunk16 frag_tn256<float>(const char* tile, int ks, int iblk, int lane) {
+    const int h = lane >> 5;
+    const int cb = (iblk + (lane & 31)) * 4;
+    chunk16 c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = ks * 8 + 4 * h + q;
+        const int pb = ((((cb >> 4) ^ ((row & 3) << 2))) << 4) | (cb & 15);
+        c[q] = *reinterpret_cast<const uint32_t*>(tile + row * 1024 + pb);
+    }
+    return c;
+}
+
+struct GemmTn256Params {
+    const char* A;
+    const char* B;
+    float* C;
+    float* colsum;
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    int k_slices_per_split;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
+    using C = Tn256<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tile_i = wg / p.tiles_n;
+    const int tile_j = wg - tile_i * p.tiles_n;
+    const int i0 = tile_i * 256, j0 = tile_j * 256;
+
+    const int total_slices = p.K / C::KS;
+    const int s_begin = blockIdx.y * p.k_slices_per_split;
+    int s_end = s_begin + p.k_slices_per_split;
+    if (s_end > total_slices) s_end = total_slices;
+    const int nslices = s_end - s_begin;
+
+    // LDS-DMA map: wave-instruction (wave, i) fills rows [(wave*2+i)*RPI, +RPI) of a slice tile
+    const char* a_src[2];
+    const char* b_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * C::RPI + (C::RPI == 2 ? (lane >> 5) : 0);
+        const int pc = C::RPI == 2 ? (lane & 31) : lane;       // physical 16-byte chunk within the row
+        const int lc = pc ^ ((row & 3) << 2);                   // logical chunk fetched from global
+        a_src[i] = p.A + ((int64_t)(s_begin * C::KS + row) * p.lda + i0) * C::ELT + lc * 16;
+        b_src[i] = p.B + ((int64_t)(s_begin * C::KS + row) * p.ldb + j0) * C::ELT + lc * 16;
+    }
+    const int dma_off = wave * 2 * 1024;
+    const int64_t a_step = (int64_t)C::KS * p.lda * C::ELT, b_step = (int64_t)C::KS * p.ldb * C::ELT;
+
+    f32x16_t acc[4][2];   // [a: i-block][b: j-block]
+    float cs[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // bias-gradient partials: column lane&31 of i-block a, this lane's k half
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const bool do_colsum = (p.colsum != nullptr) && (tile_j == 0) && (wn == 0);   // wave-uniform
+
+    auto issue = [&](int s) {
+        const int sc = s < nslices ? s : nslices - 1;
+        char* la = smem + (s & (G2_STAGES - 1)) * 2 * G2_TILE + dma_off;
+        char* lb = la + G2_TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + sc * a_step),
+                                             (__attribute__((address_space(3))) void*)(la + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + sc * b_step),
+                                             (__attribute__((address_space(3))) void*)(lb + i * 1024), 16, 0, 0);
+        }
+    };
+
+    if (nslices > 0) {
+        issue(0);
+        issue(1);
+        issue(2);
+    }
+    MAEST_WAIT_VMCNT(8);
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one phase
+    chunk16 fa[2][4], fb[2][2];
+    for (int s = 0; s < nslices; ++s) {
+        const char* la = smem + (s & (G2_STAGES - 1)) * 2 * G2_TILE;
+        const char* lb = la + G2_TILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fa[ks][a] = frag_tn256<T>(la, ks, wm * 128 + a * 32, lane);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fb[ks][b] = frag_tn256<T>(lb, ks, wn * 64 + b * 32, lane);
+        }
+        issue(s + 3);
+        __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) mma_chunk<T>(acc[a][b], fa[ks][a], fb[ks][b]);   // D rows = i, cols = j
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (do_colsum) {   // the fragments already hold A[k][i] for (i = lane&31, 8 or 4 k's): sum them on the VALU
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t w = fa[ks][a][e];
+                        if (C::ELT == 2) cs[a] += bf2f((bf16_t)(w & 0xffffu)) + bf2f((bf16_t)(w >> 16));
+                        else cs[a] += u2f(w);
+                    }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    MAEST_WAIT_VMCNT(0);
+
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = j0 + wn * 64 + b * 32 + (lane & 31);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 128 + a * 32 + frag_row(r, lane);
+                unsafeAtomicAdd(p.C + (int64_t)row * p.ldc + col, acc[a][b][r]);
+            }
+    }
+    if (do_colsum) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float tot = cs[a] + __shfl_xor(cs[a], 32, 64);     // merge the two k halves
+            if (lane < 32) unsafeAtomicAdd(p.colsum + i0 + wm * 128 + a * 32 + lane, tot);
+        }
+    }
+}
+
+template <typename T>
+static int launch_tn256(GemmTn256Params& p, int split_k, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn256_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_tn256_kernel<T>, dim3(p.tiles_m * p.tiles_n, split_k), dim3(512), G2_SMEM, stream, p);
+    return check_launch("maest_gemm_tn(256)");
+}
+
+// Called by maest_gemm_tn; returns -1 when the shape does not qualify.  split_k <= 0 = automatic.
+int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C, int64_t ldc, int M,
+                   int N, int K, float* colsum, int split_k, hipStream_t stream) {
+    const int ks = dtype == MAEST_BF16 ? Tn256<bf16_t>::KS : Tn256<float>::KS;
+    if ((M % 256) != 0 || (N % 256) != 0 || (K % ks) != 0 || K < 8 * ks) return -1;
+    if ((int64_t)M * N < (int64_t)12 * 65536) return -1;   // few output tiles: the 128x128 kernel splits K finer
+    GemmTn256Params p;
+    p.A = (const char*)A; p.B = (const char*)B; p.C = C; p.colsum = colsum;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.tiles_m = M / 256;
+    p.tiles_n = N / 256;
+    const int total = K / ks;
+    const int tiles = p.tiles_m * p.tiles_n;
+    if (split_k <= 0) split_k = (256 + tiles - 1) / tiles;   // one workgroup per CU
+    if (split_k > total / 4) split_k = total / 4 > 0 ? total / 4 : 1;
+    p.k_slices_per_split = (total + split_k - 1) / split_k;
+    split_k = (total + p.k_slices_per_split - 1) / p.k_slices_per_split;
+    return dtype == MAEST_BF16 ? launch_tn256<bf16_t>(p, split_k, stream) : launch_tn256<float>(p, split_k, stream);
+}
+
 }  // namespace maest

@@ -150,7 +150,7 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int, out=None, 
     `out` / `bias_out` (pre-zeroed fp32) receive the results if given."""
     dw = (torch.zeros((n_out, k_out), dtype=torch.float32, device=dy.device) if out is None
           else out.view(n_out, k_out))
-    ops.gemm_tn(dy, x, dw, colsum=bias_out, split_k=_split_k(n_out, k_out, dy.shape[0]), M=n_out, N=k_out)
+    ops.gemm_tn(dy, x, dw, colsum=bias_out, split_k=0, M=n_out, N=k_out)   # 0 = kernel-chosen split
     return dw
 
 

@@ -83,7 +83,7 @@ def case_gemm_tn(dev, dtype, K, M, N, seed=3, lda_pad=0):
     ref = a.float().t() @ b.float()
     ref_cs = a.float().sum(0)
     at = 4e-7 * K + (0 if dtype == torch.float32 else 1e-3)
-    for sk in (1, 3):
+    for sk in (1, 3, 0):
         out = torch.zeros((M, N), dtype=torch.float32, device=dev)
         cs = torch.zeros(M, dtype=torch.float32, device=dev)
         a_dev = a_full.to(dev)[:, :M]

@@ -29,6 +29,12 @@ def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_emu_gemm_tn_256_tile_lds_dma_kernel(emu, dtype):
+    """M, N multiples of 256 and K a multiple of the slice route to gemm256.hip:gemm_tn256_kernel."""
+    KC.case_gemm_tn(emu, dtype, 288 if dtype == torch.bfloat16 else 144, 256, 256)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_emu_gemm_tn(emu, dtype):
     KC.case_gemm_tn(emu, dtype, 150, 136, 200)
     KC.case_gemm_tn(emu, dtype, 40, 24, 72, lda_pad=8)
