@@ -105,27 +105,28 @@ int maest_attn_bwd(const void* qkv, const void* out, const void* dout, const flo
 
 /* ---- K16 + K4 operand: mixup + im2col of the 16x16 / stride-10 patches ---------------------------
  * PatchEmbed.forward (models/maest.py:243-256) fused with Module.training_step's mixup
- * (models/module.py:77-83) and with the structured-patchout column selection (models/maest.py:684-687:
- * dropped time columns are never computed -- mathematically identical).
+ * (models/module.py:77-83) and with EVERY patchout variant of models/maest.py:678-780 (structured time /
+ * frequency, fixed index lists, interleaved, unstructured): the host resolves them into one list of kept
+ * patch tokens and dropped patches are never computed -- mathematically identical to compute-then-drop.
  * x: fp32 [B, F, T]; perm: int32 [B] or NULL; lam: fp32 [B] or NULL (x' = lam*x + (1-lam)*x[perm]).
- * t_idx: int32 [Tk] kept patch columns (sorted) or NULL (= all T' columns).
- * out: dtype [B*Fp*Tk, 256], row = b*Fp*Tk + f*Tk + tk, col = ky*16 + kx. */
+ * tok_ft: int32 [P, 2] = (frequency patch index f, time patch index t) of each kept token, in sequence
+ * order.  out: dtype [B*P, 256], row = b*P + j, col = ky*16 + kx, patch origin (10 f, 10 t). */
 int maest_patch_im2col(const float* x, int B, int F, int T, const int32_t* perm, const float* lam,
-                       const int32_t* t_idx, int Fp, int Tk, void* out, int dtype, void* stream);
+                       const int32_t* tok_ft, int P, void* out, int dtype, void* stream);
 
 /* ---- K5 + K6: positional add + token assembly (models/maest.py:645-675, 769, 785-796) ------------
- * patches: fp32 [B*Fp*Tk, 768] (conv output incl. bias); x0: fp32 [B, 2 + Fp*Tk, 768]
+ * patches: fp32 [B*P, 768] (conv output incl. bias); x0: fp32 [B, 2 + P, 768]
  *   x0[b,0] = cls + new_pos[0]; x0[b,1] = dist + new_pos[1];
- *   x0[b, 2 + f*Tk + tk] = patches[...] + time_pos[:, toffset + t_idx[tk]] + freq_pos[:, f]
- * time_pos: fp32 [768, Tt]; freq_pos: fp32 [768, Fp]. */
+ *   x0[b, 2 + j] = (patches[b*P + j] + time_pos[:, toffset + t_j]) + freq_pos[:, f_j]
+ * time_pos: fp32 [768, Tt]; freq_pos: fp32 [768, Fg]. */
 int maest_token_assemble(const float* patches, const float* cls_token, const float* dist_token,
-                         const float* new_pos, const float* freq_pos, const float* time_pos,
-                         int Tt, int toffset, const int32_t* t_idx, int B, int Fp, int Tk, float* x0,
+                         const float* new_pos, const float* freq_pos, const float* time_pos, int Fg,
+                         int Tt, int toffset, const int32_t* tok_ft, int B, int P, float* x0,
                          void* stream);
-/* Backward of the above: dx0 fp32 [B, N, 768] -> dpatches (dtype, [B*Fp*Tk, 768]) and ACCUMULATED
- * fp32 grads d_cls[768], d_dist[768], d_new_pos[2,768], d_freq_pos[768,Fp], d_time_pos[768,Tt]. */
-int maest_token_assemble_bwd(const float* dx0, int B, int Fp, int Tk, int Tt, int toffset,
-                             const int32_t* t_idx, void* dpatches, int dtype, float* d_cls,
+/* Backward of the above: dx0 fp32 [B, 2+P, 768] -> dpatches (dtype, [B*P, 768]) and ACCUMULATED
+ * fp32 grads d_cls[768], d_dist[768], d_new_pos[2,768], d_freq_pos[768,Fg], d_time_pos[768,Tt]. */
+int maest_token_assemble_bwd(const float* dx0, int B, int P, int Fg, int Tt, int toffset,
+                             const int32_t* tok_ft, void* dpatches, int dtype, float* d_cls,
                              float* d_dist, float* d_new_pos, float* d_freq_pos, float* d_time_pos,
                              void* stream);
 

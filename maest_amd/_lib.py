@@ -30,8 +30,8 @@ SIGNATURES = {
     "maest_layernorm_bwd": [_P, _L, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
     "maest_attn_fwd": [_P, _P, _P, _I, _I, _I, _F, _P],
     "maest_attn_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
-    "maest_patch_im2col": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _P],
-    "maest_token_assemble": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P],
+    "maest_patch_im2col": [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P],
+    "maest_token_assemble": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P, _P],
     "maest_token_assemble_bwd": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "maest_head_pool_fwd": [_P, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P],
     "maest_head_pool_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P],

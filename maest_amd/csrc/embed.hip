@@ -20,17 +20,17 @@ constexpr int PE_S = 10;   // stride
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ x, int B, int F, int T,
                                                            const int32_t* __restrict__ perm,
                                                            const float* __restrict__ lam,
-                                                           const int32_t* __restrict__ t_idx, int Fp, int Tk,
+                                                           const int32_t* __restrict__ tok_ft, int P,
                                                            void* __restrict__ out, int dtype) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)B * Fp * Tk * PE_K;
+    const int64_t total = (int64_t)B * P * PE_K;
     if (gid >= total) return;
     const int ky = (int)(gid & 15);
     const int64_t prow = gid >> 4;
-    const int tk = (int)(prow % Tk);
-    const int f = (int)((prow / Tk) % Fp);
-    const int b = (int)(prow / ((int64_t)Tk * Fp));
-    const int tcol = (t_idx != nullptr ? t_idx[tk] : tk) * PE_S;
+    const int j = (int)(prow % P);
+    const int b = (int)(prow / P);
+    const int f = tok_ft[2 * j];
+    const int tcol = tok_ft[2 * j + 1] * PE_S;
     const float* src = x + ((int64_t)b * F + f * PE_S + ky) * T + tcol;
     float v[16];
 #pragma unroll
@@ -66,16 +66,15 @@ __global__ __launch_bounds__(256) void token_assemble_kernel(const float* __rest
                                                              const float* __restrict__ new_pos,
                                                              const float* __restrict__ freq_pos,
                                                              const float* __restrict__ time_pos, int Tt, int toffset,
-                                                             const int32_t* __restrict__ t_idx, int B, int Fp, int Tk,
+                                                             const int32_t* __restrict__ tok_ft, int B, int Fg, int P,
                                                              float* __restrict__ x0) {
-    const int Ntok = 2 + Fp * Tk;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)B * Ntok * (PE_D / 4);
-    if (gid >= total) return;
-    const int c = (int)(gid % (PE_D / 4)) * 4;
-    const int64_t tok = gid / (PE_D / 4);
-    const int n = (int)(tok % Ntok);
-    const int b = (int)(tok / Ntok);
+    const int Ntok = 2 + P;
+    const int gid = blockIdx.x * 256 + threadIdx.x;      // grid: (tokens x channel quads, batch)
+    if (gid >= Ntok * (PE_D / 4)) return;
+    const int n = gid / (PE_D / 4);
+    const int c = (gid - n * (PE_D / 4)) * 4;
+    const int b = blockIdx.y;
+    const int64_t tok = (int64_t)b * Ntok + n;
     float o[4];
     if (n == 0) {
 #pragma unroll
@@ -85,28 +84,28 @@ __global__ __launch_bounds__(256) void token_assemble_kernel(const float* __rest
         for (int e = 0; e < 4; ++e) o[e] = dist_token[c + e] + new_pos[PE_D + c + e];
     } else {
         const int j = n - 2;
-        const int f = j / Tk, tk = j - f * Tk;
-        const int tcol = toffset + (t_idx != nullptr ? t_idx[tk] : tk);
-        const float4 p = *reinterpret_cast<const float4*>(patches + ((int64_t)b * Fp * Tk + j) * PE_D + c);
+        const int f = tok_ft[2 * j];
+        const int tcol = toffset + tok_ft[2 * j + 1];
+        const float4 p = *reinterpret_cast<const float4*>(patches + ((int64_t)b * P + j) * PE_D + c);
         const float pv[4] = {p.x, p.y, p.z, p.w};
         // reference order: (conv + time_pos) + freq_pos   (maest.py:670,675)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            o[e] = (pv[e] + time_pos[(int64_t)(c + e) * Tt + tcol]) + freq_pos[(int64_t)(c + e) * Fp + f];
+            o[e] = (pv[e] + time_pos[(int64_t)(c + e) * Tt + tcol]) + freq_pos[(int64_t)(c + e) * Fg + f];
     }
     *reinterpret_cast<float4*>(x0 + tok * PE_D + c) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // grid (Ntok, 3): thread = channel; loops over the batch (coalesced over channels)
-__global__ __launch_bounds__(256) void token_assemble_bwd_kernel(const float* __restrict__ dx0, int B, int Fp, int Tk,
+__global__ __launch_bounds__(256) void token_assemble_bwd_kernel(const float* __restrict__ dx0, int B, int Fg, int P,
                                                                  int Tt, int toffset,
-                                                                 const int32_t* __restrict__ t_idx,
+                                                                 const int32_t* __restrict__ tok_ft,
                                                                  void* __restrict__ dpatches, int dtype,
                                                                  float* __restrict__ d_cls, float* __restrict__ d_dist,
                                                                  float* __restrict__ d_new_pos,
                                                                  float* __restrict__ d_freq_pos,
                                                                  float* __restrict__ d_time_pos) {
-    const int Ntok = 2 + Fp * Tk;
+    const int Ntok = 2 + P;
     const int n = blockIdx.x;
     const int c = blockIdx.y * 256 + threadIdx.x;
     float s = 0.0f;
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(256) void token_assemble_bwd_kernel(const float* __
         const float g = dx0[((int64_t)b * Ntok + n) * PE_D + c];
         s += g;
         if (n >= 2 && dpatches != nullptr) {
-            const int64_t o = ((int64_t)b * Fp * Tk + (n - 2)) * PE_D + c;
+            const int64_t o = ((int64_t)b * P + (n - 2)) * PE_D + c;
             if (dtype == MAEST_BF16) reinterpret_cast<bf16_t*>(dpatches)[o] = f2bf(g);
             else reinterpret_cast<float*>(dpatches)[o] = g;
         }
@@ -127,9 +126,9 @@ __global__ __launch_bounds__(256) void token_assemble_bwd_kernel(const float* __
         d_new_pos[PE_D + c] += s;
     } else {
         const int j = n - 2;
-        const int f = j / Tk, tk = j - f * Tk;
-        const int tcol = toffset + (t_idx != nullptr ? t_idx[tk] : tk);
-        unsafeAtomicAdd(d_freq_pos + (int64_t)c * Fp + f, s);
+        const int f = tok_ft[2 * j];
+        const int tcol = toffset + tok_ft[2 * j + 1];
+        unsafeAtomicAdd(d_freq_pos + (int64_t)c * Fg + f, s);
         unsafeAtomicAdd(d_time_pos + (int64_t)c * Tt + tcol, s);
     }
 }
@@ -159,42 +158,39 @@ __global__ __launch_bounds__(256) void spec_mask_kernel(float* __restrict__ x, i
 using namespace maest;
 
 extern "C" int maest_patch_im2col(const float* x, int B, int F, int T, const int32_t* perm, const float* lam,
-                                  const int32_t* t_idx, int Fp, int Tk, void* out, int dtype, void* stream) {
-    MAEST_REQUIRE(x && out, "maest_patch_im2col: null pointer");
-    MAEST_REQUIRE(B > 0 && Fp > 0 && Tk > 0, "maest_patch_im2col: bad shape B=%d Fp=%d Tk=%d", B, Fp, Tk);
-    MAEST_REQUIRE((Fp - 1) * PE_S + PE_K <= F, "maest_patch_im2col: Fp=%d does not fit F=%d", Fp, F);
-    MAEST_REQUIRE(T >= PE_K, "maest_patch_im2col: T=%d too short", T);
+                                  const int32_t* tok_ft, int P, void* out, int dtype, void* stream) {
+    MAEST_REQUIRE(x && out && tok_ft, "maest_patch_im2col: null pointer");
+    MAEST_REQUIRE(B > 0 && P > 0, "maest_patch_im2col: bad shape B=%d P=%d", B, P);
+    MAEST_REQUIRE(F >= PE_K && T >= PE_K, "maest_patch_im2col: input %dx%d smaller than a patch", F, T);
     MAEST_REQUIRE((perm == nullptr) == (lam == nullptr), "maest_patch_im2col: perm and lam go together");
-    MAEST_REQUIRE(t_idx != nullptr || (Tk - 1) * PE_S + PE_K <= T, "maest_patch_im2col: Tk=%d does not fit T=%d", Tk, T);
     MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_patch_im2col: bad dtype");
-    const int64_t total = (int64_t)B * Fp * Tk * PE_K;
+    const int64_t total = (int64_t)B * P * PE_K;
     hipLaunchKernelGGL(patch_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       x, B, F, T, perm, lam, t_idx, Fp, Tk, out, dtype);
+                       x, B, F, T, perm, lam, tok_ft, P, out, dtype);
     return check_launch("maest_patch_im2col");
 }
 
 extern "C" int maest_token_assemble(const float* patches, const float* cls_token, const float* dist_token,
-                                    const float* new_pos, const float* freq_pos, const float* time_pos, int Tt,
-                                    int toffset, const int32_t* t_idx, int B, int Fp, int Tk, float* x0,
-                                    void* stream) {
-    MAEST_REQUIRE(patches && cls_token && dist_token && new_pos && freq_pos && time_pos && x0,
+                                    const float* new_pos, const float* freq_pos, const float* time_pos, int Fg, int Tt,
+                                    int toffset, const int32_t* tok_ft, int B, int P, float* x0, void* stream) {
+    MAEST_REQUIRE(patches && cls_token && dist_token && new_pos && freq_pos && time_pos && x0 && tok_ft,
                   "maest_token_assemble: null pointer");
-    MAEST_REQUIRE(B > 0 && Fp > 0 && Tk > 0 && Tt > 0 && toffset >= 0, "maest_token_assemble: bad shape");
-    const int64_t total = (int64_t)B * (2 + Fp * Tk) * (PE_D / 4);
-    hipLaunchKernelGGL(token_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    MAEST_REQUIRE(B > 0 && P > 0 && Fg > 0 && Tt > 0 && toffset >= 0, "maest_token_assemble: bad shape");
+    const int per_clip = (2 + P) * (PE_D / 4);
+    hipLaunchKernelGGL(token_assemble_kernel, dim3((per_clip + 255) / 256, B), dim3(256), 0,
                        (hipStream_t)stream, patches, cls_token, dist_token, new_pos, freq_pos, time_pos, Tt, toffset,
-                       t_idx, B, Fp, Tk, x0);
+                       tok_ft, B, Fg, P, x0);
     return check_launch("maest_token_assemble");
 }
 
-extern "C" int maest_token_assemble_bwd(const float* dx0, int B, int Fp, int Tk, int Tt, int toffset,
-                                        const int32_t* t_idx, void* dpatches, int dtype, float* d_cls, float* d_dist,
+extern "C" int maest_token_assemble_bwd(const float* dx0, int B, int P, int Fg, int Tt, int toffset,
+                                        const int32_t* tok_ft, void* dpatches, int dtype, float* d_cls, float* d_dist,
                                         float* d_new_pos, float* d_freq_pos, float* d_time_pos, void* stream) {
-    MAEST_REQUIRE(dx0 && d_cls && d_dist && d_new_pos && d_freq_pos && d_time_pos,
+    MAEST_REQUIRE(dx0 && d_cls && d_dist && d_new_pos && d_freq_pos && d_time_pos && tok_ft,
                   "maest_token_assemble_bwd: null pointer");
-    MAEST_REQUIRE(B > 0 && Fp > 0 && Tk > 0 && Tt > 0, "maest_token_assemble_bwd: bad shape");
-    hipLaunchKernelGGL(token_assemble_bwd_kernel, dim3(2 + Fp * Tk, PE_D / 256), dim3(256), 0, (hipStream_t)stream,
-                       dx0, B, Fp, Tk, Tt, toffset, t_idx, dpatches, dtype, d_cls, d_dist, d_new_pos, d_freq_pos,
+    MAEST_REQUIRE(B > 0 && P > 0 && Fg > 0 && Tt > 0, "maest_token_assemble_bwd: bad shape");
+    hipLaunchKernelGGL(token_assemble_bwd_kernel, dim3(2 + P, PE_D / 256), dim3(256), 0, (hipStream_t)stream,
+                       dx0, B, Fg, P, Tt, toffset, tok_ft, dpatches, dtype, d_cls, d_dist, d_new_pos, d_freq_pos,
                        d_time_pos);
     return check_launch("maest_token_assemble_bwd");
 }

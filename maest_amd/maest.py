@@ -162,25 +162,23 @@ class _Engine:
         self.w = _Weights()
 
     # ---- forward ----------------------------------------------------------------------------
-    def forward(self, x3: torch.Tensor, dt, *, toffset: int, t_idx: Optional[torch.Tensor], perm, lam,
+    def forward(self, x3: torch.Tensor, dt, *, toffset: int, tok_ft: torch.Tensor, perm, lam,
                 stop_block: int = -1, return_self_attention: bool = False, save: bool = False):
-        """x3: fp32 [B, F, T] on the device.  Returns (outputs, ctx)."""
+        """x3: fp32 [B, F, T] on the device; tok_ft: int32 [P, 2] kept patch tokens.  Returns (outputs, ctx)."""
         m, W = self.m, self.w
         B, F, T = x3.shape
-        Fp = (F - PATCH) // m.patch_embed.stride[0] + 1
-        Tp = (T - PATCH) // m.patch_embed.stride[1] + 1
-        Tk = Tp if t_idx is None else int(t_idx.numel())
-        N = 2 + Fp * Tk
+        P = int(tok_ft.shape[0])
+        N = 2 + P
         M = B * N
-        ctx = {"B": B, "N": N, "Fp": Fp, "Tk": Tk, "toffset": toffset, "t_idx": t_idx, "dt": dt} if save else None
+        ctx = {"B": B, "N": N, "toffset": toffset, "tok_ft": tok_ft, "dt": dt} if save else None
 
-        cols = ops.patch_im2col(x3, Fp, Tk, dt, t_idx=t_idx, perm=perm, lam=lam)
+        cols = ops.patch_im2col(x3, tok_ft, dt, perm=perm, lam=lam)
         patches = ops.gemm_nt(cols, W.get(m.patch_embed.proj.weight, dt), m.patch_embed.proj.bias,
                               out_dtype=torch.float32)
         Tt = m.time_new_pos_embed.shape[-1]
         x = ops.token_assemble(patches, m.cls_token.reshape(-1), m.dist_token.reshape(-1),
                                m.new_pos_embed.reshape(2, EMBED_DIM), m.freq_new_pos_embed.reshape(EMBED_DIM, -1),
-                               m.time_new_pos_embed.reshape(EMBED_DIM, Tt), toffset, t_idx, B, Fp, Tk)
+                               m.time_new_pos_embed.reshape(EMBED_DIM, Tt), toffset, tok_ft, B)
         x = x.reshape(M, EMBED_DIM)
         if save:
             ctx["cols"] = cols
@@ -245,7 +243,8 @@ class _Engine:
         gradient is written straight into the sink's flat bucket view and reported as soon as it is
         complete, so the RCCL all-reduce of a bucket overlaps with the rest of the backward."""
         m, W = self.m, self.w
-        dt, B, N, Fp, Tk = ctx["dt"], ctx["B"], ctx["N"], ctx["Fp"], ctx["Tk"]
+        dt, B, N = ctx["dt"], ctx["B"], ctx["N"]
+        Fp = m.freq_new_pos_embed.shape[2]
         M = B * N
         dev = ctx["x_final"].device
         G = {}
@@ -356,7 +355,7 @@ class _Engine:
         d_cls_t, d_dist_t = buf("cls_token", EMBED_DIM), buf("dist_token", EMBED_DIM)
         d_np = buf("new_pos_embed", 2, EMBED_DIM)
         d_fp, d_tp = buf("freq_new_pos_embed", EMBED_DIM, Fp), buf("time_new_pos_embed", EMBED_DIM, Tt)
-        dpatch = ops.token_assemble_bwd(dx, B, Fp, Tk, Tt, ctx["toffset"], ctx["t_idx"], dt, d_cls_t, d_dist_t, d_np,
+        dpatch = ops.token_assemble_bwd(dx, B, Fp, Tt, ctx["toffset"], ctx["tok_ft"], dt, d_cls_t, d_dist_t, d_np,
                                         d_fp, d_tp)
         done("cls_token", d_cls_t.view(1, 1, EMBED_DIM))
         done("dist_token", d_dist_t.view(1, 1, EMBED_DIM))
@@ -414,15 +413,6 @@ class MAEST(nn.Module):
                                       "embed_dim=768, 12 heads x 64, 16x16 patches, mono input")
         if not distilled:
             raise NotImplementedError("every MAEST architecture is DeiT-distilled (cls + dist tokens)")
-        for name, v in (("u_patchout", u_patchout), ("s_patchout_f", s_patchout_f),
-                        ("s_patchout_f_indices", s_patchout_f_indices),
-                        ("s_patchout_f_interleaved", s_patchout_f_interleaved),
-                        ("s_patchout_t_indices", s_patchout_t_indices),
-                        ("s_patchout_t_interleaved", s_patchout_t_interleaved)):
-            if v:
-                raise NotImplementedError(
-                    f"{name}: only structured TIME patchout (s_patchout_t) is implemented in maest_amd; "
-                    "none of the reference's named configs uses the other variants")
         self.num_classes = num_classes
         self.u_patchout = u_patchout
         self.img_size = tuple(img_size)
@@ -537,14 +527,45 @@ class MAEST(nn.Module):
         if not chunked:
             self._check_patches_fit(1 + S // MelSpectrogram.hop_len)
 
-    def _draw_train_indices(self, Tp):
-        """The reference's RNG draws, same generators, same order (maest.py:648-650, 684-686)."""
+    def _resolve_tokens(self, Fp, Tp, pinned=None):
+        """Every patchout variant of the reference (maest.py:645-657, 678-780) resolved on the host into
+        (toffset, kept patch tokens [P, 2] = (f, t) in sequence order).  RNG: the reference's generator
+        calls in the reference's order -- randint (time-table offset), randperm(T') (s_patchout_t),
+        randperm(F') (s_patchout_f), ..., randperm(seq) (u_patchout) -- so a shared torch.manual_seed
+        reproduces the reference's draws.  `pinned = (toffset, t_keep)` overrides the two training draws."""
         table = self.time_new_pos_embed.shape[-1]
-        toffset = torch.randint(1 + table - Tp, (1,)).item()
-        t_idx = None
-        if self.s_patchout_t:
-            t_idx = torch.randperm(Tp)[: Tp - self.s_patchout_t].sort().values
-        return toffset, t_idx
+        f_list = torch.arange(Fp)
+        t_list = torch.arange(Tp)
+        toffset = 0
+        if pinned is not None:
+            toffset, t_keep = pinned
+            if t_keep is not None:
+                t_list = torch.as_tensor(t_keep, dtype=torch.long).cpu()
+        elif self.training:
+            toffset = torch.randint(1 + table - Tp, (1,)).item()
+            if self.s_patchout_t:
+                t_list = t_list[torch.randperm(Tp)[: Tp - self.s_patchout_t].sort().values]
+        if self.training and self.s_patchout_f:
+            f_list = f_list[torch.randperm(Fp)[: Fp - self.s_patchout_f].sort().values]
+        if self.s_patchout_f_indices:
+            pos = torch.arange(len(f_list))
+            for i in self.s_patchout_f_indices:
+                pos = pos[pos != int(i)]
+            f_list = f_list[pos]
+        if self.s_patchout_f_interleaved:
+            f_list = f_list[torch.arange(0, len(f_list), self.s_patchout_f_interleaved)]
+        if self.s_patchout_t_indices:
+            pos = torch.arange(len(t_list))
+            for i in self.s_patchout_t_indices:
+                pos = pos[pos != int(i)]
+            t_list = t_list[pos]
+        if self.s_patchout_t_interleaved:
+            t_list = t_list[torch.arange(0, len(t_list), self.s_patchout_t_interleaved)]
+        tok = torch.stack(torch.meshgrid(f_list, t_list, indexing="ij"), dim=-1).reshape(-1, 2)   # f-major (maest.py:769)
+        if self.training and self.u_patchout:
+            seq_len = tok.shape[0]
+            tok = tok[torch.randperm(seq_len)[: seq_len - self.u_patchout].sort().values]
+        return int(toffset), tok.to(torch.int32).contiguous()
 
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, x, transformer_block: int = -1, return_self_attention: bool = False,
@@ -552,7 +573,7 @@ class MAEST(nn.Module):
                 ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
         """Same contract as the reference's ``MAEST.forward`` (maest.py:831-933).
 
-        ``_mixup=(perm, lam)`` and ``_patchout=(toffset, t_idx)`` are private hooks used by
+        ``_mixup=(perm, lam)`` and ``_patchout=(toffset, kept_time_columns)`` are private hooks used by
         ``maest_amd.module.Module.training_step`` (fused mixup) and by the parity tests (pinned draws)."""
         x = self._prepare_input(x, melspectrogram_input)
         if x.dim() != 4 or x.shape[1] != 1:
@@ -569,19 +590,20 @@ class MAEST(nn.Module):
         x3 = x3.contiguous()
         dt = self._compute_dtype()
 
-        toffset, t_idx = 0, None
-        if _patchout is not None:
-            toffset, t_idx = _patchout
-        elif self.training:
-            toffset, t_idx = self._draw_train_indices(Tp)
-        if t_idx is not None:
-            t_idx = torch.as_tensor(t_idx).to(device=x3.device, dtype=torch.int32).contiguous()
+        Fp = (F - PATCH) // self.patch_embed.stride[0] + 1
+        if Fp > self.freq_new_pos_embed.shape[2]:
+            raise Exception(f"{Fp} frequency patches exceed the frequency positional table "
+                            f"{tuple(self.freq_new_pos_embed.shape)}")
+        toffset, tok_ft = self._resolve_tokens(Fp, Tp, _patchout)
+        if tok_ft.shape[0] < 1:
+            raise Exception("patchout removed every patch token")
+        tok_ft = tok_ft.to(x3.device)
         perm = lam = None
         if _mixup is not None:
             perm, lam = _mixup
             perm = perm.to(device=x3.device, dtype=torch.int32).contiguous()
             lam = lam.to(device=x3.device, dtype=torch.float32).contiguous()
-        kw = dict(toffset=int(toffset), t_idx=t_idx, perm=perm, lam=lam)
+        kw = dict(toffset=int(toffset), tok_ft=tok_ft, perm=perm, lam=lam)
 
         if transformer_block != -1:
             with torch.no_grad():

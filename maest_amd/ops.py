@@ -201,30 +201,32 @@ def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float):
     return dqkv
 
 
-def patch_im2col(x: torch.Tensor, Fp: int, Tk: int, dtype, t_idx=None, perm=None, lam=None):
-    """x fp32 [B, F, T] -> im2col operand [B*Fp*Tk, 256] (mixup and patchout fused)."""
-    _chk(x, t_idx, perm, lam)
-    assert x.dtype == torch.float32 and x.dim() == 3
+def patch_im2col(x: torch.Tensor, tok_ft: torch.Tensor, dtype, perm=None, lam=None):
+    """x fp32 [B, F, T], tok_ft int32 [P, 2] -> im2col operand [B*P, 256] (mixup and patchout fused)."""
+    _chk(x, tok_ft, perm, lam)
+    assert x.dtype == torch.float32 and x.dim() == 3 and tok_ft.dtype == torch.int32
     B, F, T = x.shape
-    out = torch.empty((B * Fp * Tk, 256), dtype=dtype, device=x.device)
-    call("maest_patch_im2col", _p(x), B, F, T, _p(perm), _p(lam), _p(t_idx), Fp, Tk, _p(out), DT[dtype], _s(x))
+    P = tok_ft.shape[0]
+    out = torch.empty((B * P, 256), dtype=dtype, device=x.device)
+    call("maest_patch_im2col", _p(x), B, F, T, _p(perm), _p(lam), _p(tok_ft), P, _p(out), DT[dtype], _s(x))
     return out
 
 
-def token_assemble(patches, cls_token, dist_token, new_pos, freq_pos, time_pos, toffset, t_idx, B, Fp, Tk):
-    _chk(patches, cls_token, dist_token, new_pos, freq_pos, time_pos, t_idx)
-    Tt = time_pos.shape[-1]
-    x0 = torch.empty((B, 2 + Fp * Tk, EMBED), dtype=torch.float32, device=patches.device)
+def token_assemble(patches, cls_token, dist_token, new_pos, freq_pos, time_pos, toffset, tok_ft, B):
+    _chk(patches, cls_token, dist_token, new_pos, freq_pos, time_pos, tok_ft)
+    Tt, Fg, P = time_pos.shape[-1], freq_pos.shape[-1], tok_ft.shape[0]
+    x0 = torch.empty((B, 2 + P, EMBED), dtype=torch.float32, device=patches.device)
     call("maest_token_assemble", _p(patches), _p(cls_token), _p(dist_token), _p(new_pos), _p(freq_pos),
-         _p(time_pos), Tt, toffset, _p(t_idx), B, Fp, Tk, _p(x0), _s(patches))
+         _p(time_pos), Fg, Tt, toffset, _p(tok_ft), B, P, _p(x0), _s(patches))
     return x0
 
 
-def token_assemble_bwd(dx0, B, Fp, Tk, Tt, toffset, t_idx, dtype, d_cls, d_dist, d_new_pos, d_freq_pos,
-                       d_time_pos, want_dpatches=True):
-    _chk(dx0, t_idx, d_cls, d_dist, d_new_pos, d_freq_pos, d_time_pos)
-    dp = torch.empty((B * Fp * Tk, EMBED), dtype=dtype, device=dx0.device) if want_dpatches else None
-    call("maest_token_assemble_bwd", _p(dx0), B, Fp, Tk, Tt, toffset, _p(t_idx), _p(dp), DT[dtype], _p(d_cls),
+def token_assemble_bwd(dx0, B, Fg, Tt, toffset, tok_ft, dtype, d_cls, d_dist, d_new_pos, d_freq_pos, d_time_pos,
+                       want_dpatches=True):
+    _chk(dx0, tok_ft, d_cls, d_dist, d_new_pos, d_freq_pos, d_time_pos)
+    P = tok_ft.shape[0]
+    dp = torch.empty((B * P, EMBED), dtype=dtype, device=dx0.device) if want_dpatches else None
+    call("maest_token_assemble_bwd", _p(dx0), B, P, Fg, Tt, toffset, _p(tok_ft), _p(dp), DT[dtype], _p(d_cls),
          _p(d_dist), _p(d_new_pos), _p(d_freq_pos), _p(d_time_pos), _s(dx0))
     return dp
 

@@ -169,6 +169,30 @@ def main():
         g4[f"t_keep_{T}"] = keep.numpy()
     np.savez(os.path.join(OUT, "g4_train_fwd_patchout.npz"), **g4)
 
+    # ---------------- G4b: the other patchout variants (maest.py:690-780), train mode, seeded draws -------
+    print("G4b")
+    g4b = {}
+    variants = {
+        "tf_u": dict(s_patchout_t=20, s_patchout_f=2, u_patchout=25),
+        "interleaved": dict(s_patchout_t_interleaved=2, s_patchout_f_interleaved=2),
+        "indices": dict(s_patchout_t_indices=(0, 5, 60), s_patchout_f_indices=(1, 8)),
+    }
+    for name, kw in variants.items():
+        mv, sdv = build(rm, "discogs-maest-10s-pw-129e", 625, **kw)
+        mv.train()
+        xv = randn((2, 1, 96, 625), 77)
+        torch.manual_seed(4242)
+        with torch.no_grad():
+            lv, fv = mv(xv.clone())
+        g4b[f"logits_{name}"] = lv.numpy()
+        g4b[f"features_{name}"] = fv.numpy()
+        # eval mode too (the fixed-index / interleaved variants apply in eval as well)
+        mv.eval()
+        with torch.no_grad():
+            le, _ = mv(xv.clone())
+        g4b[f"logits_eval_{name}"] = le.numpy()
+    np.savez(os.path.join(OUT, "g4b_patchout_variants.npz"), **g4b)
+
     # ---------------- G5: training step (loss + gradients) ---------------------------------
     print("G5")
     B, T, C = 4, 625, 400

@@ -229,7 +229,8 @@ def patch_embed(x: torch.Tensor, sd) -> torch.Tensor:
 
 def tokens_from_patches(p: torch.Tensor, sd, toffset: int = 0,
                         t_keep: Optional[Sequence[int]] = None,
-                        f_keep: Optional[Sequence[int]] = None) -> torch.Tensor:
+                        f_keep: Optional[Sequence[int]] = None,
+                        u_keep: Optional[Sequence[int]] = None) -> torch.Tensor:
     """Positional add + structured patchout + flatten + cls/dist concat
     (maest.py:645-675, 678-701, 769, 785-796).  ``toffset`` / ``t_keep`` / ``f_keep`` are the
     values the reference draws from ``torch.randint`` / ``torch.randperm`` in training mode
@@ -247,6 +248,8 @@ def tokens_from_patches(p: torch.Tensor, sd, toffset: int = 0,
     if f_keep is not None:
         p = p[:, :, torch.as_tensor(list(f_keep), dtype=torch.long), :]
     x = p.flatten(2).transpose(1, 2)
+    if u_keep is not None:      # unstructured patchout: sorted random subset of the sequence (maest.py:773-780)
+        x = x[:, torch.as_tensor(list(u_keep), dtype=torch.long), :]
     cls = sd["cls_token"].expand(B, -1, -1) + sd["new_pos_embed"][:, :1, :]
     dist = sd["dist_token"].expand(B, -1, -1) + sd["new_pos_embed"][:, 1:, :]
     return torch.cat((cls, dist, x), dim=1)
@@ -285,9 +288,9 @@ def block(x: torch.Tensor, sd, i: int, return_self_attention: bool = False) -> t
 
 def forward_features(x4: torch.Tensor, sd, transformer_block: int = -1,
                      return_self_attention: bool = False, toffset: int = 0,
-                     t_keep=None, f_keep=None, probes: Optional[list] = None):
+                     t_keep=None, f_keep=None, probes: Optional[list] = None, u_keep=None):
     """``MAEST.forward_features`` (maest.py:634-829)."""
-    x = tokens_from_patches(patch_embed(x4, sd), sd, toffset, t_keep, f_keep)
+    x = tokens_from_patches(patch_embed(x4, sd), sd, toffset, t_keep, f_keep, u_keep)
     if transformer_block == -1:
         for i in range(DEPTH):
             x = block(x, sd, i)
@@ -306,11 +309,11 @@ def forward_features(x4: torch.Tensor, sd, transformer_block: int = -1,
 def forward(x: torch.Tensor, sd, img_size: Tuple[int, int], transformer_block: int = -1,
             return_self_attention: bool = False, melspectrogram_input: bool = False,
             distilled_type: str = "mean", toffset: int = 0, t_keep=None, f_keep=None,
-            probes: Optional[list] = None):
+            probes: Optional[list] = None, u_keep=None):
     """``MAEST.forward`` (maest.py:831-933)."""
     x4 = prepare_input(x, img_size, melspectrogram_input)
     out = forward_features(x4, sd, transformer_block, return_self_attention,
-                           toffset, t_keep, f_keep, probes)
+                           toffset, t_keep, f_keep, probes, u_keep)
     if transformer_block != -1:
         return None, out
     cls, dist = out

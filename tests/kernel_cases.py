@@ -182,14 +182,16 @@ def case_patch_embed(dev, dtype, B, T, patchout=0, mix=False, seed=30):
     rng = np.random.Generator(np.random.PCG64(seed + 1))
     keep = np.sort(rng.permutation(Tp)[: Tp - patchout]).astype(np.int32) if patchout else None
     Tk = Tp - patchout
-    t_idx = torch.from_numpy(keep).to(dev) if keep is not None else None
+    t_list = torch.arange(Tp) if keep is None else torch.from_numpy(keep).long()
+    tok = torch.stack(torch.meshgrid(torch.arange(Fp), t_list, indexing="ij"), -1).reshape(-1, 2).to(torch.int32)
+    tok_dev = tok.contiguous().to(dev)
     perm = lam = None
     xm = x
     if mix:
         perm = torch.from_numpy(rng.permutation(B).astype(np.int32))
         lam = torch.from_numpy(rng.random(B).astype(np.float32))
         xm = O.mixup(x, perm.long(), lam)
-    cols = ops.patch_im2col(x.to(dev), Fp, Tk, dtype, t_idx=t_idx,
+    cols = ops.patch_im2col(x.to(dev), tok_dev, dtype,
                             perm=None if perm is None else perm.to(dev), lam=None if lam is None else lam.to(dev))
     ref = F.unfold(xm.unsqueeze(1), kernel_size=16, stride=10)          # [B, 256, Fp*Tp]
     ref = ref.reshape(B, 256, Fp, Tp)
@@ -210,7 +212,7 @@ def case_patch_embed(dev, dtype, B, T, patchout=0, mix=False, seed=30):
     x0 = ops.token_assemble(patches.to(dev), sd["cls_token"].reshape(768).to(dev), sd["dist_token"].reshape(768).to(dev),
                             sd["new_pos_embed"].reshape(2, 768).contiguous().to(dev),
                             sd["freq_new_pos_embed"].reshape(768, Fp).contiguous().to(dev),
-                            sd["time_new_pos_embed"].reshape(768, Tt).contiguous().to(dev), toff, t_idx, B, Fp, Tk)
+                            sd["time_new_pos_embed"].reshape(768, Tt).contiguous().to(dev), toff, tok_dev, B)
     close(x0, want, 0, 1e-6, "token assemble")
     # backward of token assembly
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
@@ -219,7 +221,7 @@ def case_patch_embed(dev, dtype, B, T, patchout=0, mix=False, seed=30):
     O.tokens_from_patches(convg, sdg, toffset=toff, t_keep=None if keep is None else keep.tolist()).backward(dx0)
     z = lambda *s: torch.zeros(*s, device=dev)
     d_cls, d_dist, d_np, d_fp, d_tp = z(768), z(768), z(2, 768), z(768, Fp), z(768, Tt)
-    dp = ops.token_assemble_bwd(dx0.to(dev), B, Fp, Tk, Tt, toff, t_idx, dtype, d_cls, d_dist, d_np, d_fp, d_tp)
+    dp = ops.token_assemble_bwd(dx0.to(dev), B, Fp, Tt, toff, tok_dev, dtype, d_cls, d_dist, d_np, d_fp, d_tp)
     gk = convg.grad if keep is None else convg.grad[:, :, :, torch.from_numpy(keep).long()]
     close(dp, gk.permute(0, 2, 3, 1).reshape(B * Fp * Tk, 768), *((0, 1e-6) if dtype == torch.float32 else (1e-2, 1e-2)), "dpatches")
     close(d_cls, sdg["cls_token"].grad.reshape(768), 1e-5, 1e-5, "d cls")

@@ -76,9 +76,21 @@ def test_unknown_arch_and_pretrained():
         get_maest("discogs-maest-10s-pw-129e")          # pretrained defaults to True like the reference
 
 
-def test_unimplemented_patchout_variants_are_explicit():
-    with pytest.raises(NotImplementedError, match="s_patchout_t"):
-        get_maest("discogs-maest-10s-pw-129e", pretrained=False, u_patchout=10)
+def test_patchout_variants_resolve_to_token_lists():
+    """Every patchout variant of maest.py:678-780 is resolved on the host into the kept-token list."""
+    m = get_maest("discogs-maest-10s-pw-129e", pretrained=False, s_patchout_t=20, s_patchout_f=2, u_patchout=25)
+    torch.manual_seed(1)
+    toff, tok = m._resolve_tokens(9, 61)
+    assert tok.shape == ((9 - 2) * (61 - 20) - 25, 2) and tok.dtype == torch.int32
+    flat = tok[:, 0].long() * 100 + tok[:, 1].long()
+    assert bool((flat[1:] > flat[:-1]).all()), "tokens stay in f-major sequence order"
+    m.eval()
+    _, tok = m._resolve_tokens(9, 61)
+    assert tok.shape == (9 * 61, 2)
+    m2 = get_maest("discogs-maest-10s-pw-129e", pretrained=False, s_patchout_t_interleaved=2,
+                   s_patchout_f_indices=(1, 8)).eval()
+    _, tok = m2._resolve_tokens(9, 61)
+    assert sorted(set(tok[:, 0].tolist())) == [0, 2, 3, 4, 5, 6, 7] and sorted(set(tok[:, 1].tolist())) == list(range(0, 61, 2))
 
 
 def test_state_dict_matches_reference_layout():
@@ -153,8 +165,8 @@ def test_train_rng_draws_match_reference_order(model):
     """toffset is drawn before the kept-column permutation, from torch's global CPU generator."""
     m = get_maest("discogs-maest-10s-pw-129e", pretrained=False, s_patchout_t=30)
     torch.manual_seed(42)
-    toff, keep = m._draw_train_indices(61)
+    toff, tok = m._resolve_tokens(9, 61)
     torch.manual_seed(42)
     want_off = torch.randint(1 + 62 - 61, (1,)).item()
     want_keep = torch.randperm(61)[:31].sort().values
-    assert toff == want_off and torch.equal(keep, want_keep)
+    assert toff == want_off and torch.equal(tok[:31, 1].long(), want_keep) and int(tok[:31, 0].max()) == 0

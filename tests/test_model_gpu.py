@@ -121,6 +121,26 @@ def test_g4_train_forward_patchout_same_rng_draws(T):
     assert rel_err(l2, g[f"logits_{T}"]) < 1e-3
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("tf_u", dict(s_patchout_t=20, s_patchout_f=2, u_patchout=25)),
+    ("interleaved", dict(s_patchout_t_interleaved=2, s_patchout_f_interleaved=2)),
+    ("indices", dict(s_patchout_t_indices=(0, 5, 60), s_patchout_f_indices=(1, 8)))])
+def test_g4b_all_patchout_variants_match_reference(name, kw):
+    """Structured frequency / unstructured / interleaved / fixed-index patchout (maest.py:690-780): same
+    seed -> same draws -> same logits as the reference fixture, in train and in eval mode."""
+    g = np.load(os.path.join(GOLD, "g4b_patchout_variants.npz"))
+    m = build("discogs-maest-10s-pw-129e", 625, **kw).train()
+    x = randn((2, 1, 96, 625), 77).to(DEV)
+    torch.manual_seed(4242)
+    with torch.no_grad():
+        logits, feats = m(x)
+    assert rel_err(logits, g[f"logits_{name}"]) < 1e-3 and rel_err(feats, g[f"features_{name}"]) < 1e-3
+    m.eval()
+    with torch.no_grad():
+        le, _ = m(x)
+    assert rel_err(le, g[f"logits_eval_{name}"]) < 1e-3
+
+
 def _g5_batch(g):
     B, T = 4, 625
     x = randn((B, 1, 96, T), 21).to(DEV)
