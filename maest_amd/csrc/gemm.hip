@@ -134,7 +134,7 @@ __device__ __forceinline__ void epi_drain(const char* smem, void* dst, int64_t l
                 }
             }
         }
-        *reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ));
     }
 }
 

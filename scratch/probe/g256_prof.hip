@@ -18,7 +18,9 @@
 //   * epilogue as in gemm.hip: weight tile is the MFMA A operand, so lanes hold 4 consecutive output
 //     columns; the C tile is staged through (the now idle) LDS in the output dtype in row groups and
 //     written with 16-byte coalesced stores with bias / GELU / residual / GELU' fused.
-#include "common.h"
+#include "../../maest_amd/csrc/common.h"
+__device__ long long* g_prof = nullptr;
+#define STAMP(i) if (tid == 0 && blockIdx.x < 256) g_prof_local[i] = clock64();
 
 namespace maest {
 
@@ -159,8 +161,7 @@ __device__ __forceinline__ void drain256(const char* smem, void* dst, int64_t ld
                 }
             }
         }
-        // streaming output: written once, re-read by a later kernel after > L2-size of other traffic
-        __builtin_nontemporal_store(v, reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ));
+        *reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ) = v;
     }
 }
 
@@ -221,11 +222,18 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(Gemm256Params p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;          // 0..7
+    long long g_prof_local[6] = {0,0,0,0,0,0};
+    STAMP(0)
     const int wm = wave >> 2, wn = wave & 3;
     const int h = lane >> 5;
 
+    // persistent workgroups (one per CU): block b (XCD b % 8, observed) walks tiles
+    //   round * gridDim + (b % 8) * (gridDim / 8) + b / 8
+    // so that the workgroups of one XCD work on neighbouring tiles (same A panel) at the same time.
     const int nwg = p.tiles_m * p.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int per_xcd = gridDim.x >> 3;
+    const int wg0 = gridDim.x >= 8 ? (int)((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    for (int wg = wg0; wg < nwg; wg += gridDim.x) {
     const int tile_m = wg / p.tiles_n;
     const int tile_n = wg - tile_m * p.tiles_n;
     const int m0 = tile_m * 256, n0 = tile_n * 256;
@@ -293,11 +301,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(Gemm256Params p) {
     // Slice s is resident before anybody reads it: every wave ends LOAD(s-1) with vmcnt(8) (slices s+1, s+2
     // may still fly) and the barrier(s) in between publish that to the other group.  DMA of slice s+3
     // overwrites buffer (s-1)&3, whose last reader (B's LOAD(s-1)) finished before barrier 2s.
+    STAMP(1)
     issue(0);
     issue(1);
     issue(2);
     MAEST_WAIT_VMCNT(8);
     __builtin_amdgcn_s_barrier();
+    STAMP(2)
     if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger (wave-uniform)
     chunk16 fa[2][4], fb[2][2];
     for (int s = 0; s < nslices; ++s) {
@@ -329,8 +339,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(Gemm256Params p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();          // un-stagger
     MAEST_WAIT_VMCNT(0);   // drain the past-the-end loads before LDS is reused
     __syncthreads();   // every wave is done with the operand buffers: LDS becomes the C staging area
+    STAMP(3)
     if (p.out_dtype == MAEST_BF16) epilogue256<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
     else epilogue256<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+    STAMP(4)
+    if (tid == 0 && blockIdx.x < 256 && wg == wg0) { for (int i = 0; i < 5; ++i) g_prof[blockIdx.x * 8 + i] = g_prof_local[i]; }
+    }   // tile loop (epilogue256 ends with a barrier: LDS is free for the next tile's DMA)
 }
 
 template <typename T>
@@ -341,7 +355,10 @@ static int launch256(Gemm256Params& p, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm_nt256_kernel<T>, dim3(p.tiles_m * p.tiles_n), dim3(512), G2_SMEM, stream, p);
+    int grid = p.tiles_m * p.tiles_n;
+    if (grid > 256) grid = 256;          // persistent: one workgroup per CU
+    if (grid >= 8) grid &= ~7;           // keep the per-XCD tile walk regular
+    hipLaunchKernelGGL(gemm_nt256_kernel<T>, dim3(grid), dim3(512), G2_SMEM, stream, p);
     return check_launch("maest_gemm_nt(256)");
 }
 
@@ -584,3 +601,26 @@ int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int d
 }
 
 }  // namespace maest
+namespace maest { void set_error(const char*, ...) {} int check_launch(const char*) { return hipGetLastError() != hipSuccess; } }
+#include <stdio.h>
+#include <vector>
+int main() {
+    const int M = 74240, N = 3072;
+    for (int K : {64, 768}) {
+        void *A, *B, *C; long long* prof;
+        hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2);
+        hipMalloc(&prof, 256 * 8 * 8);
+        hipMemset(A, 0, (size_t)M * K * 2); hipMemset(B, 0, (size_t)N * K * 2);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_prof), &prof, sizeof(prof));
+        for (int it = 0; it < 3; ++it)
+            maest::gemm_nt256_try(A, K, B, K, MAEST_BF16, C, N, MAEST_BF16, M, N, K, nullptr, MAEST_EPI_NONE, nullptr, nullptr, 0, 0);
+        hipDeviceSynchronize();
+        std::vector<long long> h(256 * 8);
+        hipMemcpy(h.data(), prof, 256 * 8 * 8, hipMemcpyDeviceToHost);
+        double s[4] = {0, 0, 0, 0};
+        for (int b = 0; b < 256; ++b) for (int i = 0; i < 4; ++i) s[i] += (double)(h[b * 8 + i + 1] - h[b * 8 + i]);
+        printf("K=%d  avg cycles (first tile of each WG): setup %.0f  prologue(fill+wait) %.0f  main loop %.0f  epilogue %.0f\n", K, s[0] / 256, s[1] / 256, s[2] / 256, s[3] / 256);
+    }
+    return 0;
+}
+

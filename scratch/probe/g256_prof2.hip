@@ -18,7 +18,9 @@
 //   * epilogue as in gemm.hip: weight tile is the MFMA A operand, so lanes hold 4 consecutive output
 //     columns; the C tile is staged through (the now idle) LDS in the output dtype in row groups and
 //     written with 16-byte coalesced stores with bias / GELU / residual / GELU' fused.
-#include "common.h"
+#include "../../maest_amd/csrc/common.h"
+__device__ long long* g_prof = nullptr;
+__device__ __forceinline__ void stamp(long long* a, int i, int tid) { if (tid == 0 || tid == 256) a[i] = clock64(); }
 
 namespace maest {
 
@@ -42,18 +44,26 @@ struct Gemm256Params {
     int tiles_m, tiles_n;
 };
 
+constexpr int G2_RING = G2_STAGES * 2 * G2_TILE;      // 131072: operand ring
+constexpr int G2_STAGE = 32768;                       // C staging area BEHIND the ring (never touched by the DMA)
+constexpr int G2_SMEM_NT = G2_RING + G2_STAGE;        // 163840 = all of a CU's LDS
+
+// C staging geometry: a pass moves 64 (bf16) / 32 (fp32) output rows of 256 columns = 32 KiB through LDS.
+// Rows are unpadded (the area is exactly 32 KiB); the 16-byte chunk index is XORed with (row & 31) so that
+// the 32 rows written by a half-wave (same columns) land on 32 different bank slots.
 template <int OSZ>
 struct Epi256 {
-    static constexpr int PITCH = 256 * OSZ + 16;              // 528 / 1040
-    static constexpr int ROWS = OSZ == 2 ? 128 : 64;          // m rows staged per pass
-    static constexpr int MT = ROWS / 32;                      // wave m-tiles per pass: 4 / 2
-    static constexpr int PASSES = 256 / ROWS;                 // 2 / 4
-    static constexpr int CPR = 256 * OSZ / 16;                // chunks per row: 32 / 64
-    static constexpr int EPC = 16 / OSZ;
+    static constexpr int ROWB = 256 * OSZ;                    // 512 / 1024
+    static constexpr int CPR = ROWB / 16;                     // 32 / 64 chunks per row
+    static constexpr int EPC = 16 / OSZ;                      // elements per chunk
+    static constexpr int MT = OSZ == 2 ? 2 : 1;               // wave m-tiles (32 rows) per pass
+    static constexpr int ROWS = 32 * MT;                      // 64 / 32
+    static constexpr int PASSES = 256 / ROWS;                 // 4 / 8
 };
 
-template <int OSZ, int GMODE, bool EXACT>
-__device__ __forceinline__ void stage256(char* smem, const f32x16_t (&acc)[2][4], const float* bias, int n0, int N,
+// registers -> staging.  GMODE 0: acc + bias; 1: gelu; 2: gelu'.  `nmt` m-tiles starting at mt0.
+template <int OSZ, int GMODE, bool EXACT, int NMT>
+__device__ __forceinline__ void stage256(char* st, const f32x16_t (&acc)[2][4], const float* bias, int n0, int N,
                                          int mt0, int wn, int lane) {
     using E = Epi256<OSZ>;
     const int h = lane >> 5;
@@ -67,8 +77,9 @@ __device__ __forceinline__ void stage256(char* smem, const f32x16_t (&acc)[2][4]
                 const float4 t = *reinterpret_cast<const float4*>(bias + n0 + nl);
                 b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w;
             }
+            const int cb = nl * OSZ;                                   // byte column
 #pragma unroll
-            for (int mi = 0; mi < E::MT; ++mi) {
+            for (int mi = 0; mi < NMT; ++mi) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -79,7 +90,8 @@ __device__ __forceinline__ void stage256(char* smem, const f32x16_t (&acc)[2][4]
                         v[e] = GMODE == 1 ? gv : dv;
                     }
                 }
-                char* dst = smem + (mi * 32 + (lane & 31)) * E::PITCH + nl * OSZ;
+                const int row = mi * 32 + (lane & 31);
+                char* dst = st + row * E::ROWB + ((((cb >> 4) ^ (row & 31))) << 4) + (cb & 15);
                 if (OSZ == 4) {
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
@@ -91,14 +103,12 @@ __device__ __forceinline__ void stage256(char* smem, const f32x16_t (&acc)[2][4]
             }
         }
 }
-
-// GELU with the derivative side output: value and derivative come out of ONE gelu_pair per element and are
-// staged together, 64 rows (2 wave m-tiles) at a time, into two LDS regions (`smem` and `smem + region`).
-template <int OSZ, bool EXACT, int NMT>
-__device__ __forceinline__ void stage256_pair(char* smem, int region, const f32x16_t (&acc)[2][4], const float* bias,
-                                              int n0, int N, int mt0, int wn, int lane) {
-    using E = Epi256<OSZ>;
+// value and derivative of GELU from ONE gelu_pair per element, 32 rows, into two 16 KiB regions (bf16 only)
+template <bool EXACT>
+__device__ __forceinline__ void stage256_pair_bf16(char* st, const f32x16_t (&acc)[2][4], const float* bias, int n0,
+                                                   int N, int mt, int wn, int lane) {
     const int h = lane >> 5;
+    const int row = lane & 31;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -109,36 +119,31 @@ __device__ __forceinline__ void stage256_pair(char* smem, int region, const f32x
                 const float4 t = *reinterpret_cast<const float4*>(bias + n0 + nl);
                 b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w;
             }
+            float v[4], d[4];
 #pragma unroll
-            for (int mi = 0; mi < NMT; ++mi) {
-                float v[4], d[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) gelu_pair<EXACT>(acc[nt][mt0 + mi][4 * g + e] + b4[e], v[e], d[e]);
-                char* dst = smem + (mi * 32 + (lane & 31)) * E::PITCH + nl * OSZ;
-                if (OSZ == 4) {
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(dst + region) = make_float4(d[0], d[1], d[2], d[3]);
-                } else {
-                    chunk8 o, q;
-                    o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
-                    q[0] = pack_bf2(d[0], d[1]); q[1] = pack_bf2(d[2], d[3]);
-                    *reinterpret_cast<chunk8*>(dst) = o;
-                    *reinterpret_cast<chunk8*>(dst + region) = q;
-                }
-            }
+            for (int e = 0; e < 4; ++e) gelu_pair<EXACT>(acc[nt][mt][4 * g + e] + b4[e], v[e], d[e]);
+            const int cb = nl * 2;
+            char* dst = st + row * 512 + ((((cb >> 4) ^ row)) << 4) + (cb & 15);
+            chunk8 o, q;
+            o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
+            q[0] = pack_bf2(d[0], d[1]); q[1] = pack_bf2(d[2], d[3]);
+            *reinterpret_cast<chunk8*>(dst) = o;
+            *reinterpret_cast<chunk8*>(dst + 16384) = q;
         }
 }
 
-template <int OSZ, int MODE, int ROWS = Epi256<OSZ>::ROWS>
-__device__ __forceinline__ void drain256(const char* smem, void* dst, int64_t ld, const void* aux, int64_t ld_aux,
-                                         int mbase, int n0, int M, int N, int tid) {
+// staging -> global, 16-byte stores, executed by the 256 threads of the second wave group only (t = 0..255).
+// MODE 0 plain, 1 += fp32 residual, 2 *= aux (aux in out dtype)
+template <int OSZ, int MODE>
+__device__ __forceinline__ void drain256(const char* st, int rows, void* dst, int64_t ld, const void* aux,
+                                         int64_t ld_aux, int mbase, int n0, int M, int N, int t) {
     using E = Epi256<OSZ>;
-#pragma unroll 4
-    for (int c = tid; c < ROWS * E::CPR; c += 512) {
+#pragma unroll 2
+    for (int c = t; c < rows * E::CPR; c += 256) {
         const int row = c / E::CPR, cc = c - row * E::CPR;
         const int gm = mbase + row, gn = n0 + cc * E::EPC;
         if (gm >= M || gn >= N) continue;
-        chunk16 v = *reinterpret_cast<const chunk16*>(smem + row * E::PITCH + cc * 16);
+        chunk16 v = *reinterpret_cast<const chunk16*>(st + row * E::ROWB + ((cc ^ (row & 31)) << 4));
         if (MODE == 1) {
             const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(aux) + (int64_t)gm * ld_aux + gn);
             v[0] = f2u(u2f(v[0]) + r.x); v[1] = f2u(u2f(v[1]) + r.y);
@@ -159,29 +164,53 @@ __device__ __forceinline__ void drain256(const char* smem, void* dst, int64_t ld
                 }
             }
         }
-        // streaming output: written once, re-read by a later kernel after > L2-size of other traffic
-        __builtin_nontemporal_store(v, reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ));
+        *reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ) = v;
     }
 }
 
+// barrier of the epilogue: LDS traffic must be complete, global stores must NOT be waited for
+__device__ __forceinline__ void epi_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+    __builtin_amdgcn_s_barrier();
+}
+
+// Epilogue of one tile.  Every wave stages its accumulators pass by pass; ONLY the second wave group
+// (wm == 1) issues global stores -- the first group owns the operand DMA stream, and vmcnt retires in
+// order, so keeping stores out of its queue is what lets the next tile's loads fly under this epilogue.
 template <int OSZ, bool EXACT>
-__device__ __forceinline__ void epilogue256(char* smem, const f32x16_t (&acc)[2][4], const Gemm256Params& p, int m0,
-                                            int n0, int wm, int wn, int lane, int tid) {
+__device__ __forceinline__ void epilogue256(char* st, const f32x16_t (&acc)[2][4], const Gemm256Params& p, int m0,
+                                            int n0, int wm, int wn, int lane, int tid, long long* pr) {
     using E = Epi256<OSZ>;
+    const bool storer = wm == 1;
+    const int t = tid - 256;
     if (p.epi == MAEST_EPI_GELU && p.aux_out != nullptr) {
-        constexpr int PR = OSZ == 2 ? 64 : 32;       // rows per pass (fp32 rows are twice as wide)
-        constexpr int PMT = PR / 32;
-        constexpr int REGION = PR * E::PITCH;        // 33792 (bf16) / 33280 (fp32); two regions per pass
+        if (OSZ == 2) {
 #pragma unroll
-        for (int ps = 0; ps < 256 / PR; ++ps) {
-            const int pwm = ps / (4 / PMT);
-            const int mt0 = (ps % (4 / PMT)) * PMT;
-            const int mbase = m0 + pwm * 128 + mt0 * 32;
-            if (wm == pwm) stage256_pair<OSZ, EXACT, PMT>(smem, REGION, acc, p.bias, n0, p.N, mt0, wn, lane);
-            __syncthreads();
-            drain256<OSZ, 0, PR>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
-            drain256<OSZ, 0, PR>(smem + REGION, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
-            __syncthreads();
+            for (int ps = 0; ps < 8; ++ps) {       // 32 rows per pass, value + derivative side by side
+                const int pwm = ps >> 2, mt = ps & 3;
+                const int mbase = m0 + pwm * 128 + mt * 32;
+                if (wm == pwm) stage256_pair_bf16<EXACT>(st, acc, p.bias, n0, p.N, mt, wn, lane);
+                epi_barrier();
+                if (storer) {
+                    drain256<2, 0>(st, 32, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, t);
+                    drain256<2, 0>(st + 16384, 32, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, t);
+                }
+                epi_barrier();
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {       // fp32 (parity mode): two stagings per 32-row pass
+                const int pwm = ps >> 2, mt = ps & 3;
+                const int mbase = m0 + pwm * 128 + mt * 32;
+                if (wm == pwm) stage256<4, 1, EXACT, 1>(st, acc, p.bias, n0, p.N, mt, wn, lane);
+                epi_barrier();
+                if (storer) drain256<4, 0>(st, 32, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, t);
+                epi_barrier();
+                if (wm == pwm) stage256<4, 2, EXACT, 1>(st, acc, p.bias, n0, p.N, mt, wn, lane);
+                epi_barrier();
+                if (storer) drain256<4, 0>(st, 32, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, t);
+                epi_barrier();
+            }
         }
         return;
     }
@@ -190,31 +219,29 @@ __device__ __forceinline__ void epilogue256(char* smem, const f32x16_t (&acc)[2]
         const int pwm = ps / (4 / E::MT);
         const int mt0 = (ps % (4 / E::MT)) * E::MT;
         const int mbase = m0 + pwm * 128 + mt0 * 32;
-        const bool mine = (wm == pwm);   // wave-uniform
-        if (p.epi == MAEST_EPI_GELU) {
-            if (p.aux_out != nullptr) {
-                if (mine) stage256<OSZ, 2, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
-                __syncthreads();
-                drain256<OSZ, 0>(smem, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
-                __syncthreads();
-            }
-            if (mine) stage256<OSZ, 1, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
-            __syncthreads();
-            drain256<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
-        } else {
-            if (mine) stage256<OSZ, 0, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
-            __syncthreads();
-            if (p.epi == MAEST_EPI_RESIDUAL)
-                drain256<OSZ, 1>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
-            else if (p.epi == MAEST_EPI_MUL)
-                drain256<OSZ, 2>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
-            else
-                drain256<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
+        stamp(pr, 3 * ps + 0, tid);
+        if (wm == pwm) {
+            if (p.epi == MAEST_EPI_GELU) stage256<OSZ, 1, EXACT, E::MT>(st, acc, p.bias, n0, p.N, mt0, wn, lane);
+            else stage256<OSZ, 0, EXACT, E::MT>(st, acc, p.bias, n0, p.N, mt0, wn, lane);
         }
-        __syncthreads();
+        stamp(pr, 3 * ps + 1, tid);
+        epi_barrier();
+        stamp(pr, 3 * ps + 2, tid);
+        if (storer) {
+            if (p.epi == MAEST_EPI_RESIDUAL)
+                drain256<OSZ, 1>(st, E::ROWS, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, t);
+            else if (p.epi == MAEST_EPI_MUL)
+                drain256<OSZ, 2>(st, E::ROWS, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, t);
+            else
+                drain256<OSZ, 0>(st, E::ROWS, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, t);
+        }
+        epi_barrier();
     }
 }
 
+// Persistent workgroups (one per CU) walk their tiles back to back; the operand DMA is ONE continuous
+// stream of 64-byte K slices through the 4-deep ring that simply crosses tile boundaries, so the first
+// three slices of tile t+1 are already landing while tile t's epilogue runs.
 template <typename T>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(Gemm256Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -223,114 +250,134 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(Gemm256Params p) {
     const int wave = tid >> 6;          // 0..7
     const int wm = wave >> 2, wn = wave & 3;
     const int h = lane >> 5;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = wg / p.tiles_n;
-    const int tile_n = wg - tile_m * p.tiles_n;
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    char* stage_area = smem + G2_RING;
 
     constexpr int ELT = (int)sizeof(T);
     constexpr int KS = G2_ROWB / ELT;        // 32 / 16 elements per slice
     const int nslices = p.K / KS;
 
-    // LDS-DMA map: wave-instruction (wave, i) fills rows [(wave*2+i)*16, +16) of a tile; lane -> (row, position)
-    const char* a_src[2];
-    const char* b_src[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (wave * 2 + i) * 16 + (lane >> 2);
-        const int csrc = (lane & 3) ^ ((r >> 2) & 3);        // source-side swizzle
-        int ra = m0 + r;
-        if (ra > p.M - 1) ra = p.M - 1;
-        int rb = n0 + r;
-        if (rb > p.N - 1) rb = p.N - 1;
-        a_src[i] = p.A + (int64_t)ra * p.lda * ELT + csrc * 16;
-        b_src[i] = p.B + (int64_t)rb * p.ldb * ELT + csrc * 16;
-    }
-    const int dma_off = wave * 2 * 1024;
+    // tiles of this workgroup: block b (XCD b % 8, observed) walks  wg0 + k * gridDim,
+    // wg0 = (b % 8) * (gridDim / 8) + b / 8, so the workgroups of one XCD share A panels in time.
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int grid = (int)gridDim.x;
+    const int wg0 = grid >= 8 ? (int)((blockIdx.x & 7) * (grid >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int ntiles = wg0 < nwg ? (nwg - wg0 + grid - 1) / grid : 0;
+    const int total = ntiles * nslices;
 
-    f32x16_t acc[2][4];   // [nt][mt]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // half h2 (0/1) of the 4 LDS-DMA instructions this wave owes to slice s: one A piece + one B piece
-    auto issue_half = [&](int s, int h2) {
-        const int sc = s < nslices ? s : nslices - 1;        // past-the-end issues re-load the last slice into a dead
-        char* la = smem + (s & (G2_STAGES - 1)) * 2 * G2_TILE + dma_off;   // buffer: keeps the vmcnt arithmetic uniform
-        char* lb = la + G2_TILE;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[h2] + (int64_t)sc * G2_ROWB),
-                                         (__attribute__((address_space(3))) void*)(la + h2 * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[h2] + (int64_t)sc * G2_ROWB),
-                                         (__attribute__((address_space(3))) void*)(lb + h2 * 1024), 16, 0, 0);
+    // ---- DMA stream state (first wave group only: waves 0-3 issue ALL loads, 8 per slice each).
+    // M % 256 == 0 and N % 256 == 0 here (host-checked), so the four 16-row pieces of a wave are a constant
+    // row stride apart and the whole state is two 32-bit lane offsets (operands < 4 GiB, host-checked).
+    uint32_t a_lane = 0, b_lane = 0;
+    const uint32_t a_piece = 16u * (uint32_t)p.lda * ELT, b_piece = 16u * (uint32_t)p.ldb * ELT;
+    int iss_g = 0, iss_slice = 0, iss_tile = 0;
+    auto set_issue_tile = [&](int k) {
+        const int wg = wg0 + k * grid;
+        const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+        const int r = wave * 64 + (lane >> 2);                       // wave = 0..3 here; piece i adds 16 rows
+        const uint32_t csrc = (uint32_t)((lane & 3) ^ ((r >> 2) & 3)) * 16u;   // source-side swizzle
+        a_lane = (uint32_t)(tm * 256 + r) * (uint32_t)p.lda * ELT + csrc;
+        b_lane = (uint32_t)(tn * 256 + r) * (uint32_t)p.ldb * ELT + csrc;
     };
-    auto issue = [&](int s) { issue_half(s, 0); issue_half(s, 1); };
-
-    int a_off[4], b_off[2], a_swz[4], b_swz[2];
+    auto issue = [&]() {   // next slice of the stream; past the end it re-loads the last slice into a dead slot
+        char* la = smem + (iss_g & (G2_STAGES - 1)) * 2 * G2_TILE + wave * 4 * 1024;
+        char* lb = la + G2_TILE;
+        const uint32_t so = (uint32_t)iss_slice * G2_ROWB;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int row = wm * 128 + mt * 32 + (lane & 31);
-        a_off[mt] = row * G2_ROWB;
-        a_swz[mt] = (row >> 2) & 3;
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int row = wn * 64 + nt * 32 + (lane & 31);
-        b_off[nt] = row * G2_ROWB;
-        b_swz[nt] = (row >> 2) & 3;
-    }
-
-    // ---- main loop: two phases per slice, LOAD (LDS -> fragment registers, issue the DMA of slice s+3) and
-    // COMPUTE (16 MFMAs, no memory traffic), separated by raw barriers.  The second wave group (wm == 1)
-    // runs ONE BARRIER BEHIND the first, so on every SIMD one wave is in COMPUTE while its partner is in
-    // LOAD: the matrix pipe never waits for ds_read / DMA issue, and those never wait for the pipe.
-    //   barrier 2s   : A: LOAD(s)     B: COMPUTE(s-1)
-    //   barrier 2s+1 : A: COMPUTE(s)  B: LOAD(s)
-    // Slice s is resident before anybody reads it: every wave ends LOAD(s-1) with vmcnt(8) (slices s+1, s+2
-    // may still fly) and the barrier(s) in between publish that to the other group.  DMA of slice s+3
-    // overwrites buffer (s-1)&3, whose last reader (B's LOAD(s-1)) finished before barrier 2s.
-    issue(0);
-    issue(1);
-    issue(2);
-    MAEST_WAIT_VMCNT(8);
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger (wave-uniform)
-    chunk16 fa[2][4], fb[2][2];
-    for (int s = 0; s < nslices; ++s) {
-        const char* la = smem + (s & (G2_STAGES - 1)) * 2 * G2_TILE;
-        const char* lb = la + G2_TILE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int kc = 2 * ks + h;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                fa[ks][mt] = *reinterpret_cast<const chunk16*>(la + a_off[mt] + ((kc ^ a_swz[mt]) << 4));
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                fb[ks][nt] = *reinterpret_cast<const chunk16*>(lb + b_off[nt] + ((kc ^ b_swz[nt]) << 4));
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.A + (a_lane + so + i * a_piece)),
+                                             (__attribute__((address_space(3))) void*)(la + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.B + (b_lane + so + i * b_piece)),
+                                             (__attribute__((address_space(3))) void*)(lb + i * 1024), 16, 0, 0);
         }
-        issue(s + 3);
-        __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): slice s+1 resident, fragments in registers
+        ++iss_g;
+        if (iss_g < total) {
+            if (++iss_slice == nslices) {
+                iss_slice = 0;
+                set_issue_tile(++iss_tile);
+            }
+        }
+    };
+
+    // fragment read offsets: row = w*.. + mt*32 + (lane&31), so the swizzle term (row >> 2) & 3 depends on the lane only
+    const int swz = (lane >> 2) & 3;
+    const int a_base = (wm * 128 + (lane & 31)) * G2_ROWB;
+    const int b_base = (wn * 64 + (lane & 31)) * G2_ROWB;
+    const int koff0 = ((0 + h) ^ swz) << 4, koff1 = ((2 + h) ^ swz) << 4;
+
+    if (ntiles > 0) {
+        if (wm == 0) {
+            set_issue_tile(0);
+            issue();
+            issue();
+            issue();
+            MAEST_WAIT_VMCNT(16);            // slice 0 resident
+        }
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one phase
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();          // un-stagger
-    MAEST_WAIT_VMCNT(0);   // drain the past-the-end loads before LDS is reused
-    __syncthreads();   // every wave is done with the operand buffers: LDS becomes the C staging area
-    if (p.out_dtype == MAEST_BF16) epilogue256<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
-    else epilogue256<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+    // ---- phases (see gemm_tn256_kernel for the same scheme): per slice LOAD (LDS -> fragments, DMA issue)
+    // and COMPUTE (16 MFMAs), raw barriers in between, second wave group one barrier behind the first:
+    //   barrier 2g   : A: LOAD(g)     B: COMPUTE(g-1)
+    //   barrier 2g+1 : A: COMPUTE(g)  B: LOAD(g)
+    // A ends LOAD(g) with vmcnt(16): slices g+2, g+3 may still fly, slice g+1 is resident; the barriers in
+    // between publish that to B.  The DMA of slice g+3 overwrites slot (g-1)&3, last read by B's LOAD(g-1),
+    // which finished before barrier 2g.
+    int gc = 0;     // global slice counter of the consumer side
+    chunk16 fa[2][4], fb[2][2];
+    for (int k = 0; k < ntiles; ++k) {
+        const int wg = wg0 + k * grid;
+        const int tile_m = wg / p.tiles_n;
+        const int tile_n = wg - tile_m * p.tiles_n;
+        const int m0 = tile_m * 256, n0 = tile_n * 256;
+        f32x16_t acc[2][4];   // [nt][mt]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+        for (int s = 0; s < nslices; ++s, ++gc) {
+            const char* la = smem + (gc & (G2_STAGES - 1)) * 2 * G2_TILE;
+            const char* lb = la + G2_TILE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ko = ks == 0 ? koff0 : koff1;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    fa[ks][mt] = *reinterpret_cast<const chunk16*>(la + a_base + ko + mt * 32 * G2_ROWB);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    fb[ks][nt] = *reinterpret_cast<const chunk16*>(lb + b_base + ko + nt * 32 * G2_ROWB);
+            }
+            if (wm == 0) {
+                issue();                              // slice gc + 3 of the stream
+                __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16) lgkmcnt(0)
+            } else {
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();          // un-stagger: both groups are done with this tile
+        long long pr[32];
+        for (int i = 0; i < 32; ++i) pr[i] = 0;
+        if (p.out_dtype == MAEST_BF16) epilogue256<2, sizeof(T) == 4>(stage_area, acc, p, m0, n0, wm, wn, lane, tid, pr);
+        else epilogue256<4, sizeof(T) == 4>(stage_area, acc, p, m0, n0, wm, wn, lane, tid, pr);
+        stamp(pr, 30, tid);
+        if ((tid == 0 || tid == 256) && k == 0 && blockIdx.x < 256) { for (int i = 0; i < 32; ++i) g_prof[(blockIdx.x * 2 + (tid >> 8)) * 32 + i] = pr[i]; }
+        if (wm == 1 && k + 1 < ntiles) __builtin_amdgcn_s_barrier();   // re-stagger for the next tile
+        if (wm == 0 && k + 1 < ntiles) { /* first group proceeds straight into LOAD of the next tile */ }
+    }
+    if (wm == 0) MAEST_WAIT_VMCNT(0);   // drain the past-the-end loads before the LDS is handed back
 }
 
 template <typename T>
@@ -338,10 +385,13 @@ static int launch256(Gemm256Params& p, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM_NT);
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm_nt256_kernel<T>, dim3(p.tiles_m * p.tiles_n), dim3(512), G2_SMEM, stream, p);
+    int grid = p.tiles_m * p.tiles_n;
+    if (grid > 256) grid = 256;          // persistent: one workgroup per CU
+    if (grid >= 8) grid &= ~7;           // keep the per-XCD tile walk regular
+    hipLaunchKernelGGL(gemm_nt256_kernel<T>, dim3(grid), dim3(512), G2_SMEM_NT, stream, p);
     return check_launch("maest_gemm_nt(256)");
 }
 
@@ -350,8 +400,10 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
                    int out_dtype, int M, int N, int K, const float* bias, int epi, const void* aux_in, void* aux_out,
                    int64_t ld_aux, hipStream_t stream) {
     if (epi == MAEST_EPI_ATOMIC) return -1;
-    if (M < 512 || N < 256 || (N % 256) != 0) return -1;
-    if ((K * (in_dtype == MAEST_BF16 ? 2 : 4)) % G2_ROWB != 0) return -1;
+    if (M < 512 || (M % 256) != 0 || N < 256 || (N % 256) != 0) return -1;
+    const int64_t elt = in_dtype == MAEST_BF16 ? 2 : 4;
+    if ((K * elt) % G2_ROWB != 0) return -1;
+    if ((int64_t)M * lda * elt >= (int64_t)0xFFFF0000 || (int64_t)N * ldb * elt >= (int64_t)0xFFFF0000) return -1;
     Gemm256Params p;
     p.A = (const char*)A; p.B = (const char*)B; p.C = C;
     p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
@@ -361,7 +413,6 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
     p.tiles_n = N / 256;
     return in_dtype == MAEST_BF16 ? launch256<bf16_t>(p, stream) : launch256<float>(p, stream);
 }
-
 
 // ================================================================================================
 // 256x256-tile TN GEMM (wgrad + bias grad):  C[i][j] += sum_k A[k][i] * B[k][j],  colsum[i] += sum_k A[k][i]
@@ -584,3 +635,27 @@ int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int d
 }
 
 }  // namespace maest
+namespace maest { void set_error(const char*, ...) {} int check_launch(const char*) { return hipGetLastError() != hipSuccess; } }
+#include <stdio.h>
+#include <vector>
+int main() {
+    const int M = 74240, N = 3072, K = 768;
+    void *A, *B, *C; long long* prof;
+    hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2);
+    hipMalloc(&prof, 512 * 32 * 8);
+    hipMemset(A, 0, (size_t)M * K * 2); hipMemset(B, 0, (size_t)N * K * 2);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_prof), &prof, sizeof(prof));
+    for (int it = 0; it < 2; ++it)
+        maest::gemm_nt256_try(A, K, B, K, MAEST_BF16, C, N, MAEST_BF16, M, N, K, nullptr, MAEST_EPI_NONE, nullptr, nullptr, 0, 0);
+    hipDeviceSynchronize();
+    std::vector<long long> h(512 * 32);
+    hipMemcpy(h.data(), prof, 512 * 32 * 8, hipMemcpyDeviceToHost);
+    for (int grp = 0; grp < 2; ++grp) {
+        printf("wave group %d (thread %d), block 17: ", grp, grp * 256);
+        long long t0 = h[(17 * 2 + grp) * 32 + 0];
+        for (int i = 0; i < 12; ++i) printf("%lld ", h[(17 * 2 + grp) * 32 + i] - t0);
+        printf(" end %lld\n", h[(17 * 2 + grp) * 32 + 30] - t0);
+    }
+    return 0;
+}
+

@@ -10,7 +10,8 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("shape", [(1120, 2304, 768), (562, 768, 3072), (300, 400, 768), (2 * 9 * 32, 768, 256)])
+@pytest.mark.parametrize("shape", [(1120, 2304, 768), (562, 768, 3072), (300, 400, 768), (2 * 9 * 32, 768, 256),
+                                   (1024, 2304, 768), (2560, 768, 3072), (9216, 768, 256), (74240, 768, 768)])
 def test_gemm(dtype, shape):
     KC.case_gemm(DEV, dtype, *shape)
 
