@@ -160,6 +160,14 @@ class _Engine:
     def __init__(self, model: "MAEST"):
         self.m = model
         self.w = _Weights()
+        self.overlap_wgrad = True
+        self._side = {}
+
+    def _side_stream(self, dev):
+        key = str(dev)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
 
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, x3: torch.Tensor, dt, *, toffset: int, tok_ft: torch.Tensor, perm, lam,
@@ -255,10 +263,38 @@ class _Engine:
                 return v.view(*shape)          # zeroed by sink.reset()
             return torch.zeros(*shape, dtype=torch.float32, device=dev)
 
+        # Weight / bias gradients are off the critical path (nothing in backward consumes them), so they run on
+        # a SIDE HIP stream and overlap with the dgrad -> LayerNorm -> attention chain on the main stream: the
+        # NT dgrad GEMMs are bound by their C-tile writes, the TN wgrad GEMMs by the MFMA pipe.
+        side = self._side_stream(dev) if (self.overlap_wgrad and dev.type == "cuda") else None
+        main = torch.cuda.current_stream(dev) if side is not None else None
+
         def done(name, g):
             G[name] = g
             if sink is not None:
-                sink.on_grad(name)
+                if side is not None:      # the bucket's all-reduce must be ordered after BOTH streams
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        sink.on_grad(name)
+                else:
+                    sink.on_grad(name)
+
+        def wgrad(name_w, name_b, dy, x, n_out, k_out, w_shape=None):
+            gw, gb = buf(name_w, n_out, k_out), buf(name_b, n_out)
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)            # dy, x and the zeroed destinations are ready at this point
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    _wgrad(dy, x, n_out, k_out, gw, gb)
+                for t in (dy, x, gw, gb):
+                    t.record_stream(side)  # keep the caching allocator from recycling them under the side stream
+            else:
+                _wgrad(dy, x, n_out, k_out, gw, gb)
+            done(name_w, gw if w_shape is None else gw.view(w_shape))
+            done(name_b, gb)
 
         C = m.head[1].out_features
         cpad = ops.round_up(C, 64)
@@ -271,9 +307,7 @@ class _Engine:
 
         def head_linear_bwd(dlogits, inp_lp, lin, prefix):
             dl = lp_padded(dlogits)
-            gb = buf(prefix + ".bias", C)
-            done(prefix + ".weight", _wgrad(dl, inp_lp, C, EMBED_DIM, buf(prefix + ".weight", C, EMBED_DIM), gb))
-            done(prefix + ".bias", gb)
+            wgrad(prefix + ".weight", prefix + ".bias", dl, inp_lp, C, EMBED_DIM)
             wt = W.get(lin.weight, dt, transposed=True, pad_cols_to=64)          # [768, cpad]
             return ops.gemm_nt(dl, wt, None, out_dtype=dt, M=B, N=EMBED_DIM, K=cpad)
 
@@ -313,15 +347,11 @@ class _Engine:
             p = f"blocks.{i}."
             H = blk.mlp.fc1.out_features
             # fc2 (+ residual):  x2 = x1 + g W2^T + b2
-            gb = buf(p + "mlp.fc2.bias", EMBED_DIM)
-            done(p + "mlp.fc2.weight", _wgrad(dx_lp, s["g"], EMBED_DIM, H, buf(p + "mlp.fc2.weight", EMBED_DIM, H), gb))
-            done(p + "mlp.fc2.bias", gb)
+            wgrad(p + "mlp.fc2.weight", p + "mlp.fc2.bias", dx_lp, s["g"], EMBED_DIM, H)
             dh = ops.gemm_nt(dx_lp, W.get(blk.mlp.fc2.weight, dt, transposed=True), None, out_dtype=dt,
                              epi=ops.EPI_MUL, aux_in=s["h"])
             # fc1
-            gb = buf(p + "mlp.fc1.bias", H)
-            done(p + "mlp.fc1.weight", _wgrad(dh, s["ln2"], H, EMBED_DIM, buf(p + "mlp.fc1.weight", H, EMBED_DIM), gb))
-            done(p + "mlp.fc1.bias", gb)
+            wgrad(p + "mlp.fc1.weight", p + "mlp.fc1.bias", dh, s["ln2"], H, EMBED_DIM)
             dln2 = ops.gemm_nt(dh, W.get(blk.mlp.fc1.weight, dt, transposed=True), None, out_dtype=dt)
             gw, gb = buf(p + "norm2.weight", EMBED_DIM), buf(p + "norm2.bias", EMBED_DIM)
             dx1, dx1_lp = ops.layernorm_bwd(dln2, s["x1"], blk.norm2.weight, s["mean2"], s["rstd2"], dx, gw, gb,
@@ -331,16 +361,10 @@ class _Engine:
             if dt == torch.float32:
                 dx1_lp = dx1
             # proj (+ residual)
-            gb = buf(p + "attn.proj.bias", EMBED_DIM)
-            done(p + "attn.proj.weight", _wgrad(dx1_lp, s["ao"], EMBED_DIM, EMBED_DIM,
-                                                buf(p + "attn.proj.weight", EMBED_DIM, EMBED_DIM), gb))
-            done(p + "attn.proj.bias", gb)
+            wgrad(p + "attn.proj.weight", p + "attn.proj.bias", dx1_lp, s["ao"], EMBED_DIM, EMBED_DIM)
             dao = ops.gemm_nt(dx1_lp, W.get(blk.attn.proj.weight, dt, transposed=True), None, out_dtype=dt)
             dqkv = ops.attn_bwd(s["qkv"], s["ao"], dao, s["lse"], B, N, blk.attn.scale)
-            gb = buf(p + "attn.qkv.bias", 3 * EMBED_DIM)
-            done(p + "attn.qkv.weight", _wgrad(dqkv, s["ln1"], 3 * EMBED_DIM, EMBED_DIM,
-                                               buf(p + "attn.qkv.weight", 3 * EMBED_DIM, EMBED_DIM), gb))
-            done(p + "attn.qkv.bias", gb)
+            wgrad(p + "attn.qkv.weight", p + "attn.qkv.bias", dqkv, s["ln1"], 3 * EMBED_DIM, EMBED_DIM)
             dln1 = ops.gemm_nt(dqkv, W.get(blk.attn.qkv.weight, dt, transposed=True), None, out_dtype=dt)
             gw, gb = buf(p + "norm1.weight", EMBED_DIM), buf(p + "norm1.bias", EMBED_DIM)
             dx, dx_lp = ops.layernorm_bwd(dln1, s["x"], blk.norm1.weight, s["mean1"], s["rstd1"], dx1, gw, gb,
@@ -362,11 +386,10 @@ class _Engine:
         done("new_pos_embed", d_np.view(1, 2, EMBED_DIM))
         done("freq_new_pos_embed", d_fp.view(1, EMBED_DIM, Fp, 1))
         done("time_new_pos_embed", d_tp.view(1, EMBED_DIM, 1, Tt))
-        gb = buf("patch_embed.proj.bias", EMBED_DIM)
-        done("patch_embed.proj.weight",
-             _wgrad(dpatch, ctx["cols"], EMBED_DIM, PATCH * PATCH,
-                    buf("patch_embed.proj.weight", EMBED_DIM, PATCH * PATCH), gb).view(m.patch_embed.proj.weight.shape))
-        done("patch_embed.proj.bias", gb)
+        wgrad("patch_embed.proj.weight", "patch_embed.proj.bias", dpatch, ctx["cols"], EMBED_DIM, PATCH * PATCH,
+              w_shape=m.patch_embed.proj.weight.shape)
+        if side is not None:
+            main.wait_stream(side)        # gradients are complete before backward returns to autograd / the optimizer
         return G
 
 
