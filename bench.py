@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--serial-kernels", action="store_true",
+                    help="disable the side-stream overlap of weight-gradient GEMMs (for kernel profiling)")
     args = ap.parse_args()
 
     from maest_amd import get_maest, ops
@@ -100,6 +102,8 @@ def main():
     net = get_maest("passt_s_swa_p16_128_ap476" if train else "discogs-maest-10s-pw-129e", pretrained=False,
                     input_t=625, s_patchout_t=args.patchout if train else 0, precision=args.precision).to(dev)
     broadcast_parameters(net)
+    if args.serial_kernels:
+        net._engine.overlap_wgrad = False
     mod = Module(net=net, mixup_alpha=0.3)
     Tp = (T - 16) // 10 + 1
     Tk = Tp - (args.patchout if train else 0)
@@ -158,6 +162,9 @@ def main():
     # records per step cost ~10 % of a step on the host; kernel durations themselves are unaffected.
     timer = None
     if not args.no_kernel_timing and world == 1:
+        # kernels are timed one at a time: with the wgrad GEMMs overlapping the dgrad chain on a second
+        # stream, an event pair around one launch would also count the time it shares the CUs with another
+        net._engine.overlap_wgrad = False
         with ops.KernelTimer(kinds={"maest_gemm_nt", "maest_gemm_tn", "maest_attn_fwd", "maest_attn_bwd"}) as timer:
             for _ in range(args.steps):
                 step()
@@ -197,7 +204,9 @@ def main():
                                    "traffic": None,
                                    "launches_per_step": g["launches"] // args.steps,
                                    "avg_launch_ms": round(g["ms"] / g["launches"], 4),
-                                   "ms_per_step": round(g["ms"] / args.steps, 3)}
+                                   "ms_per_step": round(g["ms"] / args.steps, 3),
+                                   "note": "second pass over the same K steps, kernels serialized (side-stream "
+                                           "overlap off) so that each event pair times one kernel alone"}
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in summ.items()}
             att = [summ.get("maest_attn_fwd"), summ.get("maest_attn_bwd")]
             aw = sum(a["work"] for a in att if a)
