@@ -37,6 +37,17 @@ def flops_per_clip_fwd(N, Tk, C=400):
     return 12 * per_block + 2 * (9 * Tk) * 256 * 768 + 2 * 768 * C
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE cannot be collected by bench.py on itself); None when the file is absent."""
+    path = os.path.join(REPO, "profiles", "r01c_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(batch, T, patchout, steps=2):
     """Oracle training step (fwd + bwd + AdamW) on the host cores: the reference's algorithm."""
     from oracle import maest_oracle as O
@@ -201,7 +212,7 @@ def main():
                                    "peak": PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
                                    "unit": "TFLOP/s",
                                    "frac": round(ach / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 4),
-                                   "traffic": None,
+                                   "traffic": pmc_traffic(),
                                    "launches_per_step": g["launches"] // args.steps,
                                    "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                                    "ms_per_step": round(g["ms"] / args.steps, 3),
