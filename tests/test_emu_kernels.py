@@ -24,10 +24,9 @@ def test_emu_gemm_ragged_n_scalar_epilogue(emu, dtype):
 @pytest.mark.parametrize("dtype", DT)
 def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype):
     """M >= 512 and N % 256 == 0 route to gemm256.hip (LDS-DMA staging, source-side swizzle)."""
-    # 3 x 3 tiles on 8 persistent workgroups: one workgroup walks two tiles (continuous DMA stream across
-    # the tile boundary, epilogue of tile 0 overlapping the first slices of tile 1)
-    K = 64 if dtype == torch.float32 else 128
-    KC.case_gemm(emu, dtype, 768, 768, K)
+    # 2 x 1 tiles, 6 K slices: the 4-deep ring wraps once
+    K = 96 if dtype == torch.float32 else 192
+    KC.case_gemm(emu, dtype, 512, 256, K)
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -58,7 +57,7 @@ def test_emu_attention(emu, dtype):
 
 
 def test_emu_attention_multi_tile_spike(emu):
-    KC.case_attention(emu, torch.float32, 1, 140, spike=True)
+    KC.case_attention(emu, torch.float32, 1, 100, spike=True)
 
 
 @pytest.mark.parametrize("dtype", DT)
