@@ -251,30 +251,38 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(c
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
             mma_rows<T>(s[kb], k_lds, kb * 32, lane, qf);
         }
+        // online softmax in the scaled log2 domain: p = 2^(s*c2 - m).  Only the ragged last tile pays for
+        // key masking; the elementwise work is written on float pairs (v_pk_fma_f32 / v_pk_add_f32).
+        if (kt == ntiles - 1 && (N & 63) != 0) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 64 + kb * 32 + frag_row(r, lane) >= N) s[kb][r] = NEG_BIG;
+        }
         float mx = NEG_BIG;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 64 + kb * 32 + frag_row(r, lane);
-                const float t = key < N ? s[kb][r] * c2 : NEG_BIG;
-                s[kb][r] = t;
-                mx = fmaxf(mx, t);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float m_new = fmaxf(m_run, mx * c2);
+        const float alpha = fast_exp2<T>(m_run - m_new);
         m_run = m_new;
-        float psum = 0.0f;
+        const f32x2_t c2v = {c2, c2}, nm = {-m_new, -m_new};
+        f32x2_t ps = {0.0f, 0.0f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[kb][r] - m_new);
-                s[kb][r] = p;
-                psum += p;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2_t sv = {s[kb][r], s[kb][r + 1]};
+                const f32x2_t e = __builtin_elementwise_fma(sv, c2v, nm);
+                const f32x2_t pv = {fast_exp2<T>(e[0]), fast_exp2<T>(e[1])};
+                s[kb][r] = pv[0];
+                s[kb][r + 1] = pv[1];
+                ps += pv;
             }
-        l_run = l_run * alpha + psum;  // per half-wave partial; halves are merged at the end
+        l_run = l_run * alpha + (ps[0] + ps[1]);  // per half-wave partial; halves are merged at the end
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -348,6 +356,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
     row_frags_load<T>(kf, kbase, QKV_LD, key, N, h);
     row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
     const bool key_ok = key < N;
+    const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
 
     f32x16_t dk[2], dv[2];
 #pragma unroll
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
         tile_load<T>(dr, dobase, OUT_LD, qt * 64, N, tid);
         if (tid < 64) {
             const int qq = qt * 64 + tid;
-            lse_r = qq < N ? lse_b[qq] * LOG2E : 0.0f;
+            lse_r = qq < N ? lse_b[qq] * LOG2E : -NEG_BIG;   // padded rows: P = 2^(-BIG) = 0
             dl_r = qq < N ? dl_b[qq] : 0.0f;
         }
     };
@@ -394,20 +403,23 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
             for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
             mma_rows<T>(s, q_lds, qb * 32, lane, kf);     // S[q][key]
             mma_rows<T>(dp, do_lds, qb * 32, lane, vf);   // dP[q][key]
+            // P = 2^(S*c2 - lse), dS = P * (dP - delta) on float pairs.  No masks: padded query rows carry
+            // lse = +BIG (P = 0 exactly), and a padded key column only feeds its own never-stored lane.
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ql = qb * 32 + 8 * g + 4 * h;  // local q of register 4g (4 consecutive rows)
-                const float4 l4 = *reinterpret_cast<const float4*>(lse_lds + ql);
-                const float4 d4 = *reinterpret_cast<const float4*>(dl_lds + ql);
-                const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
-                const float dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_lds + ql);
+                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dl_lds + ql);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; e += 2) {
                     const int r = 4 * g + e;
-                    const bool ok = key_ok && (qt * 64 + ql + e) < N;
-                    const float p = ok ? exp2f(s[r] * c2 - lv[e]) : 0.0f;
-                    s[r] = p;                       // P
-                    dp[r] = p * (dp[r] - dvv[e]);   // dS (unscaled)
+                    const f32x2_t sv = {s[r], s[r + 1]}, nl = {-l4[e], -l4[e + 1]};
+                    const f32x2_t dpv = {dp[r], dp[r + 1]}, dl = {d4[e], d4[e + 1]};
+                    const f32x2_t ev = __builtin_elementwise_fma(sv, c2v, nl);
+                    const f32x2_t pv = {fast_exp2<T>(ev[0]), fast_exp2<T>(ev[1])};
+                    const f32x2_t ds = pv * (dpv - dl);
+                    s[r] = pv[0]; s[r + 1] = pv[1];       // P
+                    dp[r] = ds[0]; dp[r + 1] = ds[1];     // dS (unscaled)
                 }
             }
             mma_transposed<T>(dv, do_lds, qb * 32, lane, s);   // dV^T[d][key] += dO^T[d][q] P[q][key]
@@ -446,6 +458,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
     const int qc = q_ok ? q : N - 1;
     const float lse_q = lse[((int64_t)b * NHEADS + head) * N + qc] * LOG2E;
     const float dl_q = delta[((int64_t)b * NHEADS + head) * N + qc];
+    const f32x2_t nlse = {-lse_q, -lse_q}, dlv = {dl_q, dl_q}, c2v = {scale * LOG2E, scale * LOG2E};
 
     f32x16_t dq[2];
 #pragma unroll
@@ -476,11 +489,20 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
             for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
             mma_rows<T>(s, k_lds, kb * 32, lane, qf);     // S^T[key][q]
             mma_rows<T>(dp, v_lds, kb * 32, lane, dof);   // dP^T[key][q]
+            // a padded key has a zero K row in LDS, so its dS column multiplies zeros below; the mask on the
+            // ragged last tile only keeps 2^(-lse) from overflowing there
+            if (kt == ntiles - 1 && (N & 63) != 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = kt * 64 + kb * 32 + frag_row(r, lane);
-                const float p = (kk < N) ? exp2f(s[r] * c2 - lse_q) : 0.0f;
-                dp[r] = p * (dp[r] - dl_q);   // dS^T (unscaled)
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 64 + kb * 32 + frag_row(r, lane) >= N) s[r] = NEG_BIG;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2_t sv = {s[r], s[r + 1]}, dpv = {dp[r], dp[r + 1]};
+                const f32x2_t ev = __builtin_elementwise_fma(sv, c2v, nlse);
+                const f32x2_t pv = {fast_exp2<T>(ev[0]), fast_exp2<T>(ev[1])};
+                const f32x2_t ds = pv * (dpv - dlv);
+                dp[r] = ds[0]; dp[r + 1] = ds[1];   // dS^T (unscaled)
             }
             mma_transposed<T>(dq, k_lds, kb * 32, lane, dp);   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
         }

@@ -18,15 +18,24 @@ __device__ __forceinline__ float bf2f(bf16_t h) {
     uint32_t u = ((uint32_t)h) << 16;
     return __builtin_bit_cast(float, u);
 }
-// round-to-nearest-even, NaN preserved as quiet NaN
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even: the gfx950 hardware conversion (v_cvt_pk_bf16_f32).  The integer
+// emulation this replaces compiled to ~8 VALU ops and an exec-mask branch PER VALUE, which made every
+// bf16 epilogue and the attention probability tiles VALU-bound.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, b);
+}
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.0f) & 0xffffu); }
+
+// 2^x: bare v_exp_f32 in bf16 mode (libm's exp2f adds a denormal-range rescale: cmp + cndmask + ldexp per
+// value); the exact libm form in fp32 parity mode
+template <typename T>
+__device__ __forceinline__ float fast_exp2(float x) {
+    if constexpr (sizeof(T) == 2) return __builtin_amdgcn_exp2f(x);
+    else return exp2f(x);
 }
 
 // A 16-byte MFMA operand chunk: 8 bf16 or 4 fp32, as loaded from LDS / global.
