@@ -224,6 +224,19 @@ def main():
             am = sum(a["ms"] for a in att if a)
             if am > 0:
                 out["attention_core_tflops"] = round(aw / (am * 1e-3) / 1e12, 1)
+            # north_star: "fraction of the attention-GEMM roofline" = the 12-block attention set (QKV projection +
+            # QK^T + PV + output projection), its launches picked out of the timed records by their
+            # algorithmic work (the MLP GEMMs have 3072-wide shapes)
+            Mtok = B * N
+            set_work = {2.0 * Mtok * 2304 * 768, 2.0 * Mtok * 768 * 768}
+            set_ms = sum(e0.elapsed_time(e1) for name, e0, e1, w in timer.records
+                         if name in ("maest_attn_fwd", "maest_attn_bwd")
+                         or (name in ("maest_gemm_nt", "maest_gemm_tn") and w in set_work)) / args.steps
+            set_flops = (3 if train else 1) * B * 12 * (2.0 * N * 768 * 2304 + 4.0 * N * N * 768 + 2.0 * N * 768 * 768)
+            if set_ms > 0:
+                out["attention_set"] = {"what": "12 x (QKV proj + QK^T + PV + out proj)" + (", fwd+bwd" if train else ", fwd"),
+                                        "ms_per_step": round(set_ms, 3), "tflops": round(set_flops / set_ms / 1e9, 1),
+                                        "mfma_frac": round(set_flops / set_ms / 1e9 / PEAK_BF16_TFLOPS, 4)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_batch, T, args.patchout if train else 0)

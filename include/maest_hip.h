@@ -77,6 +77,11 @@ int maest_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, 
  * With dtype == MAEST_F32 it is a plain copy / transpose (parity mode). */
 int maest_cast_weights(const float* src, void* dst, void* dst_t, int rows, int cols, int dtype,
                        void* stream);
+/* The same for n parameters in one launch (HOST arrays of n device pointers / shapes; dst[i] or dst_t[i] may
+ * be NULL): the operand-copy refresh after an optimizer step (autocast's per-call weight casts in the
+ * reference, ex_maest.py:51 precision="16-mixed"). */
+int maest_cast_weights_multi(int n, const float* const* src, void* const* dst, void* const* dst_t,
+                             const int* rows, const int* cols, int dtype, void* stream);
 
 /* ---- K7 LayerNorm over the last dim (nn.LayerNorm: models/maest.py:395,405,499,553,571) ---------
  * x: fp32 [rows, cols] (ldx); y: y_dtype [rows, cols] (ldy); mean/rstd: fp32 [rows] or NULL.

@@ -26,6 +26,7 @@ SIGNATURES = {
     "maest_gemm_tn": [_P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _P, _I, _P],
     "maest_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
     "maest_cast_weights": [_P, _P, _P, _I, _I, _I, _P],
+    "maest_cast_weights_multi": [_I, _P, _P, _P, _P, _P, _I, _P],
     "maest_layernorm_fwd": [_P, _L, _P, _P, _P, _L, _I, _P, _P, _I, _I, _F, _P],
     "maest_layernorm_bwd": [_P, _L, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
     "maest_attn_fwd": [_P, _P, _P, _I, _I, _I, _F, _P],

@@ -52,6 +52,21 @@ struct AttnCfg {
     static constexpr int ASTEPS = acc_steps<T>::value;
 };
 
+// Workgroup -> (row block, head, batch).  The row blocks of one (batch, head) re-read the same K/V (or Q/dO)
+// tiles; dispatched as a plain 3-D grid they land on different XCDs (round-robin) and each pulls its own copy
+// from HBM (measured 2.3x the algorithmic fetch at N = 290).  A 1-D grid remapped per XCD keeps them on one L2.
+struct AttnBlock { int rb, head, b; };
+__device__ __forceinline__ AttnBlock attn_block(int nrb, int B) {
+    const int total = nrb * NHEADS * B;
+    const int q = xcd_remap(blockIdx.x, total);
+    AttnBlock a;
+    a.rb = q % nrb;
+    const int bh = q / nrb;
+    a.head = bh % NHEADS;
+    a.b = bh / NHEADS;
+    return a;
+}
+
 // ---- 64-row tile staging: global -> registers -> LDS (row-major and/or transposed) -------------
 template <typename T>
 struct TileRegs {
@@ -204,14 +219,15 @@ __device__ __forceinline__ void store_dT(const f32x16_t (&acc)[2], T* row_ptr, i
 template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(const T* __restrict__ qkv,
                                                                                 T* __restrict__ out,
-                                                                                float* __restrict__ lse, int N,
+                                                                                float* __restrict__ lse, int B, int N,
                                                                                 float scale) {
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[key][d], V[key][d] }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const AttnBlock blk = attn_block((N + 127) / 128, B);
+    const int head = blk.head, b = blk.b;
+    const int q0 = blk.rb * 128 + wave * 32;
     const int q = q0 + (lane & 31);
     const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
     const T* kbase = qbase + NHEADS * HD;
@@ -336,15 +352,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
-    const float* __restrict__ delta, T* __restrict__ dqkv, int N, float scale) {
+    const float* __restrict__ delta, T* __restrict__ dqkv, int B, int N, float scale) {
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // 2 x { Q[q][d], dO[q][d], lse[64] (pre-multiplied by log2e), delta[64] }
     constexpr int BUF = 2 * C::TILE + 512;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int key = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const AttnBlock blk = attn_block((N + 127) / 128, B);
+    const int head = blk.head, b = blk.b;
+    const int key = blk.rb * 128 + wave * 32 + (lane & 31);
     const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
     const T* kbase = qbase + NHEADS * HD;
     const T* vbase = qbase + 2 * NHEADS * HD;
@@ -439,13 +456,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
 template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
-    const float* __restrict__ delta, T* __restrict__ dqkv, int N, float scale) {
+    const float* __restrict__ delta, T* __restrict__ dqkv, int B, int N, float scale) {
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[key][d], V[key][d] }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const AttnBlock blk = attn_block((N + 127) / 128, B);
+    const int head = blk.head, b = blk.b;
+    const int q = blk.rb * 128 + wave * 32 + (lane & 31);
     const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
     const T* kbase = qbase + NHEADS * HD;
     const T* vbase = qbase + 2 * NHEADS * HD;
@@ -526,8 +544,8 @@ static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
         once = true;
     }
-    dim3 grid((N + 127) / 128, NHEADS, B);
-    hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, N, scale);
+    dim3 grid(((N + 127) / 128) * NHEADS * B);
+    hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, B, N, scale);
     return check_launch("maest_attn_fwd");
 }
 
@@ -548,11 +566,11 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
     const int64_t items = (int64_t)B * N * NHEADS * 4;
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
                        (const T*)out, (const T*)dout, delta, B, N);
-    dim3 grid((N + 127) / 128, NHEADS, B);
+    dim3 grid(((N + 127) / 128) * NHEADS * B);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, grid, dim3(256), smem_a, st, (const T*)qkv, (const T*)dout, lse,
-                       (const float*)delta, (T*)dqkv, N, scale);
+                       (const float*)delta, (T*)dqkv, B, N, scale);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), smem_b, st, (const T*)qkv, (const T*)dout, lse,
-                       (const float*)delta, (T*)dqkv, N, scale);
+                       (const float*)delta, (T*)dqkv, B, N, scale);
     return check_launch("maest_attn_bwd");
 }
 

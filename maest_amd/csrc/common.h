@@ -166,6 +166,43 @@ __device__ __forceinline__ void gelu_pair(float x, float& g, float& dg) {
     dg = cdf + x * e * 0.39894228040143268f;
 }
 
+// The same on a pair of values with packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32: two lanes of work per
+// instruction) -- the GEMM epilogues spend their VALU time here.  EXACT falls back to the scalar form.
+template <bool EXACT>
+__device__ __forceinline__ void gelu_pair2(f32x2_t x, f32x2_t& g, f32x2_t& dg) {
+    if constexpr (EXACT) {
+        float g0, g1, d0, d1;
+        gelu_pair<true>(x[0], g0, d0);
+        gelu_pair<true>(x[1], g1, d1);
+        g = f32x2_t{g0, g1};
+        dg = f32x2_t{d0, d1};
+    } else {
+        const f32x2_t k1 = {-0.72134752044448170f, -0.72134752044448170f};       // -0.5 * log2(e)
+        const f32x2_t t2 = (x * x) * k1;
+        const f32x2_t e = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};   // exp(-x^2/2)
+        const f32x2_t au = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+        const f32x2_t one = {1.0f, 1.0f};
+        const f32x2_t pk = {0.3275911f * 0.70710678118654752f, 0.3275911f * 0.70710678118654752f};
+        const f32x2_t den = __builtin_elementwise_fma(au, pk, one);
+        const f32x2_t t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+        const f32x2_t a5 = {1.061405429f, 1.061405429f}, a4 = {-1.453152027f, -1.453152027f};
+        const f32x2_t a3 = {1.421413741f, 1.421413741f}, a2 = {-0.284496736f, -0.284496736f};
+        const f32x2_t a1 = {0.254829592f, 0.254829592f};
+        f32x2_t poly = __builtin_elementwise_fma(t, a5, a4);
+        poly = __builtin_elementwise_fma(t, poly, a3);
+        poly = __builtin_elementwise_fma(t, poly, a2);
+        poly = __builtin_elementwise_fma(t, poly, a1);
+        poly = poly * t;
+        const f32x2_t ea = __builtin_elementwise_fma(-poly, e, one);           // erf(|u|)
+        const f32x2_t half = {0.5f, 0.5f};
+        const f32x2_t hs = {__builtin_copysignf(0.5f, x[0]), __builtin_copysignf(0.5f, x[1])};
+        const f32x2_t cdf = __builtin_elementwise_fma(ea, hs, half);           // 0.5 * (1 + erf(u))
+        const f32x2_t c = {0.39894228040143268f, 0.39894228040143268f};
+        g = x * cdf;
+        dg = __builtin_elementwise_fma(x * e, c, cdf);
+    }
+}
+
 // exact-erf GELU (nn.GELU default) and its derivative
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {

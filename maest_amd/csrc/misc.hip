@@ -59,6 +59,50 @@ __global__ __launch_bounds__(256) void cast_weights_kernel(const float* __restri
     }
 }
 
+// ---- the same for MANY parameters in one launch: after an optimizer step every weight needs fresh operand
+// copies; ~100 tiny launches cost more in launch latency than in bytes.  The item table travels by value.
+constexpr int CAST_MAX_ITEMS = 64;
+struct CastTable {
+    const float* src[CAST_MAX_ITEMS];
+    void* dst[CAST_MAX_ITEMS];
+    void* dst_t[CAST_MAX_ITEMS];
+    int rows[CAST_MAX_ITEMS], cols[CAST_MAX_ITEMS];
+    int tile_begin[CAST_MAX_ITEMS + 1];   // prefix sum of 64x64 tiles
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void cast_weights_multi_kernel(const CastTable tab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);  // [64][65]
+    int it = 0;
+    while (it + 1 < tab.n && (int)blockIdx.x >= tab.tile_begin[it + 1]) ++it;   // block-uniform scalar search
+    const int rows = tab.rows[it], cols = tab.cols[it];
+    const float* __restrict__ src = tab.src[it];
+    T* __restrict__ dst = reinterpret_cast<T*>(tab.dst[it]);
+    T* __restrict__ dst_t = reinterpret_cast<T*>(tab.dst_t[it]);
+    const int local = blockIdx.x - tab.tile_begin[it];
+    const int tcols = (cols + 63) / 64;
+    const int r0 = (local / tcols) * 64, c0 = (local % tcols) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + i * 4 + ty, c = c0 + tx;
+        float v = 0.0f;
+        if (r < rows && c < cols) {
+            v = src[(int64_t)r * cols + c];
+            if (dst != nullptr) dst[(int64_t)r * cols + c] = elem_traits<T>::from_f32(v);
+        }
+        tile[(i * 4 + ty) * 65 + tx] = v;
+    }
+    if (dst_t == nullptr) return;  // uniform
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + i * 4 + ty, r = r0 + tx;
+        if (c < cols && r < rows) dst_t[(int64_t)c * rows + r] = elem_traits<T>::from_f32(tile[tx * 65 + i * 4 + ty]);
+    }
+}
+
 // ---- out[c] += sum_r src[r][c]; grid (ceil(cols/256), row chunks of 512)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ src, int64_t ld, int rows, int cols,
@@ -150,6 +194,34 @@ extern "C" int maest_cast_weights(const float* src, void* dst, void* dst_t, int 
         hipLaunchKernelGGL(cast_weights_kernel<float>, grid, dim3(256), 64 * 65 * 4, (hipStream_t)stream, src,
                            (float*)dst, (float*)dst_t, rows, cols);
     return check_launch("maest_cast_weights");
+}
+
+extern "C" int maest_cast_weights_multi(int n, const float* const* src, void* const* dst, void* const* dst_t,
+                                        const int* rows, const int* cols, int dtype, void* stream) {
+    MAEST_REQUIRE(n > 0 && src && dst && dst_t && rows && cols, "maest_cast_weights_multi: null pointer / n <= 0");
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_cast_weights_multi: bad dtype");
+    for (int base = 0; base < n; base += CAST_MAX_ITEMS) {
+        CastTable tab;
+        tab.n = n - base < CAST_MAX_ITEMS ? n - base : CAST_MAX_ITEMS;
+        int tiles = 0;
+        for (int i = 0; i < tab.n; ++i) {
+            const int k = base + i;
+            MAEST_REQUIRE(src[k] && (dst[k] || dst_t[k]) && rows[k] > 0 && cols[k] > 0,
+                          "maest_cast_weights_multi: bad item %d", k);
+            tab.src[i] = src[k]; tab.dst[i] = dst[k]; tab.dst_t[i] = dst_t[k];
+            tab.rows[i] = rows[k]; tab.cols[i] = cols[k];
+            tab.tile_begin[i] = tiles;
+            tiles += ((rows[k] + 63) / 64) * ((cols[k] + 63) / 64);
+        }
+        tab.tile_begin[tab.n] = tiles;
+        if (dtype == MAEST_BF16)
+            hipLaunchKernelGGL(cast_weights_multi_kernel<bf16_t>, dim3(tiles), dim3(256), 64 * 65 * 4,
+                               (hipStream_t)stream, tab);
+        else
+            hipLaunchKernelGGL(cast_weights_multi_kernel<float>, dim3(tiles), dim3(256), 64 * 65 * 4,
+                               (hipStream_t)stream, tab);
+    }
+    return check_launch("maest_cast_weights_multi");
 }
 
 extern "C" int maest_colsum(const void* src, int64_t ld, int rows, int cols, int dtype, float* out, void* stream) {

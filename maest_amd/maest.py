@@ -134,6 +134,27 @@ class _Weights:
         self._cache[key] = (ver, out)
         return out
 
+    def refresh(self, params, dtype, with_t: bool):
+        """Bring the plain (and, for training, transposed) operand copies of `params` up to date in one launch."""
+        if dtype == torch.float32 and not with_t:
+            return
+        stale = []
+        for p in params:
+            ver = p._version
+            for tr in ((False, True) if with_t else (False,)):
+                hit = self._cache.get((id(p), dtype, tr, 0))
+                if hit is None or hit[0] != ver or hit[1].device != p.device:
+                    stale.append(p)
+                    break
+        if not stale:
+            return
+        outs = ops.cast_weights_multi([p.detach() for p in stale], dtype, want=dtype != torch.float32, want_t=with_t)
+        for p, (o, ot) in zip(stale, outs):
+            if o is not None:
+                self._cache[(id(p), dtype, False, 0)] = (p._version, o)
+            if ot is not None:
+                self._cache[(id(p), dtype, True, 0)] = (p._version, ot)
+
     def clear(self):
         self._cache.clear()
 
@@ -179,6 +200,8 @@ class _Engine:
         N = 2 + P
         M = B * N
         ctx = {"B": B, "N": N, "toffset": toffset, "tok_ft": tok_ft, "dt": dt} if save else None
+        W.refresh([lin.weight for blk in m.blocks for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)],
+                  dt, with_t=save)
 
         cols = ops.patch_im2col(x3, tok_ft, dt, perm=perm, lam=lam)
         patches = ops.gemm_nt(cols, W.get(m.patch_embed.proj.weight, dt), m.patch_embed.proj.bias,

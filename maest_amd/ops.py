@@ -156,6 +156,32 @@ def cast_weights(src: torch.Tensor, dtype, want=True, want_t=False):
     return dst, dst_t
 
 
+def cast_weights_multi(srcs, dtype, want=True, want_t=False):
+    """Many fp32 parameters -> operand copies in ONE launch.  Returns a list of (copy | None, transposed | None)."""
+    _chk(*srcs)
+    n = len(srcs)
+    w2 = [s.reshape(s.shape[0], -1) for s in srcs]
+    dev = srcs[0].device
+    outs = []
+    for w in w2:
+        assert w.dtype == torch.float32 and w.is_contiguous()
+        r, c = w.shape
+        outs.append((torch.empty((r, c), dtype=dtype, device=dev) if want else None,
+                     torch.empty((c, r), dtype=dtype, device=dev) if want_t else None))
+    vp = ctypes.c_void_p * n
+    ip = ctypes.c_int * n
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    a_src = vp(*[w.data_ptr() for w in w2])
+    a_dst = vp(*[ptr(o[0]) for o in outs])
+    a_dt = vp(*[ptr(o[1]) for o in outs])
+    a_r = ip(*[w.shape[0] for w in w2])
+    a_c = ip(*[w.shape[1] for w in w2])
+    _timed_call("maest_cast_weights_multi", 0.0, n, ctypes.cast(a_src, ctypes.c_void_p), ctypes.cast(a_dst, ctypes.c_void_p),
+                ctypes.cast(a_dt, ctypes.c_void_p), ctypes.cast(a_r, ctypes.c_void_p), ctypes.cast(a_c, ctypes.c_void_p),
+                DT[dtype], _s(srcs[0]))
+    return outs
+
+
 def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype, save_stats=False):
     """x fp32 [rows, 768] -> y (out_dtype), optionally (mean, rstd)."""
     _chk(x, gamma, beta)

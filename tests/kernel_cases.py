@@ -111,6 +111,16 @@ def case_transpose(dev, dtype, rows, cols):
     d, dt_ = ops.cast_weights(w.to(dev), dtype, want=True, want_t=True)
     close(d, w.to(dtype), 0, 0, "cast")
     close(dt_, w.to(dtype).t(), 0, 0, "cast transposed")
+    # many parameters, one launch (ragged shapes, NULL outputs)
+    ws = [rnd((rows, cols), 60), rnd((cols, 33), 61), rnd((65, 64), 62)]
+    for want, want_t in ((True, True), (False, True), (True, False)):
+        outs = ops.cast_weights_multi([t.to(dev) for t in ws], dtype, want=want, want_t=want_t)
+        for t, (o, ot) in zip(ws, outs):
+            assert (o is None) == (not want) and (ot is None) == (not want_t)
+            if o is not None:
+                close(o, t.to(dtype), 0, 0, "cast multi")
+            if ot is not None:
+                close(ot, t.to(dtype).t(), 0, 0, "cast multi transposed")
 
 
 # --------------------------------------------------------------------------------------- LayerNorm

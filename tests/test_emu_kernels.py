@@ -23,9 +23,11 @@ def test_emu_gemm_ragged_n_scalar_epilogue(emu, dtype):
 
 @pytest.mark.parametrize("dtype", DT)
 def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype):
-    """M >= 512 and N % 256 == 0 route to gemm256.hip (LDS-DMA staging, source-side swizzle)."""
-    # 2 x 1 tiles, 6 K slices: the 4-deep ring wraps once
+    """M >= 512 and N % 128 == 0 route to gemm256.hip (LDS-DMA staging, source-side swizzle): the 256x128
+    kernel when N % 256 == 0, else the 256x128 two-workgroups-per-CU kernel."""
+    # 6 K slices: the 3- / 4-deep rings wrap
     K = 96 if dtype == torch.float32 else 192
+    KC.case_gemm(emu, dtype, 512, 128, K)
     KC.case_gemm(emu, dtype, 512, 256, K)
 
 
