@@ -304,19 +304,43 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(Gemm256Params p) {
     // Slice s is resident before anybody reads it: every wave ends LOAD(s-1) with vmcnt(8) (slices s+1, s+2
     // may still fly) and the barrier(s) in between publish that to the other group.  DMA of slice s+3
     // overwrites buffer (s-1)&3, whose last reader (B's LOAD(s-1)) finished before barrier 2s.
-    issue(0);
-    issue(1);
-    issue(2);
-    MAEST_WAIT_VMCNT(8);
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger (wave-uniform)
+    // DMA issue order.  One LDS-DMA instruction reads 16 rows x 64 B: HALF of each 128-byte line it touches;
+    // the other half belongs to the next K slice.  Issued three slices apart, the two halves were two separate
+    // L2 -> L1 line fills (the CU streams 64 KiB of lines per slice pair through a 32 KiB L1), and the measured
+    // L2 -> LDS rate (18 B/clk/CU) capped the loop at ~1250 TFLOP/s while the same loop without DMA ran at 2200.
+    // So slices are issued in PAIRS, row piece by row piece: (piece, slice s+2) immediately followed by
+    // (piece, slice s+3) -- the same sixteen lines back to back.  Even iterations issue 8 loads, odd ones none.
     chunk16 fa[2][4], fb[2][2];
-    for (int s = 0; s < nslices; ++s) {
+    auto issue_pair = [&](int s) {
+        issue_half(s, 0); issue_half(s + 1, 0);
+        issue_half(s, 1); issue_half(s + 1, 1);
+    };
+    auto compute = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#ifndef MAEST_ABLATE_NO_MFMA
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
+#else
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[0][mt][ks] += u2f(fa[ks][mt][0] ^ fb[ks][mt & 1][1]);
+#endif
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto load_frags = [&](int s) {
         const char* la = smem + (s & (G2_STAGES - 1)) * 2 * G2_TILE;
         const char* lb = la + G2_TILE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int kc = 2 * ks + h;
+#ifdef MAEST_ABLATE_NO_DSREAD
+            if (s > 0) continue;
+#endif
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
                 fa[ks][mt] = *reinterpret_cast<const chunk16*>(la + a_off[mt] + ((kc ^ a_swz[mt]) << 4));
@@ -324,18 +348,29 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(Gemm256Params p) {
             for (int nt = 0; nt < 2; ++nt)
                 fb[ks][nt] = *reinterpret_cast<const chunk16*>(lb + b_off[nt] + ((kc ^ b_swz[nt]) << 4));
         }
-        issue(s + 3);
-        __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): slice s+1 resident, fragments in registers
+    };
+    issue_pair(0);                   // slices 0, 1
+    MAEST_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger (wave-uniform)
+    // iteration s (even): slice s+1 (4 loads, issued at s-2 / in the prologue) may still fly; issue s+2, s+3;
+    //   vmcnt(8) retires slice s+1.   iteration s+1 (odd): s+2, s+3 fly; vmcnt(4) retires s+2.
+    for (int s = 0; s < nslices; s += 2) {
+        load_frags(s);
+#ifndef MAEST_ABLATE_NO_DMA
+        issue_pair(s + 2);
+#endif
+        __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
-        __builtin_amdgcn_s_setprio(0);
+        compute();
         __builtin_amdgcn_s_barrier();
+        if (s + 1 < nslices) {
+            load_frags(s + 1);
+            __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            compute();
+            __builtin_amdgcn_s_barrier();
+        }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();          // un-stagger
     MAEST_WAIT_VMCNT(0);   // drain the past-the-end loads before LDS is reused
@@ -354,6 +389,195 @@ static int launch256(Gemm256Params& p, hipStream_t stream) {
     }
     hipLaunchKernelGGL(gemm_nt256_kernel<T>, dim3(p.tiles_m * p.tiles_n), dim3(512), G2_SMEM, stream, p);
     return check_launch("maest_gemm_nt(256)");
+}
+
+// ================================================================================================
+// 256x256 tile, FULL-CACHE-LINE operand stages ("wide" kernel).
+// Measured on MI355X (scratch/probe/dma_bw.hip, ablate.sh): the vector-memory front end retires roughly one
+// cache-LINE request per ~3.7 clk per CU whatever part of the line is used, so the 64-byte row slices of the
+// kernel above move 16-18 B/clk/CU and their DMA -- not the MFMA pipe (that loop runs at 2200 TFLOP/s with the
+// DMA removed) -- caps it near 1250 TFLOP/s.  Whole 128-byte lines move 35 B/clk/CU.  Hence:
+//   * a K STAGE is 128 bytes per row (64 bf16 / 32 fp32); one LDS-DMA instruction fetches 8 rows x 128 B.
+//   * an operand UNIT is 256 rows x 128 B = 32 KiB; units alternate A_0 B_0 A_1 B_1 ... through a ring of
+//     NBUF = 5 buffers (all 160 KiB of LDS): when stage j has been read, its two buffers take B_{j+2} and
+//     A_{j+3}, so the DMA queue always holds 1.5 stages and only its last unit may still fly at a stage boundary
+//     (counted vmcnt(4)).
+//   * a stage is consumed in two k halves (LOAD 12 ds_read_b128 / COMPUTE 16 MFMAs each) with the same
+//     one-barrier stagger between the two wave groups as above.
+//   * bank swizzle for 128-byte rows: physical 16-byte chunk p of row r holds logical chunk p ^ ((r >> 1) & 7)
+//     (applied on the DMA source address); a 16-lane ds_read_b128 group then covers all 16 slots of 256 B.
+// ================================================================================================
+constexpr int W2_ROWB = 128;
+constexpr int W2_UNIT = 256 * W2_ROWB;      // 32768
+constexpr int W2_NBUF = 5;
+constexpr int W2_SMEM = W2_NBUF * W2_UNIT;  // 163840
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;          // 0..7
+    const int wm = wave >> 2, wn = wave & 3;
+    const int h = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = wg / p.tiles_n;
+    const int tile_n = wg - tile_m * p.tiles_n;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+
+    constexpr int ELT = (int)sizeof(T);
+    constexpr int KS = W2_ROWB / ELT;        // 64 / 32 elements per stage
+    const int nstages = p.K / KS;
+
+    // LDS-DMA map: instruction i (0..3) of this wave fills rows [(wave*4+i)*8, +8) of a unit; lane -> (row, chunk)
+    const char* a_src[4];
+    const char* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int csrc = (lane & 7) ^ ((r >> 1) & 7);        // source-side swizzle
+        int ra = m0 + r;
+        if (ra > p.M - 1) ra = p.M - 1;
+        int rb = n0 + r;
+        if (rb > p.N - 1) rb = p.N - 1;
+        a_src[i] = p.A + (int64_t)ra * p.lda * ELT + csrc * 16;
+        b_src[i] = p.B + (int64_t)rb * p.ldb * ELT + csrc * 16;
+    }
+    const int dma_off = wave * 4 * 1024;
+
+    f32x16_t acc[2][4];   // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // unit u = 2*stage + (0: A, 1: B) lives in buffer u % NBUF
+    auto issue_unit = [&](int stage, bool is_b, int buf) {
+        const int sc = stage < nstages ? stage : nstages - 1;   // past-the-end: re-load the last stage into a dead buffer
+        char* dst = smem + buf * W2_UNIT + dma_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* src = (is_b ? b_src[i] : a_src[i]) + (int64_t)sc * W2_ROWB;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        }
+    };
+
+    int a_off[4], b_off[2], a_swz[4], b_swz[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int row = wm * 128 + mt * 32 + (lane & 31);
+        a_off[mt] = row * W2_ROWB;
+        a_swz[mt] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int row = wn * 64 + nt * 32 + (lane & 31);
+        b_off[nt] = row * W2_ROWB;
+        b_swz[nt] = (row >> 1) & 7;
+    }
+
+    chunk16 fa[2][4], fb[2][2];
+    auto load_frags = [&](int abuf, int bbuf, int kh) {
+        const char* la = smem + abuf * W2_UNIT;
+        const char* lb = smem + bbuf * W2_UNIT;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kc = 4 * kh + 2 * ks + h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                fa[ks][mt] = *reinterpret_cast<const chunk16*>(la + a_off[mt] + ((kc ^ a_swz[mt]) << 4));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                fb[ks][nt] = *reinterpret_cast<const chunk16*>(lb + b_off[nt] + ((kc ^ b_swz[nt]) << 4));
+        }
+    };
+    auto compute = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto next = [](int b, int by) { b += by; return b >= W2_NBUF ? b - W2_NBUF : b; };
+
+    // prologue: units 0..4 = A_0 B_0 A_1 B_1 A_2
+    issue_unit(0, false, 0);
+    issue_unit(0, true, 1);
+    issue_unit(1, false, 2);
+    issue_unit(1, true, 3);
+    issue_unit(2, false, 4);
+    MAEST_WAIT_VMCNT(12);            // stage 0 landed (this wave's share)
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger (wave-uniform)
+    // Per stage j, group A (wm == 0) passes barriers  b1 b2 b3 b4  as
+    //   LOAD(j,0) b1 COMPUTE(j,0) b2 LOAD(j,1) b3 COMPUTE(j,1) [vmcnt] b4
+    // and group B, one barrier behind, as
+    //   b1 LOAD(j,0) b2 COMPUTE(j,0) b3 LOAD(j,1) [vmcnt] b4 COMPUTE(j,1).
+    // At b4 everybody has finished reading stage j's two buffers and has retired its own share of stage j+1.
+    // ALL DMA is issued from LOAD phases, behind the ds_reads: the memory front end accepts about one 8-line
+    // instruction per 30 clk per CU, and a wave stuck in that queue during COMPUTE would stall its MFMAs (measured:
+    // the same loop with the DMA removed runs 45 % faster, without the vmcnt waits no faster).  LOAD(j,0) refills
+    // A_{j-1}'s buffer with B_{j+1}, LOAD(j,1) refills B_{j-1}'s with A_{j+2}; only the latter may still fly at b4.
+    int abuf = 0, bbuf = 1;          // buffers of A_j, B_j
+    for (int j = 0; j < nstages; ++j) {
+        load_frags(abuf, bbuf, 0);
+#ifndef MAEST_ABLATE_NO_DMA
+        if (j > 0) issue_unit(j + 1, true, next(abuf, W2_NBUF - 2));
+#endif
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+        __builtin_amdgcn_s_barrier();
+        compute();
+        __builtin_amdgcn_s_barrier();
+        load_frags(abuf, bbuf, 1);
+#ifndef MAEST_ABLATE_NO_DMA
+        if (j > 0) issue_unit(j + 2, false, next(bbuf, W2_NBUF - 2));
+#endif
+        if (wm == 0) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();           // b3
+            compute();
+#ifndef MAEST_ABLATE_NO_VMWAIT
+            MAEST_WAIT_VMCNT(4);
+#endif
+            __builtin_amdgcn_s_barrier();           // b4
+        } else {
+#ifndef MAEST_ABLATE_NO_VMWAIT
+            __builtin_amdgcn_s_waitcnt(0x0074);     // vmcnt(4) lgkmcnt(0)
+#else
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+            __builtin_amdgcn_s_barrier();           // b4
+            compute();
+            __builtin_amdgcn_s_barrier();
+        }
+        abuf = next(abuf, 2);
+        bbuf = next(bbuf, 2);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();          // un-stagger
+    MAEST_WAIT_VMCNT(0);   // drain the past-the-end loads before LDS is reused
+    __syncthreads();       // LDS becomes the C staging area
+    if (p.out_dtype == MAEST_BF16) epilogue256<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+    else epilogue256<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+}
+
+template <typename T>
+static int launch256w(Gemm256Params& p, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256w_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, W2_SMEM);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_nt256w_kernel<T>, dim3(p.tiles_m * p.tiles_n), dim3(512), W2_SMEM, stream, p);
+    return check_launch("maest_gemm_nt(256w)");
 }
 
 // ================================================================================================
@@ -636,6 +860,12 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
     p.tiles_m = (M + 255) / 256;
     // Measured (scratch/gemm_ab.py): the one-workgroup-per-CU 256x256 kernel wins on every ViT shape but the
     // value-only GELU epilogue; the 256x128 two-per-CU kernel serves N % 256 != 0 and MAEST_GEMM_VARIANT=2.
+    // default: the full-cache-line kernel (fastest on every ViT shape, scratch/gemm_ab.py); MAEST_GEMM_VARIANT
+    // = 1 / 2 select the 64-byte-slice 256x256 kernel / the 256x128 two-per-CU kernel for A/B timing and tests
+    if (variant != 1 && variant != 2 && (N % 256) == 0 && (K * (in_dtype == MAEST_BF16 ? 2 : 4)) % W2_ROWB == 0) {
+        p.tiles_n = N / 256;
+        return in_dtype == MAEST_BF16 ? launch256w<bf16_t>(p, stream) : launch256w<float>(p, stream);
+    }
     if (variant != 2 && (N % 256) == 0) {
         p.tiles_n = N / 256;
         return in_dtype == MAEST_BF16 ? launch256<bf16_t>(p, stream) : launch256<float>(p, stream);

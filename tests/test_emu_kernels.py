@@ -22,13 +22,20 @@ def test_emu_gemm_ragged_n_scalar_epilogue(emu, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype):
-    """M >= 512 and N % 128 == 0 route to gemm256.hip (LDS-DMA staging, source-side swizzle): the 256x128
-    kernel when N % 256 == 0, else the 256x128 two-workgroups-per-CU kernel."""
+def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype, monkeypatch):
+    """The 64-byte-slice kernels of gemm256.hip: 256x128 two-per-CU (N % 256 != 0) and 256x256 (variant 1)."""
     # 6 K slices: the 3- / 4-deep rings wrap
     K = 96 if dtype == torch.float32 else 192
     KC.case_gemm(emu, dtype, 512, 128, K)
+    monkeypatch.setenv("MAEST_GEMM_VARIANT", "1")
     KC.case_gemm(emu, dtype, 512, 256, K)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_emu_gemm_256_tile_full_line_stages(emu, dtype):
+    """gemm_nt256w_kernel (the default for M >= 512, N % 256 == 0): 128-byte K stages through a 5-buffer unit
+    ring (7 stages: the ring wraps)."""
+    KC.case_gemm(emu, dtype, 512, 256, 224 if dtype == torch.float32 else 448)
 
 
 @pytest.mark.parametrize("dtype", DT)
