@@ -496,14 +496,28 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
                 fb[ks][nt] = *reinterpret_cast<const chunk16*>(lb + b_off[nt] + ((kc ^ b_swz[nt]) << 4));
         }
     };
-    auto compute = [&]() {
+    // COMPUTE phase with one operand unit's DMA (4 instructions of this wave) spread between the 16 MFMAs: the
+    // memory front end accepts about one 8-line instruction per 30 clk per CU, so the four waves of a group
+    // feed it at exactly its rate, never in a burst, and a wave is never parked in the queue while it owes MFMAs.
+    auto compute = [&](bool dma, int stage, bool is_b, int buf) {
+        const int sc = stage < nstages ? stage : nstages - 1;   // past-the-end: re-load the last stage into a dead buffer
+        char* dst = smem + buf * W2_UNIT + dma_off;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
+#ifndef MAEST_ABLATE_NO_DMA
+                if (dma) {
+                    const int i = ks * 2 + nt;
+                    const char* src = (is_b ? b_src[i] : a_src[i]) + (int64_t)sc * W2_ROWB;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                }
+#endif
+            }
         __builtin_amdgcn_s_setprio(0);
     };
     auto next = [](int b, int by) { b += by; return b >= W2_NBUF ? b - W2_NBUF : b; };
@@ -522,28 +536,24 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     // and group B, one barrier behind, as
     //   b1 LOAD(j,0) b2 COMPUTE(j,0) b3 LOAD(j,1) [vmcnt] b4 COMPUTE(j,1).
     // At b4 everybody has finished reading stage j's two buffers and has retired its own share of stage j+1.
-    // ALL DMA is issued from LOAD phases, behind the ds_reads: the memory front end accepts about one 8-line
-    // instruction per 30 clk per CU, and a wave stuck in that queue during COMPUTE would stall its MFMAs (measured:
-    // the same loop with the DMA removed runs 45 % faster, without the vmcnt waits no faster).  LOAD(j,0) refills
-    // A_{j-1}'s buffer with B_{j+1}, LOAD(j,1) refills B_{j-1}'s with A_{j+2}; only the latter may still fly at b4.
+    // Refills ride inside COMPUTE phases (see compute()):
+    //   group A: COMPUTE(j,0) B_{j+1} -> A_{j-1}'s buffer,  COMPUTE(j,1) A_{j+2} -> B_{j-1}'s buffer
+    //   group B: COMPUTE(j,0) A_{j+2} -> B_{j-1}'s buffer,  COMPUTE(j,1) B_{j+2} -> A_j's buffer (free since b4(j))
+    // so that every load has at least three phases to land; only the A unit issued last may still fly at b4.
     int abuf = 0, bbuf = 1;          // buffers of A_j, B_j
     for (int j = 0; j < nstages; ++j) {
+        const int abuf_prev = next(abuf, W2_NBUF - 2), bbuf_prev = next(bbuf, W2_NBUF - 2);
         load_frags(abuf, bbuf, 0);
-#ifndef MAEST_ABLATE_NO_DMA
-        if (j > 0) issue_unit(j + 1, true, next(abuf, W2_NBUF - 2));
-#endif
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
         __builtin_amdgcn_s_barrier();
-        compute();
+        if (wm == 0) compute(j > 0, j + 1, true, abuf_prev);
+        else compute(j > 0, j + 2, false, bbuf_prev);
         __builtin_amdgcn_s_barrier();
         load_frags(abuf, bbuf, 1);
-#ifndef MAEST_ABLATE_NO_DMA
-        if (j > 0) issue_unit(j + 2, false, next(bbuf, W2_NBUF - 2));
-#endif
         if (wm == 0) {
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();           // b3
-            compute();
+            compute(j > 0, j + 2, false, bbuf_prev);
 #ifndef MAEST_ABLATE_NO_VMWAIT
             MAEST_WAIT_VMCNT(4);
 #endif
@@ -555,7 +565,7 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
             __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
             __builtin_amdgcn_s_barrier();           // b4
-            compute();
+            compute(true, j + 2, true, abuf);
             __builtin_amdgcn_s_barrier();
         }
         abuf = next(abuf, 2);
@@ -986,17 +996,21 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     const bool do_colsum = (p.colsum != nullptr) && (tile_j == 0) && (wn == 0);   // wave-uniform
 
-    auto issue = [&](int s) {
+    // piece q (0..3) of the 4 LDS-DMA instructions this wave owes to slice s: A0 B0 A1 B1
+    auto issue_piece = [&](int s, int q) {
         const int sc = s < nslices ? s : nslices - 1;
         char* la = smem + (s & (G2_STAGES - 1)) * 2 * G2_TILE + dma_off;
-        char* lb = la + G2_TILE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        const int i = q >> 1;
+        if ((q & 1) == 0)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + sc * a_step),
                                              (__attribute__((address_space(3))) void*)(la + i * 1024), 16, 0, 0);
+        else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + sc * b_step),
-                                             (__attribute__((address_space(3))) void*)(lb + i * 1024), 16, 0, 0);
-        }
+                                             (__attribute__((address_space(3))) void*)(la + G2_TILE + i * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_piece(s, q);
     };
 
     if (nslices > 0) {
@@ -1018,7 +1032,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) fb[ks][b] = frag_tn256<T>(lb, ks, wn * 64 + b * 32, lane);
         }
-        issue(s + 3);
+        issue(s + 3);   // (in the LOAD phase: spread between the MFMAs of COMPUTE it measured 9 % slower here)
         __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
