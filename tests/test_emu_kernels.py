@@ -39,9 +39,10 @@ def test_emu_gemm_256_tile_full_line_stages(emu, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_emu_gemm_tn_256_tile_lds_dma_kernel(emu, dtype):
+def test_emu_gemm_tn_256_tile_lds_dma_kernel(emu, dtype, monkeypatch):
     """M, N multiples of 256 and K a multiple of the slice route to gemm256.hip:gemm_tn256_kernel."""
-    KC.case_gemm_tn(emu, dtype, 288 if dtype == torch.bfloat16 else 144, 256, 256)
+    monkeypatch.setenv("MAEST_GEMM_VARIANT", "4")   # take the 256-tile kernel although there are only 2 tiles
+    KC.case_gemm_tn(emu, dtype, 288 if dtype == torch.bfloat16 else 144, 256, 512)
 
 
 @pytest.mark.parametrize("dtype", DT)

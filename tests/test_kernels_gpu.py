@@ -17,7 +17,7 @@ def test_gemm(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("shape", [(1121, 768, 3072), (2300, 2304, 768), (64, 400, 768), (7, 519 + 57, 768), (5184, 768, 256), (4640, 768, 3072), (2320, 2304, 768)])
+@pytest.mark.parametrize("shape", [(1121, 768, 3072), (2300, 2304, 768), (64, 400, 768), (7, 519 + 57, 768), (5184, 768, 256), (4640, 768, 3072), (2320, 2304, 768), (2304, 768, 768)])
 def test_gemm_tn(dtype, shape):
     K, M, N = shape
     if M == 519 + 57:
