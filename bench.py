@@ -40,12 +40,31 @@ def flops_per_clip_fwd(N, Tk, C=400):
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE cannot be collected by bench.py on itself); None when the file is absent."""
-    path = os.path.join(REPO, "profiles", "r01c_pmc_traffic.json")
+    path = os.path.join(REPO, "profiles", "r01d_pmc_traffic.json")
     try:
         with open(path) as f:
             return json.load(f)["traffic_bytes_per_launch"]
     except Exception:
         return None
+
+
+def cpu_baseline_infer(batch, T, steps=2):
+    """Oracle eval forward on the host cores (B = 8, N = 560)."""
+    from oracle import maest_oracle as O
+    sd = O.make_state_dict(625, seed=1234)
+    rng = np.random.Generator(np.random.PCG64(3))
+    x = torch.from_numpy(rng.standard_normal((batch, 96, T), dtype=np.float32))
+    times = []
+    with torch.no_grad():
+        for it in range(steps + 1):
+            t0 = time.perf_counter()
+            O.forward(x, sd, (96, 625), melspectrogram_input=True)
+            if it > 0:
+                times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    return {"value": round(batch / t, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle eval forward (fp32) batch={batch} T={T}; median of {steps} passes after 1 warm-up, "
+                      f"{t:.2f} s/pass"}
 
 
 def cpu_baseline(batch, T, patchout, steps=2):
@@ -206,7 +225,7 @@ def main():
             g = summ.get("maest_gemm_nt")
             if g and g["ms"] > 0:
                 ach = g["work"] / (g["ms"] * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": ("maest_gemm_nt (gemm_nt256_kernel<bf16> + gemm_nt_kernel<bf16> for small shapes)"
+                out["roofline"] = {"bound": "mfma", "kernel": ("maest_gemm_nt (gemm_nt256w_kernel<bf16>; gemm_nt_kernel<bf16> for the 2 small head GEMMs)"
                                               if args.precision == "bf16" else "maest_gemm_nt (fp32 MFMA)"),
                                    "achieved": round(ach, 1),
                                    "peak": PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
@@ -239,7 +258,8 @@ def main():
                                         "mfma_frac": round(set_flops / set_ms / 1e9 / PEAK_BF16_TFLOPS, 4)}
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_batch, T, args.patchout if train else 0)
+                out["cpu_baseline"] = (cpu_baseline(args.cpu_batch, T, args.patchout) if train
+                                       else cpu_baseline_infer(args.cpu_batch, T))
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
