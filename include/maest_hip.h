@@ -178,6 +178,18 @@ int maest_logmel(const float* wave, int B, int S, const float* window, const flo
 /* ---- optimizer-side helper: scale a flat fp32 gradient bucket (after the RCCL all-reduce) */
 int maest_scale_f32(float* x, int64_t n, float alpha, void* stream);
 
+/* ---- on-disk mel chunks -> network input (the step before the hot path) ------------
+ * Replaces DiscogsDataset.load_melspectrogram (discogs/dataset.py:69-140) + norm_func
+ * (discogs/datamodule.py:126-136) for a whole batch.
+ * frames: raw float16 rows [sum_b frames_read[b], n_bands] as stored on disk (helpers/
+ * melspectrogram_extractor.py:44-48), clip b starting at row row_start[b] (device arrays).
+ * out: fp32 [B, n_bands, T]; clip b = its frames_read[b] <= T frames, zero padded to T, the padding
+ * centred by a roll of (T - frames_read) / 2, transposed; with normalize != 0 then (x - mean) / div with both
+ * constants and both results rounded to float16 exactly as numpy evaluates the reference expression. */
+int maest_melfile_assemble(const uint16_t* frames, const int64_t* row_start, const int32_t* frames_read,
+                           int B, int n_bands, int T, int normalize, float norm_mean, float norm_div,
+                           float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,6 +153,54 @@ __global__ __launch_bounds__(256) void spec_mask_kernel(float* __restrict__ x, i
     }
 }
 
+// ---- on-disk mel chunks -> network input.
+// Reference: DiscogsDataset.load_melspectrogram (discogs/dataset.py:69-140: raw float16 [frames, 96] rows,
+// zero padding centred by np.roll(pad // 2), transpose to [96, T]) followed by the datamodule's norm_func
+// (discogs/datamodule.py:126-136: (x - mean) / (2 std), evaluated by numpy IN float16: both constants are
+// rounded to half, and so is each of the two results).  One workgroup = 64 frames x 96 bands of one clip,
+// transposed through LDS so that the reads are whole 192-byte frame rows and the writes 256-byte time runs.
+__global__ __launch_bounds__(256) void melfile_assemble_kernel(const uint16_t* __restrict__ frames,
+                                                               const int64_t* __restrict__ row_start,
+                                                               const int32_t* __restrict__ frames_read, int n_bands,
+                                                               int T, int normalize, float norm_mean, float norm_div,
+                                                               float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float (*tile)[97] = reinterpret_cast<float (*)[97]>(smem);   // [64][97]
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    const int nf = frames_read[b];
+    const int shift = nf < T ? (T - nf) / 2 : 0;                 // np.roll(padded, pad // 2, axis=0)
+    const _Float16 mean_h = (_Float16)norm_mean, div_h = (_Float16)norm_div;
+    const uint16_t* src = frames + row_start[b] * n_bands;
+    for (int i = threadIdx.x; i < 64 * n_bands; i += 256) {
+        const int tl = i / n_bands, f = i - tl * n_bands;
+        const int t = t0 + tl;
+        float v = 0.0f;
+        if (t < T) {
+            int sidx = t - shift;
+            if (sidx < 0) sidx += T;                             // rolled-around tail of the zero padding
+            if (sidx < nf) {
+                const uint16_t raw = src[(int64_t)sidx * n_bands + f];
+                _Float16 h = __builtin_bit_cast(_Float16, raw);
+                if (normalize) {
+                    h = (_Float16)((float)h - (float)mean_h);    // half - half, rounded to half
+                    h = (_Float16)((float)h / (float)div_h);     // half / half, rounded to half
+                }
+                v = (float)h;
+            } else if (normalize) {
+                _Float16 h = (_Float16)(0.0f - (float)mean_h);   // the zero padding is normalised too
+                h = (_Float16)((float)h / (float)div_h);
+                v = (float)h;
+            }
+        }
+        tile[tl][f] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_bands * 64; i += 256) {
+        const int f = i >> 6, tl = i & 63;
+        if (t0 + tl < T) out[((int64_t)b * n_bands + f) * T + t0 + tl] = tile[tl][f];
+    }
+}
+
 }  // namespace maest
 
 using namespace maest;
@@ -204,4 +252,15 @@ extern "C" int maest_spec_mask(float* x, int B, int F, int T, const int32_t* t_s
     hipLaunchKernelGGL(spec_mask_kernel, dim3(B, n_t + n_f), dim3(256), 0, (hipStream_t)stream, x, F, T, t_stripes,
                        n_t, f_stripes, n_f);
     return check_launch("maest_spec_mask");
+}
+
+extern "C" int maest_melfile_assemble(const uint16_t* frames, const int64_t* row_start, const int32_t* frames_read,
+                                      int B, int n_bands, int T, int normalize, float norm_mean, float norm_div,
+                                      float* out, void* stream) {
+    MAEST_REQUIRE(frames && row_start && frames_read && out, "maest_melfile_assemble: null pointer");
+    MAEST_REQUIRE(B > 0 && T > 0 && n_bands > 0 && n_bands <= 96, "maest_melfile_assemble: bad shape B=%d T=%d bands=%d",
+                  B, T, n_bands);
+    hipLaunchKernelGGL(melfile_assemble_kernel, dim3((T + 63) / 64, B), dim3(256), 64 * 97 * 4, (hipStream_t)stream, frames,
+                       row_start, frames_read, n_bands, T, normalize, norm_mean, norm_div, out);
+    return check_launch("maest_melfile_assemble");
 }

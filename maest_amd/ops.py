@@ -5,6 +5,7 @@ from __future__ import annotations
 import ctypes
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -322,6 +323,25 @@ def spec_mask_(x: torch.Tensor, t_stripes=None, f_stripes=None):
     n_f = 0 if f_stripes is None else f_stripes.shape[1]
     call("maest_spec_mask", _p(x), B, F, T, _p(t_stripes), n_t, _p(f_stripes), n_f, _s(x))
     return x
+
+
+def melfile_assemble(frames: torch.Tensor, row_start: torch.Tensor, frames_read: torch.Tensor, T: int,
+                     normalize: bool = True, norm_mean: float = 2.06755686098554,
+                     norm_std: float = 1.268292820667291) -> torch.Tensor:
+    """Raw on-disk mel rows (float16 [rows, n_bands], device) -> network input fp32 [B, n_bands, T]
+    (pad + centre-roll + transpose + the datamodule's float16 normalisation; csrc/embed.hip)."""
+    _chk(frames, row_start, frames_read)
+    assert frames.dtype == torch.float16 and frames.dim() == 2 and frames.is_contiguous()
+    assert row_start.dtype == torch.int64 and frames_read.dtype == torch.int32
+    B = int(frames_read.numel())
+    n_bands = int(frames.shape[1])
+    out = torch.empty((B, n_bands, T), dtype=torch.float32, device=frames.device)
+    # numpy evaluates (x - mean) / (std * 2) in float16 with both python scalars cast to float16 first
+    mean_h = float(np.float16(norm_mean))
+    div_h = float(np.float16(norm_std * 2))
+    call("maest_melfile_assemble", _p(frames), _p(row_start), _p(frames_read), B, n_bands, T, 1 if normalize else 0,
+         mean_h, div_h, _p(out), _s(frames))
+    return out
 
 
 def logmel(wave: torch.Tensor, consts) -> torch.Tensor:

@@ -318,3 +318,32 @@ def case_mel(dev, B, S, seed=80):
     close(got, want, 1e-3, 1e-3, "logmel")
     err = (got.cpu() - want).abs().max().item()
     assert err < 2e-4, f"logmel max abs err {err}"
+
+
+# ------------------------------------------------------------------ on-disk mel chunks -> input
+def case_melfile(dev, tmp_path, size=50, counts=(80, 30, 31, 50, 1, 45), offsets=(13, 0, 0, 0, 0, 20), seed=90):
+    """MelFileReader (host plan + one device kernel) against the oracle restatement of the reference reader,
+    bit-exact (float16 arithmetic reproduced on the device): plain slice, short files (even / odd padding),
+    exact length, a single frame, and an offset that runs past the end of the file."""
+    from maest_amd.melfile import MelFileReader
+    from oracle import melfile_oracle as MO
+    rd = MelFileReader(tmp_path, clip_length=1, sample_rate=size, hop_size=1)     # melspectrogram_size = size
+    assert rd.melspectrogram_size == size
+    rng = np.random.Generator(np.random.PCG64(seed))
+    names = []
+    for i, n in enumerate(counts):
+        fr = (rng.random((n, 96), dtype=np.float32) * 5.0).astype("float16")
+        name = f"clip{i}.mel"
+        fr.tofile(tmp_path / name)
+        names.append(name)
+    for normalize in (True, False):
+        got = rd.load_batch(names, dev, offsets=list(offsets), normalize=normalize)
+        assert got.shape == (len(counts), 1, 96, size) and got.dtype == torch.float32
+        for i, name in enumerate(names):
+            want = MO.load_melspectrogram(tmp_path / name, size, 96, offsets[i])
+            if normalize:
+                want = MO.norm_func(want)
+            assert want.dtype == np.float16
+            w32 = torch.from_numpy(want.astype(np.float32))
+            assert torch.equal(got[i].cpu(), w32), (
+                f"melfile clip {i} normalize={normalize}: max diff {(got[i].cpu() - w32).abs().max().item()}")

@@ -93,3 +93,7 @@ def test_emu_spec_mask(emu):
 
 def test_emu_mel(emu):
     KC.case_mel(emu, 1, 2560)
+
+
+def test_emu_melfile(emu, tmp_path):
+    KC.case_melfile(emu, tmp_path)

@@ -1,4 +1,5 @@
 """GPU (`-m gpu`): every C-ABI kernel vs the oracle on a real MI355X, at the shapes the model uses."""
+import numpy as np
 import pytest
 import torch
 
@@ -76,3 +77,12 @@ def test_mel():
     KC.case_mel(DEV, 2, 160000)
     KC.case_mel(DEV, 1, 480000, seed=81)
     KC.case_mel(DEV, 1, 5000, seed=82)
+
+
+def test_melfile(tmp_path):
+    KC.case_melfile(DEV, tmp_path)
+    # full-size clips (10 s = 625 frames), batch 64, ragged lengths and offsets
+    rng = np.random.Generator(np.random.PCG64(5))
+    counts = [int(c) for c in rng.integers(1, 1400, 64)]
+    offsets = [int(rng.integers(0, max(c - 300, 1))) for c in counts]
+    KC.case_melfile(DEV, tmp_path, size=625, counts=counts, offsets=offsets, seed=91)
