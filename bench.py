@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-batch", type=int, default=8, help="clips per oracle step of the CPU baseline (SURVEY 8d: B = 8)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--serial-kernels", action="store_true",
                     help="disable the side-stream overlap of weight-gradient GEMMs (for kernel profiling)")

@@ -59,8 +59,12 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
     }
 }
 
-// x0[b, n, c4]: one thread per 4 channels of one token
-__global__ __launch_bounds__(256) void token_assemble_kernel(const float* __restrict__ patches,
+// x0[b, n, :]: a workgroup owns ONE token position n and a chunk of the batch.  The positional terms of that
+// position (column tcol of time_pos [768, Tt], column f of freq_pos [768, Fg]: strided gathers) are fetched
+// once per workgroup; the batch loop then streams float4 rows (the gather per element had made this kernel
+// 4x slower than its bytes).  192 threads, 4 channels each.
+constexpr int TA_BCHUNK = 32;
+__global__ __launch_bounds__(192) void token_assemble_kernel(const float* __restrict__ patches,
                                                              const float* __restrict__ cls_token,
                                                              const float* __restrict__ dist_token,
                                                              const float* __restrict__ new_pos,
@@ -69,31 +73,38 @@ __global__ __launch_bounds__(256) void token_assemble_kernel(const float* __rest
                                                              const int32_t* __restrict__ tok_ft, int B, int Fg, int P,
                                                              float* __restrict__ x0) {
     const int Ntok = 2 + P;
-    const int gid = blockIdx.x * 256 + threadIdx.x;      // grid: (tokens x channel quads, batch)
-    if (gid >= Ntok * (PE_D / 4)) return;
-    const int n = gid / (PE_D / 4);
-    const int c = (gid - n * (PE_D / 4)) * 4;
-    const int b = blockIdx.y;
-    const int64_t tok = (int64_t)b * Ntok + n;
-    float o[4];
-    if (n == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = cls_token[c + e] + new_pos[c + e];
-    } else if (n == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = dist_token[c + e] + new_pos[PE_D + c + e];
-    } else {
-        const int j = n - 2;
-        const int f = tok_ft[2 * j];
-        const int tcol = toffset + tok_ft[2 * j + 1];
-        const float4 p = *reinterpret_cast<const float4*>(patches + ((int64_t)b * P + j) * PE_D + c);
-        const float pv[4] = {p.x, p.y, p.z, p.w};
-        // reference order: (conv + time_pos) + freq_pos   (maest.py:670,675)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            o[e] = (pv[e] + time_pos[(int64_t)(c + e) * Tt + tcol]) + freq_pos[(int64_t)(c + e) * Fg + f];
+    const int n = blockIdx.x;
+    const int c = threadIdx.x * 4;
+    const int b0 = blockIdx.y * TA_BCHUNK;
+    const int b1 = b0 + TA_BCHUNK < B ? b0 + TA_BCHUNK : B;
+    if (n < 2) {
+        const float* tok = n == 0 ? cls_token : dist_token;
+        float4 o;
+        o.x = tok[c] + new_pos[n * PE_D + c];
+        o.y = tok[c + 1] + new_pos[n * PE_D + c + 1];
+        o.z = tok[c + 2] + new_pos[n * PE_D + c + 2];
+        o.w = tok[c + 3] + new_pos[n * PE_D + c + 3];
+        for (int b = b0; b < b1; ++b) *reinterpret_cast<float4*>(x0 + ((int64_t)b * Ntok + n) * PE_D + c) = o;
+        return;
     }
-    *reinterpret_cast<float4*>(x0 + tok * PE_D + c) = make_float4(o[0], o[1], o[2], o[3]);
+    const int j = n - 2;
+    const int f = tok_ft[2 * j];
+    const int tcol = toffset + tok_ft[2 * j + 1];
+    float tp[4], fp[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        tp[e] = time_pos[(int64_t)(c + e) * Tt + tcol];
+        fp[e] = freq_pos[(int64_t)(c + e) * Fg + f];
+    }
+    for (int b = b0; b < b1; ++b) {
+        const float4 p = *reinterpret_cast<const float4*>(patches + ((int64_t)b * P + j) * PE_D + c);
+        float4 o;   // reference order: (conv + time_pos) + freq_pos   (maest.py:670,675)
+        o.x = (p.x + tp[0]) + fp[0];
+        o.y = (p.y + tp[1]) + fp[1];
+        o.z = (p.z + tp[2]) + fp[2];
+        o.w = (p.w + tp[3]) + fp[3];
+        *reinterpret_cast<float4*>(x0 + ((int64_t)b * Ntok + n) * PE_D + c) = o;
+    }
 }
 
 // grid (Ntok, 3): thread = channel; loops over the batch (coalesced over channels)
@@ -224,8 +235,7 @@ extern "C" int maest_token_assemble(const float* patches, const float* cls_token
     MAEST_REQUIRE(patches && cls_token && dist_token && new_pos && freq_pos && time_pos && x0 && tok_ft,
                   "maest_token_assemble: null pointer");
     MAEST_REQUIRE(B > 0 && P > 0 && Fg > 0 && Tt > 0 && toffset >= 0, "maest_token_assemble: bad shape");
-    const int per_clip = (2 + P) * (PE_D / 4);
-    hipLaunchKernelGGL(token_assemble_kernel, dim3((per_clip + 255) / 256, B), dim3(256), 0,
+    hipLaunchKernelGGL(token_assemble_kernel, dim3(2 + P, (B + TA_BCHUNK - 1) / TA_BCHUNK), dim3(PE_D / 4), 0,
                        (hipStream_t)stream, patches, cls_token, dist_token, new_pos, freq_pos, time_pos, Tt, toffset,
                        tok_ft, B, Fg, P, x0);
     return check_launch("maest_token_assemble");

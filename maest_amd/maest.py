@@ -184,6 +184,16 @@ class _Engine:
         self.overlap_wgrad = True
         self._side = {}
 
+    def _grad_layout(self):
+        """{parameter name: (offset, numel)} into a flat fp32 gradient buffer, 256-byte aligned."""
+        if getattr(self, "_layout", None) is None:
+            off, lay = 0, {}
+            for n, p in self.m.named_parameters():
+                lay[n] = (off, p.numel())
+                off += (p.numel() + 63) // 64 * 64
+            self._layout = (lay, off)
+        return self._layout
+
     def _side_stream(self, dev):
         key = str(dev)
         if key not in self._side:
@@ -280,10 +290,20 @@ class _Engine:
         dev = ctx["x_final"].device
         G = {}
 
+        # without a sink, all parameter gradients of this pass are views of ONE zero-filled flat buffer (one fill
+        # kernel instead of ~160; the wgrad kernels accumulate into it with split-K atomics)
+        flat, layout = None, None
+        if sink is None:
+            layout, total = self._grad_layout()
+            flat = torch.zeros(total, dtype=torch.float32, device=dev)
+
         def buf(name, *shape):
             v = sink.grad_buffer(name) if sink is not None else None
             if v is not None:
                 return v.view(*shape)          # zeroed by sink.reset()
+            if layout is not None and name in layout:
+                off, n = layout[name]
+                return flat[off:off + n].view(*shape)
             return torch.zeros(*shape, dtype=torch.float32, device=dev)
 
         # Weight / bias gradients are off the critical path (nothing in backward consumes them), so they run on
