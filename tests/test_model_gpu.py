@@ -305,3 +305,26 @@ def test_grad_sink_path_equals_autograd_path():
         assert p.grad.data_ptr() == red.grad_buffer(n).data_ptr()
         d = (p.grad - ref[n]).abs().max().item()
         assert d <= 1e-5 * max(ref[n].abs().max().item(), 1e-6) + 1e-7, (n, d)   # atomics: order-only noise
+
+
+def test_hip_graph_captured_inference_is_bit_identical():
+    """north_star configs[4]: the eval forward replayed from a HIP graph equals the eager launches bit for bit,
+    for successive inputs, and is re-captured after a parameter update."""
+    net = build("discogs-maest-10s-pw-129e", 625, precision="bf16").eval()
+    xs = [randn((4, 96, 626), 300 + i).to(DEV) for i in range(4)]
+    with torch.no_grad():
+        eager = [tuple(o.clone() for o in net(x)) for x in xs]
+        net.enable_hip_graph()
+        for rep in range(2):
+            for x, want in zip(xs, eager):
+                got = net(x)
+                assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        assert any(st["graph"] is not None for st in net._graphs.values()), "no graph was captured"
+        with torch.no_grad():
+            net.head[1].bias.add_(1.0)                   # parameter update -> stale graph must not be replayed
+        ref = net.enable_hip_graph(False)(xs[0])
+        net.enable_hip_graph()
+        for _ in range(3):
+            got = net(xs[0])
+            assert torch.equal(got[0], ref[0])
+        assert torch.allclose(got[0], eager[0][0] + 1.0, atol=1e-5)
