@@ -391,6 +391,189 @@ static int launch256(Gemm256Params& p, hipStream_t stream) {
     return check_launch("maest_gemm_nt(256)");
 }
 
+// ---- C-tile epilogue shared by the full-line 256x256 kernel (TNC = 256 columns, 512 threads, 160 KiB of LDS) and the
+// 256x128 kernel (TNC = 128, 256 threads, 72 KiB): the whole tile -- or the largest row group that fits, with two
+// regions for the GELU + GELU' pair -- is staged in ONE pass by ALL waves at once (the older epilogue256 staged one
+// wave group at a time in 128 KiB), then drained with 16-byte non-temporal stores.
+template <int OSZ, int TNC>
+struct EpiT {
+    static constexpr int PITCH = TNC * OSZ + 16;      // 272 / 528 (TNC 128), 528 / 1040 (TNC 256)
+    static constexpr int CPR = TNC * OSZ / 16;        // 16-byte chunks per row
+    static constexpr int EPC = 16 / OSZ;
+};
+
+// one 32-row m-tile of this wave's block -> LDS rows [lrow0, lrow0 + 32); GMODE 0 none, 1 GELU value, 3 value + GELU'
+template <int OSZ, int GMODE, bool EXACT, int TNC>
+__device__ __forceinline__ void stageT(char* smem, int region, const f32x16_t& a0, const f32x16_t& a1,
+                                       const float* bias, int n0, int N, int lrow0, int wn, int lane) {
+    using E = EpiT<OSZ, TNC>;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = wn * 64 + nt * 32 + 8 * g + 4 * h;
+            f32x4_t b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (bias != nullptr && n0 + nl < N) b4 = *reinterpret_cast<const f32x4_t*>(bias + n0 + nl);
+            float v[4], d[4];
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const f32x2_t xv = {(nt == 0 ? a0[4 * g + e] : a1[4 * g + e]) + b4[e],
+                                    (nt == 0 ? a0[4 * g + e + 1] : a1[4 * g + e + 1]) + b4[e + 1]};
+                f32x2_t gv = xv, dv = {0.0f, 0.0f};
+                if (GMODE != 0) gelu_pair2<EXACT>(xv, gv, dv);
+                v[e] = gv[0]; v[e + 1] = gv[1];
+                d[e] = dv[0]; d[e + 1] = dv[1];
+            }
+            char* dst = smem + (lrow0 + (lane & 31)) * E::PITCH + nl * OSZ;
+            if (OSZ == 4) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                if (GMODE == 3) *reinterpret_cast<float4*>(dst + region) = make_float4(d[0], d[1], d[2], d[3]);
+            } else {
+                chunk8 o;
+                o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
+                *reinterpret_cast<chunk8*>(dst) = o;
+                if (GMODE == 3) {
+                    chunk8 q;
+                    q[0] = pack_bf2(d[0], d[1]); q[1] = pack_bf2(d[2], d[3]);
+                    *reinterpret_cast<chunk8*>(dst + region) = q;
+                }
+            }
+        }
+}
+
+template <int OSZ, int MODE, int TNC, int NTH>
+__device__ __forceinline__ void drainT(const char* smem, int rows, void* dst, int64_t ld, const void* aux,
+                                       int64_t ld_aux, int mbase, int n0, int M, int N, int tid) {
+    using E = EpiT<OSZ, TNC>;
+#pragma unroll 4
+    for (int c = tid; c < rows * E::CPR; c += NTH) {
+        const int row = c / E::CPR, cc = c - row * E::CPR;
+        const int gm = mbase + row, gn = n0 + cc * E::EPC;
+        if (gm >= M || gn >= N) continue;
+        chunk16 v = *reinterpret_cast<const chunk16*>(smem + row * E::PITCH + cc * 16);
+        if (MODE == 1) {
+            const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(aux) + (int64_t)gm * ld_aux + gn);
+            v[0] = f2u(u2f(v[0]) + r.x); v[1] = f2u(u2f(v[1]) + r.y);
+            v[2] = f2u(u2f(v[2]) + r.z); v[3] = f2u(u2f(v[3]) + r.w);
+        } else if (MODE == 2) {
+            if (OSZ == 4) {
+                const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(aux) + (int64_t)gm * ld_aux + gn);
+                v[0] = f2u(u2f(v[0]) * r.x); v[1] = f2u(u2f(v[1]) * r.y);
+                v[2] = f2u(u2f(v[2]) * r.z); v[3] = f2u(u2f(v[3]) * r.w);
+            } else {
+                const chunk16 r = *reinterpret_cast<const chunk16*>(reinterpret_cast<const bf16_t*>(aux) + (int64_t)gm * ld_aux + gn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t vw = v[e], rw = r[e];
+                    const float lo = u2f(vw << 16) * u2f(rw << 16);
+                    const float hi = u2f(vw & 0xffff0000u) * u2f(rw & 0xffff0000u);
+                    v[e] = pack_bf2(lo, hi);
+                }
+            }
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ));
+    }
+}
+
+template <int OSZ, bool EXACT, int TNC, int NTH>
+__device__ __forceinline__ void epilogueT(char* smem, const f32x16_t (&acc)[2][4], const Gemm256Params& p, int m0,
+                                          int n0, int wm, int wn, int lane, int tid) {
+    using E = EpiT<OSZ, TNC>;
+    const bool gelu = p.epi == MAEST_EPI_GELU;
+    const bool pair = gelu && p.aux_out != nullptr;
+    // rows per pass so that the staging area (two regions for the pair form) fits the LDS ring it reuses
+    auto run = [&](auto rp_tag, auto pair_tag) {
+        constexpr int RP = decltype(rp_tag)::value;
+        constexpr bool PAIR = decltype(pair_tag)::value;
+        constexpr int REGION = RP * E::PITCH;
+#pragma unroll
+        for (int ps = 0; ps < 256 / RP; ++ps) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int r0 = wm * 128 + mt * 32;             // wave-uniform
+                if (r0 >= ps * RP && r0 < (ps + 1) * RP) {
+                    if (PAIR) stageT<OSZ, 3, EXACT, TNC>(smem, REGION, acc[0][mt], acc[1][mt], p.bias, n0, p.N, r0 - ps * RP, wn, lane);
+                    else if (gelu) stageT<OSZ, 1, EXACT, TNC>(smem, 0, acc[0][mt], acc[1][mt], p.bias, n0, p.N, r0 - ps * RP, wn, lane);
+                    else stageT<OSZ, 0, EXACT, TNC>(smem, 0, acc[0][mt], acc[1][mt], p.bias, n0, p.N, r0 - ps * RP, wn, lane);
+                }
+            }
+            __syncthreads();
+            const int mbase = m0 + ps * RP;
+            if (PAIR) {
+                drainT<OSZ, 0, TNC, NTH>(smem, RP, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
+                drainT<OSZ, 0, TNC, NTH>(smem + REGION, RP, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
+            } else if (p.epi == MAEST_EPI_RESIDUAL) {
+                drainT<OSZ, 1, TNC, NTH>(smem, RP, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
+            } else if (p.epi == MAEST_EPI_MUL) {
+                drainT<OSZ, 2, TNC, NTH>(smem, RP, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
+            } else {
+                drainT<OSZ, 0, TNC, NTH>(smem, RP, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
+            }
+            if (ps + 1 < 256 / RP) __syncthreads();
+        }
+    };
+    if (pair) run(std::integral_constant<int, (OSZ == 2 ? 128 : 64)>{}, std::true_type{});
+    else run(std::integral_constant<int, (OSZ == 2 ? 256 : 128)>{}, std::false_type{});
+}
+
+constexpr int W2_ROWB = 128;
+constexpr int W2_UNIT = 256 * W2_ROWB;      // 32768
+constexpr int W2_NBUF = 5;
+constexpr int W2_SMEM = W2_NBUF * W2_UNIT;  // 163840
+
+// ---- pipelined C-tile epilogue of the full-line kernel (512 threads, 160 KiB of LDS).
+// Measured: staging the whole tile in one pass is SLOWER than two 128-row passes (0.36 vs 0.33 ms for the qkv
+// shape) -- with more passes the LDS staging of one overlaps the HBM stores of the previous one.  So: four passes,
+// pass ps = m-tile ps of BOTH wave groups (rows wm*128 + ps*32 ..+32: every wave stages one m-tile per pass, none
+// idles), two staging buffers, ONE barrier per pass: each wave first drains pass ps (its 16-byte stores go in
+// flight), then converts / activates and stages pass ps+1 into the other buffer underneath them.
+template <int OSZ, bool EXACT, bool PAIR, int MODE>
+__device__ __forceinline__ void epilogueW_run(char* smem, const f32x16_t (&acc)[2][4], const Gemm256Params& p, int m0,
+                                              int n0, int wm, int wn, int lane, int tid, bool gelu) {
+    using E = EpiT<OSZ, 256>;
+    constexpr int REGION = 64 * E::PITCH;                       // one 64-row staging region: 33792 / 66560
+    constexpr int BUF = (PAIR ? 2 : 1) * REGION;
+    constexpr bool DOUBLE = 2 * BUF <= W2_SMEM;                 // everything but the fp32 value + GELU' pair
+    auto stage = [&](int ps, char* buf) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            if (mt == ps) {
+                if (PAIR) stageT<OSZ, 3, EXACT, 256>(buf, REGION, acc[0][mt], acc[1][mt], p.bias, n0, p.N, wm * 32, wn, lane);
+                else if (gelu) stageT<OSZ, 1, EXACT, 256>(buf, 0, acc[0][mt], acc[1][mt], p.bias, n0, p.N, wm * 32, wn, lane);
+                else stageT<OSZ, 0, EXACT, 256>(buf, 0, acc[0][mt], acc[1][mt], p.bias, n0, p.N, wm * 32, wn, lane);
+            }
+    };
+    auto drain = [&](int ps, const char* buf) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                  // the two 32-row groups of the pass are 128 rows apart
+            const int mbase = m0 + half * 128 + ps * 32;
+            const char* src = buf + half * 32 * E::PITCH;
+            drainT<OSZ, MODE, 256, 512>(src, 32, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
+            if (PAIR) drainT<OSZ, 0, 256, 512>(src + REGION, 32, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
+        }
+    };
+    stage(0, smem);
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        char* cur = smem + (DOUBLE ? (ps & 1) * BUF : 0);
+        drain(ps, cur);
+        if (!DOUBLE && ps < 3) __syncthreads();                 // single buffer: everybody has drained before the refill
+        if (ps < 3) stage(ps + 1, smem + (DOUBLE ? ((ps + 1) & 1) * BUF : 0));
+        if (ps < 3) __syncthreads();
+    }
+}
+template <int OSZ, bool EXACT>
+__device__ __forceinline__ void epilogueW(char* smem, const f32x16_t (&acc)[2][4], const Gemm256Params& p, int m0,
+                                          int n0, int wm, int wn, int lane, int tid) {
+    const bool gelu = p.epi == MAEST_EPI_GELU;
+    if (gelu && p.aux_out != nullptr) epilogueW_run<OSZ, EXACT, true, 0>(smem, acc, p, m0, n0, wm, wn, lane, tid, true);
+    else if (p.epi == MAEST_EPI_RESIDUAL) epilogueW_run<OSZ, EXACT, false, 1>(smem, acc, p, m0, n0, wm, wn, lane, tid, false);
+    else if (p.epi == MAEST_EPI_MUL) epilogueW_run<OSZ, EXACT, false, 2>(smem, acc, p, m0, n0, wm, wn, lane, tid, false);
+    else epilogueW_run<OSZ, EXACT, false, 0>(smem, acc, p, m0, n0, wm, wn, lane, tid, gelu);
+}
+
 // ================================================================================================
 // 256x256 tile, FULL-CACHE-LINE operand stages ("wide" kernel).
 // Measured on MI355X (scratch/probe/dma_bw.hip, ablate.sh): the vector-memory front end retires roughly one
@@ -407,12 +590,8 @@ static int launch256(Gemm256Params& p, hipStream_t stream) {
 //   * bank swizzle for 128-byte rows: physical 16-byte chunk p of row r holds logical chunk p ^ ((r >> 1) & 7)
 //     (applied on the DMA source address); a 16-lane ds_read_b128 group then covers all 16 slots of 256 B.
 // ================================================================================================
-constexpr int W2_ROWB = 128;
-constexpr int W2_UNIT = 256 * W2_ROWB;      // 32768
-constexpr int W2_NBUF = 5;
-constexpr int W2_SMEM = W2_NBUF * W2_UNIT;  // 163840
 
-template <typename T>
+template <typename T, int EPIV>
 __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -574,19 +753,27 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();          // un-stagger
     MAEST_WAIT_VMCNT(0);   // drain the past-the-end loads before LDS is reused
     __syncthreads();       // LDS becomes the C staging area
-    if (p.out_dtype == MAEST_BF16) epilogue256<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
-    else epilogue256<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+    if (EPIV == 0) {        // two-pass epilogue of the 64-byte-slice kernel
+        if (p.out_dtype == MAEST_BF16) epilogue256<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+        else epilogue256<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+    } else if (EPIV == 1) { // four passes, double buffered
+        if (p.out_dtype == MAEST_BF16) epilogueW<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+        else epilogueW<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+    } else {                // whole tile in one pass
+        if (p.out_dtype == MAEST_BF16) epilogueT<2, sizeof(T) == 4, 256, 512>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+        else epilogueT<4, sizeof(T) == 4, 256, 512>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+    }
 }
 
-template <typename T>
+template <typename T, int EPIV>
 static int launch256w(Gemm256Params& p, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256w_kernel<T>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256w_kernel<T, EPIV>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, W2_SMEM);
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm_nt256w_kernel<T>, dim3(p.tiles_m * p.tiles_n), dim3(512), W2_SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_nt256w_kernel<T, EPIV>), dim3(p.tiles_m * p.tiles_n), dim3(512), W2_SMEM, stream, p);
     return check_launch("maest_gemm_nt(256w)");
 }
 
@@ -604,128 +791,6 @@ constexpr int H2_A = 256 * G2_ROWB;                   // 16384
 constexpr int H2_STAGE = (256 + H2_TN) * G2_ROWB;     // 24576
 constexpr int H2_STAGES = 3;
 constexpr int H2_SMEM = H2_STAGES * H2_STAGE;         // 73728
-
-template <int OSZ>
-struct EpiH {
-    static constexpr int PITCH = H2_TN * OSZ + 16;    // 272 / 528
-    static constexpr int CPR = H2_TN * OSZ / 16;      // chunks per row: 16 / 32
-    static constexpr int EPC = 16 / OSZ;
-};
-
-// one 32-row m-tile of this wave's block -> LDS rows [lrow0, lrow0 + 32); GMODE 0 none, 1 GELU value, 3 value + GELU'
-template <int OSZ, int GMODE, bool EXACT>
-__device__ __forceinline__ void stageH(char* smem, int region, const f32x16_t& a0, const f32x16_t& a1,
-                                       const float* bias, int n0, int N, int lrow0, int wn, int lane) {
-    using E = EpiH<OSZ>;
-    const int h = lane >> 5;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nl = wn * 64 + nt * 32 + 8 * g + 4 * h;
-            f32x4_t b4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (bias != nullptr && n0 + nl < N) b4 = *reinterpret_cast<const f32x4_t*>(bias + n0 + nl);
-            float v[4], d[4];
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                const f32x2_t xv = {(nt == 0 ? a0[4 * g + e] : a1[4 * g + e]) + b4[e],
-                                    (nt == 0 ? a0[4 * g + e + 1] : a1[4 * g + e + 1]) + b4[e + 1]};
-                f32x2_t gv = xv, dv = {0.0f, 0.0f};
-                if (GMODE != 0) gelu_pair2<EXACT>(xv, gv, dv);
-                v[e] = gv[0]; v[e + 1] = gv[1];
-                d[e] = dv[0]; d[e + 1] = dv[1];
-            }
-            char* dst = smem + (lrow0 + (lane & 31)) * E::PITCH + nl * OSZ;
-            if (OSZ == 4) {
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                if (GMODE == 3) *reinterpret_cast<float4*>(dst + region) = make_float4(d[0], d[1], d[2], d[3]);
-            } else {
-                chunk8 o;
-                o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
-                *reinterpret_cast<chunk8*>(dst) = o;
-                if (GMODE == 3) {
-                    chunk8 q;
-                    q[0] = pack_bf2(d[0], d[1]); q[1] = pack_bf2(d[2], d[3]);
-                    *reinterpret_cast<chunk8*>(dst + region) = q;
-                }
-            }
-        }
-}
-
-template <int OSZ, int MODE>
-__device__ __forceinline__ void drainH(const char* smem, int rows, void* dst, int64_t ld, const void* aux,
-                                       int64_t ld_aux, int mbase, int n0, int M, int N, int tid) {
-    using E = EpiH<OSZ>;
-#pragma unroll 4
-    for (int c = tid; c < rows * E::CPR; c += 256) {
-        const int row = c / E::CPR, cc = c - row * E::CPR;
-        const int gm = mbase + row, gn = n0 + cc * E::EPC;
-        if (gm >= M || gn >= N) continue;
-        chunk16 v = *reinterpret_cast<const chunk16*>(smem + row * E::PITCH + cc * 16);
-        if (MODE == 1) {
-            const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(aux) + (int64_t)gm * ld_aux + gn);
-            v[0] = f2u(u2f(v[0]) + r.x); v[1] = f2u(u2f(v[1]) + r.y);
-            v[2] = f2u(u2f(v[2]) + r.z); v[3] = f2u(u2f(v[3]) + r.w);
-        } else if (MODE == 2) {
-            if (OSZ == 4) {
-                const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(aux) + (int64_t)gm * ld_aux + gn);
-                v[0] = f2u(u2f(v[0]) * r.x); v[1] = f2u(u2f(v[1]) * r.y);
-                v[2] = f2u(u2f(v[2]) * r.z); v[3] = f2u(u2f(v[3]) * r.w);
-            } else {
-                const chunk16 r = *reinterpret_cast<const chunk16*>(reinterpret_cast<const bf16_t*>(aux) + (int64_t)gm * ld_aux + gn);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t vw = v[e], rw = r[e];
-                    const float lo = u2f(vw << 16) * u2f(rw << 16);
-                    const float hi = u2f(vw & 0xffff0000u) * u2f(rw & 0xffff0000u);
-                    v[e] = pack_bf2(lo, hi);
-                }
-            }
-        }
-        __builtin_nontemporal_store(v, reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ));
-    }
-}
-
-template <int OSZ, bool EXACT>
-__device__ __forceinline__ void epilogueH(char* smem, const f32x16_t (&acc)[2][4], const Gemm256Params& p, int m0,
-                                          int n0, int wm, int wn, int lane, int tid) {
-    using E = EpiH<OSZ>;
-    const bool gelu = p.epi == MAEST_EPI_GELU;
-    const bool pair = gelu && p.aux_out != nullptr;
-    // rows per pass so that the staging area (two regions for the pair form) fits the 72 KiB ring
-    auto run = [&](auto rp_tag, auto pair_tag) {
-        constexpr int RP = decltype(rp_tag)::value;
-        constexpr bool PAIR = decltype(pair_tag)::value;
-        constexpr int REGION = RP * E::PITCH;
-#pragma unroll
-        for (int ps = 0; ps < 256 / RP; ++ps) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int r0 = wm * 128 + mt * 32;             // wave-uniform
-                if (r0 >= ps * RP && r0 < (ps + 1) * RP) {
-                    if (PAIR) stageH<OSZ, 3, EXACT>(smem, REGION, acc[0][mt], acc[1][mt], p.bias, n0, p.N, r0 - ps * RP, wn, lane);
-                    else if (gelu) stageH<OSZ, 1, EXACT>(smem, 0, acc[0][mt], acc[1][mt], p.bias, n0, p.N, r0 - ps * RP, wn, lane);
-                    else stageH<OSZ, 0, EXACT>(smem, 0, acc[0][mt], acc[1][mt], p.bias, n0, p.N, r0 - ps * RP, wn, lane);
-                }
-            }
-            __syncthreads();
-            const int mbase = m0 + ps * RP;
-            if (PAIR) {
-                drainH<OSZ, 0>(smem, RP, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
-                drainH<OSZ, 0>(smem + REGION, RP, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
-            } else if (p.epi == MAEST_EPI_RESIDUAL) {
-                drainH<OSZ, 1>(smem, RP, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
-            } else if (p.epi == MAEST_EPI_MUL) {
-                drainH<OSZ, 2>(smem, RP, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
-            } else {
-                drainH<OSZ, 0>(smem, RP, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
-            }
-            if (ps + 1 < 256 / RP) __syncthreads();
-        }
-    };
-    if (pair) run(std::integral_constant<int, (OSZ == 2 ? 128 : 64)>{}, std::true_type{});
-    else run(std::integral_constant<int, (OSZ == 2 ? 256 : 128)>{}, std::false_type{});
-}
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_nt256x128_kernel(Gemm256Params p) {
@@ -837,8 +902,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt256x128_kernel(Gemm256Params p)
     }
     MAEST_WAIT_VMCNT(0);
     __syncthreads();   // LDS becomes the C staging area
-    if (p.out_dtype == MAEST_BF16) epilogueH<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
-    else epilogueH<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+    if (p.out_dtype == MAEST_BF16) epilogueT<2, sizeof(T) == 4, H2_TN, 256>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+    else epilogueT<4, sizeof(T) == 4, H2_TN, 256>(smem, acc, p, m0, n0, wm, wn, lane, tid);
 }
 
 template <typename T>
@@ -874,7 +939,14 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
     // = 1 / 2 select the 64-byte-slice 256x256 kernel / the 256x128 two-per-CU kernel for A/B timing and tests
     if (variant != 1 && variant != 2 && (N % 256) == 0 && (K * (in_dtype == MAEST_BF16 ? 2 : 4)) % W2_ROWB == 0) {
         p.tiles_n = N / 256;
-        return in_dtype == MAEST_BF16 ? launch256w<bf16_t>(p, stream) : launch256w<float>(p, stream);
+        // epilogue form, measured side by side in one run (scratch/gemm_ab.py): the two-pass form wins for bf16
+        // outputs by 1-5 %, the four-pass double-buffered form for the fp32 residual outputs by 3-5 %, the
+        // one-pass form never.  MAEST_GEMM_EPILOGUE = 0 / 1 / 2 forces one of them.
+        const char* eenv = getenv("MAEST_GEMM_EPILOGUE");
+        const int ev = eenv ? atoi(eenv) : (epi == MAEST_EPI_RESIDUAL ? 1 : 0);
+        if (ev == 1) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 1>(p, stream) : launch256w<float, 1>(p, stream);
+        if (ev == 2) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 2>(p, stream) : launch256w<float, 2>(p, stream);
+        return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 0>(p, stream) : launch256w<float, 0>(p, stream);
     }
     if (variant != 2 && (N % 256) == 0) {
         p.tiles_n = N / 256;

@@ -24,9 +24,9 @@ for M in (256 * 290, 256 * 560):
                  ("mul->bf16", lambda: ops.gemm_nt(a, w, None, out=out_bf, epi=ops.EPI_MUL, aux_in=aux))]
         for cn, fn in cases:
             r = []
-            for v in ("3", "0"):
-                os.environ["MAEST_GEMM_VARIANT"] = v
+            for v in ("0", "1", "2"):
+                os.environ["MAEST_GEMM_EPILOGUE"] = v
                 ms = bench(fn); r.append(ms)
             fl = 2.0 * M * N * K
-            print(f"  {nm:5s} {cn:11s} 256w: {r[0]:7.3f} ms {fl/r[0]/1e9:7.1f} TF/s | 256x256: {r[1]:7.3f} ms {fl/r[1]/1e9:7.1f} TF/s")
+            print(f"  {nm:5s} {cn:11s} 2pass: {r[0]:7.3f} ms | 4pass-dbuf: {r[1]:7.3f} ms | 1pass: {r[2]:7.3f} ms   best {fl/min(r)/1e9:7.1f} TF/s")
         del a, w, out_bf, out32, res, aux
