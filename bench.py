@@ -130,7 +130,8 @@ def main():
     B, T = args.batch, args.frames
     train = args.mode == "train"
     net = get_maest("passt_s_swa_p16_128_ap476" if train else "discogs-maest-10s-pw-129e", pretrained=False,
-                    input_t=625, s_patchout_t=args.patchout if train else 0, precision=args.precision).to(dev)
+                    input_t=(T // 5) * 5 if T > 640 else 625,   # time table: 62 columns for 10 s, 187 for the 30 s configs
+                    s_patchout_t=args.patchout if train else 0, precision=args.precision).to(dev)
     broadcast_parameters(net)
     if args.serial_kernels:
         net._engine.overlap_wgrad = False
@@ -206,13 +207,16 @@ def main():
         fwd = flops_per_clip_fwd(N, Tk)
         step_flops = (3 if train else 1) * fwd * B
         out = {
-            "metric": "clips/sec (10s@16kHz, 96-mel) MAEST-10s " + ("fwd+bwd" if train else "fwd"),
+            "metric": ("clips/sec (10s@16kHz, 96-mel) MAEST-10s " if T <= 640 else "clips/sec (30s@16kHz, 96-mel) MAEST-30s ")
+                      + ("fwd+bwd" if train else "fwd"),
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": ("maest_10s_random_weights_pretrain training step (BASELINE configs[2]): "
-                                    "mixup + fwd + BCE + bwd + AdamW" if train else
-                                    "discogs-maest-10s-pw-129e inference (BASELINE configs[1])"),
+            "config": {"workload": (("maest_10s_random_weights_pretrain training step (BASELINE configs[2]): "
+                                     "mixup + fwd + BCE + bwd + AdamW" if train else
+                                     "discogs-maest-10s-pw-129e inference (BASELINE configs[1])") if T <= 640 else
+                                    (f"30 s clips ({T} frames): " + ("maest_30s_from_passt_pretrain-shaped training step "
+                                     "(BASELINE configs[3], per-GPU shape)" if train else "discogs-maest-30s inference"))),
                        "arch": "passt_s_swa_p16_128_ap476 (DeiT-B distilled, 85.9M params), random init",
                        "per_gpu_batch": B, "global_batch": B * world, "mel": [96, T],
                        "s_patchout_t": args.patchout if train else 0, "tokens": N, "classes": 400,
