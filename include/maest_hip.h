@@ -175,8 +175,22 @@ int maest_logmel(const float* wave, int B, int S, const float* window, const flo
                  const int32_t* fb_start, const int32_t* fb_len, const float* fb_w, int fb_stride,
                  float log_scale, float norm_mean, float norm_2std, float* out, void* stream);
 
+/* ---- second mel parameterisation: AugmentMelSTFT (models/preprocess.py:17-128; north_star names the file, the
+ * reference's MAEST path never calls it).  wave: fp32 [B, S] at 32 kHz; out: fp32 [B, n_mels, T], T = 1 + (S-1)/320.
+ * y = pre0*x[n] + pre1*x[n+1] (pre-emphasis, reference [-0.97, 1]); STFT n_fft 1024 / hop 320 / center / reflect with
+ * `window` = the 800-point non-periodic Hann zero-padded to 1024; power; band-sparse filterbank over 513 bins
+ * (fb_start / fb_len / fb_w as in maest_logmel); out = (log(mel + log_eps) + norm_add) / norm_div.
+ * twiddle: fp32 [1024, 2] = exp(-2*pi*i*k/1024).  n_mels <= 128. */
+int maest_augment_mel(const float* wave, int B, int S, const float* window, const float* twiddle,
+                      const int32_t* fb_start, const int32_t* fb_len, const float* fb_w, int fb_stride,
+                      int n_mels, float pre0, float pre1, float log_eps, float norm_add, float norm_div,
+                      float* out, void* stream);
+
 /* ---- optimizer-side helper: scale a flat fp32 gradient bucket (after the RCCL all-reduce) */
 int maest_scale_f32(float* x, int64_t n, float alpha, void* stream);
+/* x = (x + add) / div in place (AugmentMelSTFT's "fast normalization" after the training-time masks,
+ * models/preprocess.py:129) */
+int maest_affine_f32(float* x, int64_t n, float add, float div, void* stream);
 
 /* ---- on-disk mel chunks -> network input (the step before the hot path) ------------
  * Replaces DiscogsDataset.load_melspectrogram (discogs/dataset.py:69-140) + norm_func

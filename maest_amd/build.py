@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmaest_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "norm.hip", "attention.hip", "embed.hip", "misc.hip", "mel.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "norm.hip", "attention.hip", "embed.hip", "misc.hip", "mel.hip", "mel2.hip"]
 
 
 def _hipcc():

@@ -162,6 +162,11 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= alpha;
 }
 
+__global__ __launch_bounds__(256) void affine_kernel(float* __restrict__ x, int64_t n, float add, float div) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        x[i] = (x[i] + add) / div;
+}
+
 }  // namespace maest
 
 using namespace maest;
@@ -266,4 +271,13 @@ extern "C" int maest_scale_f32(float* x, int64_t n, float alpha, void* stream) {
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, alpha);
     return check_launch("maest_scale_f32");
+}
+
+extern "C" int maest_affine_f32(float* x, int64_t n, float add, float div, void* stream) {
+    MAEST_REQUIRE(x && n >= 0 && div != 0.0f, "maest_affine_f32: bad arguments");
+    if (n == 0) return MAEST_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(affine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, add, div);
+    return check_launch("maest_affine_f32");
 }

@@ -362,3 +362,23 @@ def scale_(x: torch.Tensor, alpha: float):
     assert x.dtype == torch.float32
     call("maest_scale_f32", _p(x), x.numel(), alpha, _s(x))
     return x
+
+
+def affine_(x: torch.Tensor, add: float, div: float):
+    """x = (x + add) / div in place (fp32)."""
+    _chk(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    call("maest_affine_f32", _p(x), x.numel(), add, div, _s(x))
+    return x
+
+
+def augment_mel(wave, window, twiddle, fb_start, fb_len, fb_w, fb_stride, n_mels, pre0, pre1, log_eps, norm_add, norm_div):
+    """wave fp32 [B, S] (32 kHz) -> fp32 [B, n_mels, 1 + (S - 1) // 320]  (csrc/mel2.hip)."""
+    _chk(wave, window, twiddle, fb_start, fb_len, fb_w)
+    assert wave.dtype == torch.float32 and wave.dim() == 2 and wave.is_contiguous()
+    B, S = wave.shape
+    T = 1 + (S - 1) // 320
+    out = torch.empty((B, n_mels, T), dtype=torch.float32, device=wave.device)
+    call("maest_augment_mel", _p(wave), B, S, _p(window), _p(twiddle), _p(fb_start), _p(fb_len), _p(fb_w), fb_stride,
+         n_mels, pre0, pre1, log_eps, norm_add, norm_div, _p(out), _s(wave))
+    return out

@@ -375,3 +375,39 @@ def spec_masking(x: torch.Tensor, time_masks: Sequence[Tuple[int, int]],
     for s, w in freq_masks:
         x[..., s:s + w, :] = 0.0
     return x
+
+
+# ----------------------------------------------------------------------------------------------
+# AugmentMelSTFT (models/preprocess.py:17-128), eval-mode path and explicit-stripe training path.
+# PARITY UNPINNED: torch.stft is torch's own, but the mel banks come from torchaudio.compliance.kaldi
+# (absent here); `kaldi_mel_banks` restates its published algorithm (VTLN warp factor 1.0).
+# ----------------------------------------------------------------------------------------------
+def kaldi_mel_banks(num_bins: int, n_fft: int, sr: float, low_freq: float, high_freq: float) -> torch.Tensor:
+    nyquist = 0.5 * sr
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    mel = lambda f: 1127.0 * torch.log(1.0 + f / 700.0)
+    mel_low = 1127.0 * math.log(1.0 + low_freq / 700.0)
+    mel_high = 1127.0 * math.log(1.0 + high_freq / 700.0)
+    delta = (mel_high - mel_low) / (num_bins + 1)
+    b = torch.arange(num_bins).unsqueeze(1)
+    left, center, right = mel_low + b * delta, mel_low + (b + 1.0) * delta, mel_low + (b + 2.0) * delta
+    m = mel((sr / n_fft) * torch.arange(n_fft // 2)).unsqueeze(0)
+    return torch.max(torch.zeros(1), torch.min((m - left) / (center - left), (right - m) / (right - center)))
+
+
+def augment_mel(x: torch.Tensor, n_mels=128, sr=32000, win_length=800, hopsize=320, n_fft=1024, fmin=0.0,
+                fmax=15500.0, f_stripe=None, t_stripe=None) -> torch.Tensor:
+    """preprocess.py:81-131 for given band edges; `f_stripe` / `t_stripe` = (start, width) zeroed after the log
+    (the training-time masks, drawn by the caller)."""
+    x = F.conv1d(x.unsqueeze(1), torch.as_tensor([[[-0.97, 1.0]]])).squeeze(1)
+    spec = torch.stft(x, n_fft, hop_length=hopsize, win_length=win_length, center=True, normalized=False,
+                      window=torch.hann_window(win_length, periodic=False), return_complex=True)
+    power = spec.real ** 2 + spec.imag ** 2
+    basis = F.pad(kaldi_mel_banks(n_mels, n_fft, sr, fmin, fmax), (0, 1), mode="constant", value=0)
+    mel = (torch.matmul(basis, power) + 0.00001).log()
+    if f_stripe is not None:
+        mel[:, f_stripe[0]:f_stripe[0] + f_stripe[1], :] = 0.0
+    if t_stripe is not None:
+        mel[:, :, t_stripe[0]:t_stripe[0] + t_stripe[1]] = 0.0
+    return (mel + 4.5) / 5.0

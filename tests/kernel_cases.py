@@ -347,3 +347,29 @@ def case_melfile(dev, tmp_path, size=50, counts=(80, 30, 31, 50, 1, 45), offsets
             w32 = torch.from_numpy(want.astype(np.float32))
             assert torch.equal(got[i].cpu(), w32), (
                 f"melfile clip {i} normalize={normalize}: max diff {(got[i].cpu() - w32).abs().max().item()}")
+
+
+# ------------------------------------------------------------------ second mel parameterisation
+def case_augment_mel(dev, B, S, seed=95):
+    """AugmentMelSTFT (csrc/mel2.hip) against the oracle restatement: eval mode, and training mode with the
+    band-edge jitter and stripes replayed from the same torch seed."""
+    from maest_amd.preprocess import AugmentMelSTFT
+    rng = np.random.Generator(np.random.PCG64(seed))
+    w = torch.from_numpy((rng.random((B, S), dtype=np.float32) * 2 - 1) * 0.5)
+    m = AugmentMelSTFT().to(dev).eval()
+    got = m(w.to(dev))
+    want = O.augment_mel(w)
+    assert got.shape == want.shape == (B, 128, 1 + (S - 1) // 320)
+    close(got, want, 1e-3, 1e-3, "augment mel (eval)")
+    # training: the reference draws fmin, fmax (torch.randint x2), then the frequency and the time stripe (rand x2 each)
+    m = AugmentMelSTFT(fmin_aug_range=10, fmax_aug_range=2000).to(dev).train()
+    torch.manual_seed(7)
+    got = m(w.to(dev))
+    torch.manual_seed(7)
+    fmin = 0.0 + torch.randint(10, (1,)).item()
+    fmax = m.fmax + 2000 // 2 - torch.randint(2000, (1,)).item()
+    T = want.shape[-1]
+    v = torch.rand(1) * 48; mv = torch.rand(1) * (128 - v); fs = (int(mv.long()), int(v.long()))
+    v = torch.rand(1) * 192; mv = torch.rand(1) * (T - v); ts = (int(mv.long()), int(v.long()))
+    want = O.augment_mel(w, fmin=fmin, fmax=fmax, f_stripe=fs, t_stripe=ts)
+    close(got, want, 1e-3, 1e-3, "augment mel (train)")

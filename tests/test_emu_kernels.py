@@ -97,3 +97,7 @@ def test_emu_mel(emu):
 
 def test_emu_melfile(emu, tmp_path):
     KC.case_melfile(emu, tmp_path)
+
+
+def test_emu_augment_mel(emu):
+    KC.case_augment_mel(emu, 1, 4000)

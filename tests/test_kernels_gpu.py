@@ -86,3 +86,8 @@ def test_melfile(tmp_path):
     counts = [int(c) for c in rng.integers(1, 1400, 64)]
     offsets = [int(rng.integers(0, max(c - 300, 1))) for c in counts]
     KC.case_melfile(DEV, tmp_path, size=625, counts=counts, offsets=offsets, seed=91)
+
+
+def test_augment_mel():
+    KC.case_augment_mel(DEV, 3, 320000)      # 10 s at 32 kHz -> [3, 128, 1000]
+    KC.case_augment_mel(DEV, 2, 33333)
