@@ -188,6 +188,10 @@ int maest_augment_mel(const float* wave, int B, int S, const float* window, cons
 
 /* ---- optimizer-side helper: scale a flat fp32 gradient bucket (after the RCCL all-reduce) */
 int maest_scale_f32(float* x, int64_t n, float alpha, void* stream);
+/* stochastic weight averaging of n parameters in one launch (HOST arrays of device pointers / sizes):
+ * avg[i] += (cur[i] - avg[i]) * inv_count   (Lightning StochasticWeightAveraging.avg_fn, helpers/swa_callback.py) */
+int maest_swa_update_multi(int n, float* const* avg, const float* const* cur, const int64_t* numel,
+                           float inv_count, void* stream);
 /* x = (x + add) / div in place (AugmentMelSTFT's "fast normalization" after the training-time masks,
  * models/preprocess.py:129) */
 int maest_affine_f32(float* x, int64_t n, float add, float div, void* stream);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "maest_sigmoid_mean": [_P, _I, _I, _P, _P],
     "maest_colsum": [_P, _L, _I, _I, _I, _P, _P],
     "maest_spec_mask": [_P, _I, _I, _I, _P, _I, _P, _I, _P],
+    "maest_swa_update_multi": [_I, _P, _P, _P, _F, _P],
     "maest_affine_f32": [_P, _L, _F, _F, _P],
     "maest_augment_mel": [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _P, _P],
     "maest_melfile_assemble": [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],

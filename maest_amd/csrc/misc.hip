@@ -162,6 +162,32 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= alpha;
 }
 
+// ---- stochastic weight averaging over MANY parameters in one launch: avg += (w - avg) * inv_count
+// (Lightning's StochasticWeightAveraging.avg_fn as used by helpers/swa_callback.py)
+struct SwaTable {
+    float* avg[CAST_MAX_ITEMS];
+    const float* cur[CAST_MAX_ITEMS];
+    int64_t numel[CAST_MAX_ITEMS];
+    int block_begin[CAST_MAX_ITEMS + 1];   // prefix sum of 4096-element chunks
+    int n;
+};
+__global__ __launch_bounds__(256) void swa_update_kernel(const SwaTable tab, float inv_count) {
+    int it = 0;
+    while (it + 1 < tab.n && (int)blockIdx.x >= tab.block_begin[it + 1]) ++it;
+    const int64_t base = (int64_t)(blockIdx.x - tab.block_begin[it]) * 4096;
+    float* __restrict__ a = tab.avg[it];
+    const float* __restrict__ w = tab.cur[it];
+    const int64_t n = tab.numel[it];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i < n) {
+            const float av = a[i];
+            a[i] = av + (w[i] - av) * inv_count;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void affine_kernel(float* __restrict__ x, int64_t n, float add, float div) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         x[i] = (x[i] + add) / div;
@@ -280,4 +306,24 @@ extern "C" int maest_affine_f32(float* x, int64_t n, float add, float div, void*
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(affine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, add, div);
     return check_launch("maest_affine_f32");
+}
+
+extern "C" int maest_swa_update_multi(int n, float* const* avg, const float* const* cur, const int64_t* numel,
+                                      float inv_count, void* stream) {
+    MAEST_REQUIRE(n > 0 && avg && cur && numel, "maest_swa_update_multi: null pointer / n <= 0");
+    for (int base = 0; base < n; base += CAST_MAX_ITEMS) {
+        SwaTable tab;
+        tab.n = n - base < CAST_MAX_ITEMS ? n - base : CAST_MAX_ITEMS;
+        int blocks = 0;
+        for (int i = 0; i < tab.n; ++i) {
+            const int k = base + i;
+            MAEST_REQUIRE(avg[k] && cur[k] && numel[k] > 0, "maest_swa_update_multi: bad item %d", k);
+            tab.avg[i] = avg[k]; tab.cur[i] = cur[k]; tab.numel[i] = numel[k];
+            tab.block_begin[i] = blocks;
+            blocks += (int)((numel[k] + 4095) / 4096);
+        }
+        tab.block_begin[tab.n] = blocks;
+        hipLaunchKernelGGL(swa_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab, inv_count);
+    }
+    return check_launch("maest_swa_update_multi");
 }

@@ -382,3 +382,18 @@ def augment_mel(wave, window, twiddle, fb_start, fb_len, fb_w, fb_stride, n_mels
     call("maest_augment_mel", _p(wave), B, S, _p(window), _p(twiddle), _p(fb_start), _p(fb_len), _p(fb_w), fb_stride,
          n_mels, pre0, pre1, log_eps, norm_add, norm_div, _p(out), _s(wave))
     return out
+
+
+def swa_update_multi(avgs, curs, inv_count: float):
+    """avg += (cur - avg) * inv_count for every (avg, cur) pair of fp32 tensors, one launch."""
+    _chk(*avgs, *curs)
+    n = len(avgs)
+    assert n == len(curs) and n > 0
+    for a, c in zip(avgs, curs):
+        assert a.dtype == c.dtype == torch.float32 and a.is_contiguous() and c.is_contiguous() and a.numel() == c.numel()
+    vp = ctypes.c_void_p * n
+    a_avg = vp(*[a.data_ptr() for a in avgs])
+    a_cur = vp(*[c.data_ptr() for c in curs])
+    a_n = (ctypes.c_int64 * n)(*[a.numel() for a in avgs])
+    call("maest_swa_update_multi", n, ctypes.cast(a_avg, ctypes.c_void_p), ctypes.cast(a_cur, ctypes.c_void_p),
+         ctypes.cast(a_n, ctypes.c_void_p), float(inv_count), _s(avgs[0]))

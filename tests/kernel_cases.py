@@ -373,3 +373,18 @@ def case_augment_mel(dev, B, S, seed=95):
     v = torch.rand(1) * 192; mv = torch.rand(1) * (T - v); ts = (int(mv.long()), int(v.long()))
     want = O.augment_mel(w, fmin=fmin, fmax=fmax, f_stripe=fs, t_stripe=ts)
     close(got, want, 1e-3, 1e-3, "augment mel (train)")
+
+
+# ------------------------------------------------------------------ stochastic weight averaging
+def case_swa(dev):
+    shapes = [(768, 33), (5,), (4097,), (3, 1, 16, 16)]
+    avg = [rnd(sh, 110 + i) for i, sh in enumerate(shapes)]
+    want = [a.clone() for a in avg]
+    got = [a.clone().to(dev) for a in avg]
+    for step in range(3):
+        cur = [rnd(sh, 120 + 10 * step + i) for i, sh in enumerate(shapes)]
+        inv = 1.0 / (step + 2)
+        ops.swa_update_multi(got, [c.to(dev) for c in cur], inv)
+        want = [w + (c - w) * inv for w, c in zip(want, cur)]
+    for g, w in zip(got, want):
+        close(g, w, 1e-6, 1e-7, "swa running mean")

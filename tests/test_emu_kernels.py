@@ -101,3 +101,7 @@ def test_emu_melfile(emu, tmp_path):
 
 def test_emu_augment_mel(emu):
     KC.case_augment_mel(emu, 1, 4000)
+
+
+def test_emu_swa(emu):
+    KC.case_swa(emu)

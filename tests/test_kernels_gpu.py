@@ -91,3 +91,7 @@ def test_melfile(tmp_path):
 def test_augment_mel():
     KC.case_augment_mel(DEV, 3, 320000)      # 10 s at 32 kHz -> [3, 128, 1000]
     KC.case_augment_mel(DEV, 2, 33333)
+
+
+def test_swa():
+    KC.case_swa(DEV)

@@ -328,3 +328,39 @@ def test_hip_graph_captured_inference_is_bit_identical():
             got = net(xs[0])
             assert torch.equal(got[0], ref[0])
         assert torch.allclose(got[0], eager[0][0] + 1.0, atol=1e-5)
+
+
+def test_weight_averager_and_device_metrics():
+    """the running mean over three weight snapshots equals their mean, the averaged model's forward
+    uses the averaged weights (stale operand copies dropped), and the device metrics agree with scikit-learn."""
+    from sklearn import metrics as skm
+    from maest_amd import metrics as M
+    from maest_amd.swa import WeightAverager
+    net = build("discogs-maest-10s-pw-129e", 625, precision="fp32").eval()
+    x = randn((2, 96, 626), 400).to(DEV)
+    wa = WeightAverager(net)
+    with torch.no_grad():
+        _ = wa.net_swa(x)                                  # fills the operand caches of the copy
+        snaps = []
+        for k in range(3):
+            for p in net.parameters():
+                p.add_(0.01 * (k + 1))
+            snaps.append({n: p.detach().clone() for n, p in net.named_parameters()})
+            wa.update()
+        for n, p in wa.net_swa.named_parameters():
+            mean = (snaps[0][n] + snaps[1][n] + snaps[2][n]) / 3
+            assert torch.allclose(p, mean, rtol=1e-6, atol=1e-7), n
+        ref = get_maest("discogs-maest-10s-pw-129e", pretrained=False, precision="fp32")
+        ref.load_state_dict(wa.net_swa.state_dict())
+        ref = ref.to(DEV).eval()
+        a, b = wa.net_swa(x)[0], ref(x)[0]
+        assert torch.equal(a, b)
+        sd = wa.state_dict()["state_dict"]
+        assert "net_swa.blocks.0.attn.qkv.weight" in sd and "net.blocks.0.attn.qkv.weight" in sd
+    rng = np.random.Generator(np.random.PCG64(9))
+    y = (rng.random((200, 40)) < 0.2).astype(np.float32); y[0] = 1; y[1] = 0
+    s = rng.random((200, 40)).astype(np.float32)
+    ap = M.macro_average_precision(torch.from_numpy(y).to(DEV), torch.from_numpy(s).to(DEV))
+    roc = M.macro_roc_auc(torch.from_numpy(y).to(DEV), torch.from_numpy(s).to(DEV))
+    assert abs(ap - skm.average_precision_score(y, s, average="macro")) < 1e-9
+    assert abs(roc - skm.roc_auc_score(y, s, average="macro")) < 1e-9
