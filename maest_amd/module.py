@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import ops
 from .maest import get_maest
-from .mixup import my_mixup
+from .augment import my_mixup
 
 
 class _BCEWithLogitsFn(torch.autograd.Function):

@@ -144,12 +144,19 @@ def test_product_never_imports_the_oracle():
 
 
 def test_mixup_draw_semantics():
-    from maest_amd.mixup import my_mixup
+    from maest_amd.augment import my_mixup
     torch.manual_seed(0)
     np.random.seed(0)
     perm, lam = my_mixup(64, 0.3)
     assert sorted(perm.tolist()) == list(range(64))
     assert lam.dtype == torch.float32 and float(lam.min()) >= 0.5 and float(lam.max()) <= 1.0
+    # same RNG consumption and float32 arithmetic as the reference helper (helpers/mixup.py:5-12)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    want_perm = torch.randperm(64)
+    b = np.random.beta(0.3, 0.3, 64).astype(np.float32)
+    want = np.concatenate([b[:, None], 1 - b[:, None]], 1).max(1)
+    assert torch.equal(perm, want_perm) and np.array_equal(lam.numpy(), want)
 
 
 def test_spec_masking_draw_ranges():
