@@ -111,6 +111,7 @@ class _Weights:
 
     def __init__(self):
         self._cache = {}
+        self.epoch = 0          # bumped whenever every copy is dropped (part of the hipGraph cache key)
 
     def get(self, p: torch.Tensor, dtype, transposed=False, pad_cols_to: int = 0):
         key = (id(p), dtype, transposed, pad_cols_to)
@@ -157,6 +158,7 @@ class _Weights:
 
     def clear(self):
         self._cache.clear()
+        self.epoch += 1
 
 
 def _split_k(n_out: int, k_out: int, tokens: int) -> int:
@@ -182,6 +184,7 @@ class _Engine:
         self.m = model
         self.w = _Weights()
         self.overlap_wgrad = True
+        self._weights_dirty = False
         self._side = {}
 
     def _grad_layout(self):
@@ -210,6 +213,13 @@ class _Engine:
         N = 2 + P
         M = B * N
         ctx = {"B": B, "N": N, "toffset": toffset, "tok_ft": tok_ft, "dt": dt} if save else None
+        # Operand copies are keyed on the parameters' version counters, but FUSED optimizers (torch.optim.AdamW(...,
+        # fused=True), multi-tensor kernels in general) update parameters in place WITHOUT bumping them -- a stale
+        # bf16 copy then keeps training on the initial weights.  So every training-mode forward recasts everything
+        # (one 0.24 ms launch for the 48 block matrices), and the first eval forward after one does too.
+        if save or self._weights_dirty:
+            W.clear()
+        self._weights_dirty = bool(save)
         W.refresh([lin.weight for blk in m.blocks for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)],
                   dt, with_t=save)
 
@@ -713,8 +723,11 @@ class MAEST(nn.Module):
         return self
 
     def _graph_forward(self, x3, dt, kw):
+        if self._engine._weights_dirty:                  # a training step happened since the last eval forward
+            self._engine.w.clear()
+            self._engine._weights_dirty = False
         key = (tuple(x3.shape), dt, kw["toffset"], int(kw["tok_ft"].shape[0]), str(x3.device),
-               sum(p._version for p in self.parameters()))
+               sum(p._version for p in self.parameters()), self._engine.w.epoch)
         st = self._graphs.get(key)
         if st is None:                                   # first call: eager (fills the operand-copy caches)
             if len(self._graphs) >= 8:

@@ -364,3 +364,31 @@ def test_weight_averager_and_device_metrics():
     roc = M.macro_roc_auc(torch.from_numpy(y).to(DEV), torch.from_numpy(s).to(DEV))
     assert abs(ap - skm.average_precision_score(y, s, average="macro")) < 1e-9
     assert abs(roc - skm.roc_auc_score(y, s, average="macro")) < 1e-9
+
+
+def test_short_training_run_bf16_tracks_fp32():
+    """Beyond single-step parity: 25 AdamW steps on a fixed synthetic batch (mixup + patchout on, same seeds) --
+    the loss must fall, and the bf16 perf mode must follow the fp32 parity mode's loss curve."""
+    curves = {}
+    for precision in ("fp32", "bf16"):
+        torch.manual_seed(11)
+        np.random.seed(11)
+        net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision=precision).train()
+        mod = Module(net=net, mixup_alpha=0.3, lr=1e-4)
+        opt = mod.configure_optimizers()
+        x = randn((16, 1, 96, 626), 500).to(DEV)
+        rng = np.random.Generator(np.random.PCG64(501))
+        y = torch.from_numpy((rng.random((16, 400)) < 0.02).astype(np.float32)).to(DEV)
+        losses = []
+        for it in range(25):
+            loss = mod.training_step((x, None, y), it)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(loss.item())
+        curves[precision] = np.array(losses)
+    f, b = curves["fp32"], curves["bf16"]
+    print("fp32 loss", f[[0, 5, 12, 24]], "bf16 loss", b[[0, 5, 12, 24]])
+    assert f[-1] < 0.5 * f[0], "25 AdamW steps must at least halve the BCE loss of a fixed batch"
+    assert np.all(np.isfinite(b))
+    assert np.max(np.abs(b - f) / f) < 0.03, f"bf16 loss curve deviates from fp32 by {np.max(np.abs(b - f) / f):.3f}"
