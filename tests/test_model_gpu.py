@@ -392,3 +392,37 @@ def test_short_training_run_bf16_tracks_fp32():
     assert f[-1] < 0.5 * f[0], "25 AdamW steps must at least halve the BCE loss of a fixed batch"
     assert np.all(np.isfinite(b))
     assert np.max(np.abs(b - f) / f) < 0.03, f"bf16 loss curve deviates from fp32 by {np.max(np.abs(b - f) / f):.3f}"
+
+
+def test_three_adamw_steps_match_the_oracle_fp32():
+    """Multi-step parity: three training steps (pinned mixup / patchout draws, AdamW) on the device in fp32 parity
+    mode against the same three steps of the oracle on the host -- exercises the weight-operand refresh."""
+    sd = O.make_state_dict(625, seed=77)
+    net = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30, precision="fp32")
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    mod = Module(net=net, mixup_alpha=0.3, lr=1e-3)
+    opt = mod.configure_optimizers()
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt_o = torch.optim.AdamW([v for k, v in sdo.items() if not k.startswith("head_dist")], lr=1e-3, betas=(0.9, 0.999),
+                              eps=1e-08, weight_decay=1e-4)
+    x = randn((2, 1, 96, 626), 700)
+    rng = np.random.Generator(np.random.PCG64(701))
+    y = torch.from_numpy((rng.random((2, 400)) < 0.02).astype(np.float32))
+    for it in range(3):
+        perm = torch.tensor([1, 0])
+        lam = torch.from_numpy(rng.uniform(0.5, 1.0, 2).astype(np.float32))
+        keep = sorted(rng.permutation(62)[:32].tolist())
+        loss = mod.training_step((x.to(DEV), None, y.to(DEV)), it, _mixup=(perm, lam), _patchout=(0, torch.tensor(keep)))
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        want, _ = O.training_loss(x, y, sdo, perm, lam, toffset=0, t_keep=keep)
+        want.backward()
+        opt_o.step()
+        opt_o.zero_grad()
+        rel = abs(loss.item() - want.item()) / abs(want.item())
+        print(f"step {it}: loss {loss.item():.6f} oracle {want.item():.6f} rel {rel:.2e}")
+        assert rel < 1e-3, (it, loss.item(), want.item())
+    for n in ("blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "patch_embed.proj.weight", "head.1.weight"):
+        assert rel_err(dict(net.named_parameters())[n], sdo[n].detach()) < 1e-3, n
