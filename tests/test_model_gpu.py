@@ -426,3 +426,25 @@ def test_three_adamw_steps_match_the_oracle_fp32():
         assert rel < 1e-3, (it, loss.item(), want.item())
     for n in ("blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "patch_embed.proj.weight", "head.1.weight"):
         assert rel_err(dict(net.named_parameters())[n], sdo[n].detach()) < 1e-3, n
+
+
+@pytest.mark.parametrize("B,T", [(1, 16), (1, 25), (3, 36), (5, 333), (7, 59), (1, 626)])
+def test_odd_input_sizes_match_the_oracle(B, T):
+    """Minimum-length, ragged and tiny-batch inputs (11 .. 560 tokens) through the full eval path and two
+    early-exit depths, fp32 parity mode vs the oracle; the bf16 mode on the same input stays within its band."""
+    sd = O.make_state_dict(625, seed=3)
+    net = get_maest("discogs-maest-10s-pw-129e", pretrained=False, precision="fp32")
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    x = randn((B, 1, 96, T), 900 + T)
+    want, wf = O.forward(x, sd, (96, 625))
+    with torch.no_grad():
+        got, gf = net(x.to(DEV))
+        assert rel_err(got, want) < 1e-3 and rel_err(gf, wf) < 1e-3
+        for blk in (0, 11):
+            _, emb = net(x.to(DEV), transformer_block=blk)
+            _, we = O.forward(x, sd, (96, 625), transformer_block=blk)
+            assert rel_err(emb, we) < 1e-3, blk
+        net.precision = "bf16"
+        got16, _ = net(x.to(DEV))
+        assert rel_err(got16, want) < 3e-2
