@@ -448,3 +448,33 @@ def test_odd_input_sizes_match_the_oracle(B, T):
         net.precision = "bf16"
         got16, _ = net(x.to(DEV))
         assert rel_err(got16, want) < 3e-2
+
+
+@pytest.mark.parametrize("B,T,po", [(1, 100, 3), (3, 333, 10), (2, 46, 1), (1, 626, 55)])
+def test_odd_size_training_step_matches_the_oracle(B, T, po):
+    """Loss and EVERY parameter gradient of a training step at ragged sizes (29 .. 200 tokens, random time-table
+    offset, batch 1) against the oracle, fp32 parity mode."""
+    rng = np.random.Generator(np.random.PCG64(B * 1000 + T))
+    sd = O.make_state_dict(625, seed=B * 1000 + T)
+    net = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=po, precision="fp32")
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    mod = Module(net=net, mixup_alpha=0.3)
+    x = torch.from_numpy(rng.standard_normal((B, 1, 96, T), dtype=np.float32))
+    y = torch.from_numpy((rng.random((B, 400)) < 0.02).astype(np.float32))
+    perm = torch.from_numpy(rng.permutation(B))
+    lam = torch.from_numpy(rng.uniform(0.5, 1, B).astype(np.float32))
+    Tp = (T - 16) // 10 + 1
+    keep = sorted(rng.permutation(Tp)[: Tp - po].tolist())
+    toff = int(rng.integers(0, 62 - Tp + 1))
+    loss = mod.training_step((x.to(DEV), None, y.to(DEV)), 0, _mixup=(perm, lam), _patchout=(toff, torch.tensor(keep)))
+    loss.backward()
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want, _ = O.training_loss(x, y, sdo, perm, lam, toffset=toff, t_keep=keep)
+    want.backward()
+    assert abs(loss.item() - want.item()) < 1e-5 * abs(want.item())
+    for n, p in net.named_parameters():
+        if sdo[n].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert rel_err(p.grad, sdo[n].grad) < 1e-3, n
