@@ -220,8 +220,11 @@ class _Engine:
         if save or self._weights_dirty:
             W.clear()
         self._weights_dirty = bool(save)
-        W.refresh([lin.weight for blk in m.blocks for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)],
-                  dt, with_t=save)
+        mats = [lin.weight for blk in m.blocks for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)]
+        mats += [m.patch_embed.proj.weight, m.head[1].weight]
+        if m.distilled_type == "separated":
+            mats.append(m.head_dist.weight)
+        W.refresh(mats, dt, with_t=save)
 
         cols = ops.patch_im2col(x3, tok_ft, dt, perm=perm, lam=lam)
         patches = ops.gemm_nt(cols, W.get(m.patch_embed.proj.weight, dt), m.patch_embed.proj.bias,
