@@ -490,3 +490,27 @@ def test_data_parallel_two_ranks_sharing_the_gpu():
     r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "weights identical after 3 steps" in r.stdout
+
+
+def test_30s_training_step_matches_the_oracle_fp32():
+    """BASELINE configs[3] shape per clip: 1876 frames, s_patchout_t = 90 -> 875 tokens (14 key tiles, 7 query
+    blocks in the attention kernels), one clip, loss and gradients against the oracle."""
+    rng = np.random.Generator(np.random.PCG64(3030))
+    sd = O.make_state_dict(1875, seed=3030)
+    net = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=1875, s_patchout_t=90, precision="fp32")
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    mod = Module(net=net, mixup_alpha=0.0)
+    x = torch.from_numpy(rng.standard_normal((1, 1, 96, 1876), dtype=np.float32))
+    y = torch.from_numpy((rng.random((1, 400)) < 0.02).astype(np.float32))
+    Tp = (1876 - 16) // 10 + 1
+    keep = sorted(rng.permutation(Tp)[: Tp - 90].tolist())
+    loss = mod.training_step((x.to(DEV), None, y.to(DEV)), 0, _patchout=(0, torch.tensor(keep)))
+    loss.backward()
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want, _ = O.training_loss(x, y, sdo, None, None, toffset=0, t_keep=keep)
+    want.backward()
+    assert abs(loss.item() - want.item()) < 1e-5 * abs(want.item())
+    for n in ("blocks.0.attn.qkv.weight", "blocks.6.attn.proj.weight", "blocks.11.mlp.fc1.weight", "time_new_pos_embed",
+              "patch_embed.proj.weight", "blocks.3.norm2.weight"):
+        assert rel_err(dict(net.named_parameters())[n].grad, sdo[n].grad) < 1e-3, n
