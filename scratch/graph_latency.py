@@ -3,7 +3,7 @@ sys.path.insert(0, ".")
 from maest_amd import get_maest
 dev = "cuda"
 net = get_maest("discogs-maest-10s-pw-129e", pretrained=False, precision="bf16").to(dev).eval()
-for B in (1, 2, 8, 32):
+for B in (1, 2, 4, 8, 16):
     x = torch.randn(B, 96, 626, device=dev)
     res = {}
     for mode in ("eager", "graph"):

@@ -26,15 +26,17 @@ def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype, monkeypatch):
     """The 64-byte-slice kernels of gemm256.hip: 256x128 two-per-CU (N % 256 != 0) and 256x256 (variant 1)."""
     # 6 K slices: the 3- / 4-deep rings wrap
     K = 96 if dtype == torch.float32 else 192
+    monkeypatch.setenv("MAEST_GEMM_MIN_M", "512")
     KC.case_gemm(emu, dtype, 512, 128, K, identity=False)   # (orientation is pinned by the small-shape cases)
     monkeypatch.setenv("MAEST_GEMM_VARIANT", "1")
     KC.case_gemm(emu, dtype, 512, 256, K, identity=False)
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_emu_gemm_256_tile_full_line_stages(emu, dtype):
+def test_emu_gemm_256_tile_full_line_stages(emu, dtype, monkeypatch):
     """gemm_nt256w_kernel (the default for M >= 512, N % 256 == 0): 128-byte K stages through a 5-buffer unit
     ring (6 stages: the ring wraps)."""
+    monkeypatch.setenv("MAEST_GEMM_MIN_M", "512")
     KC.case_gemm(emu, dtype, 512, 256, 192 if dtype == torch.float32 else 384, identity=False)   # 6 stages > 5 buffers
 
 

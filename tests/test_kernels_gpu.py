@@ -18,6 +18,14 @@ def test_gemm(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(1120, 2304, 768), (2560, 768, 3072), (1024, 768, 256)])
+def test_gemm_big_tile_kernels_at_small_m(dtype, shape, monkeypatch):
+    """the 256-row-tile kernels (normally taken from 8192 rows up) forced onto small and ragged M"""
+    monkeypatch.setenv("MAEST_GEMM_MIN_M", "512")
+    KC.case_gemm(DEV, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("shape", [(1121, 768, 3072), (2300, 2304, 768), (64, 400, 768), (7, 519 + 57, 768), (5184, 768, 256), (4640, 768, 3072), (2320, 2304, 768), (2304, 768, 768)])
 def test_gemm_tn(dtype, shape):
     K, M, N = shape
