@@ -683,7 +683,10 @@ class MAEST(nn.Module):
             toffset, tok_ft = self._resolve_tokens(Fp, Tp, _patchout)
             if tok_ft.shape[0] < 1:
                 raise Exception("patchout removed every patch token")
-            tok_ft = tok_ft.to(x3.device)
+            if x3.is_cuda and not tok_ft.is_cuda:     # training: a fresh list every step; no stream-draining copy
+                tok_ft = tok_ft.contiguous().pin_memory().to(x3.device, non_blocking=True)
+            else:
+                tok_ft = tok_ft.to(x3.device)
             if not self.training and _patchout is None:
                 self._tok_cache[tok_key] = (toffset, tok_ft)
         perm = lam = None

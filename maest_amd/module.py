@@ -34,6 +34,24 @@ class _BCEWithLogitsFn(torch.autograd.Function):
         return dz * g, None, None, None, None
 
 
+def _mix_to_device(mix, device):
+    """(perm, lam) host draws -> int32 / fp32 device tensors through pinned memory, without a stream-draining
+    synchronous copy; done ONCE per step (the forward and the loss both consume them)."""
+    if mix is None:
+        return None
+    perm, lam = mix
+    dev = torch.device(device)
+
+    def put(t, dtype):
+        t = t.to(dtype)
+        if t.device == dev:
+            return t.contiguous()
+        if dev.type == "cuda" and t.device.type == "cpu":
+            return t.contiguous().pin_memory().to(dev, non_blocking=True)
+        return t.to(dev).contiguous()
+    return put(perm, torch.int32), put(lam, torch.float32)
+
+
 def bce_with_logits(z, y, perm=None, lam=None, weight=1.0):
     y = y.to(device=z.device, dtype=torch.float32).contiguous()
     if perm is not None:
@@ -69,6 +87,7 @@ class Module(nn.Module):
         x, f, y = batch
         batch_size = len(y)
         mix = _mixup if _mixup is not None else self._mixup(batch_size)
+        mix = _mix_to_device(mix, x.device)
         y_hat, embed = self.forward(x, _mixup=mix, _patchout=_patchout)
         perm, lam = mix if mix is not None else (None, None)
         return bce_with_logits(y_hat, y, perm, lam)
@@ -90,6 +109,7 @@ class TeacherStudentModule(Module):
         x, f, y, y_teacher = batch
         batch_size = len(y)
         mix = _mixup if _mixup is not None else self._mixup(batch_size)
+        mix = _mix_to_device(mix, x.device)
         y_hat, y_hat_teacher, _ = self.forward(x, _mixup=mix, _patchout=_patchout)
         perm, lam = mix if mix is not None else (None, None)
         loss_standard = bce_with_logits(y_hat, y, perm, lam, weight=0.5)
