@@ -40,7 +40,7 @@ def flops_per_clip_fwd(N, Tk, C=400):
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE cannot be collected by bench.py on itself); None when the file is absent."""
-    path = os.path.join(REPO, "profiles", "r01f_pmc_traffic.json")
+    path = os.path.join(REPO, "profiles", "r01g_pmc_traffic.json")
     try:
         with open(path) as f:
             return json.load(f)["traffic_bytes_per_launch"]
