@@ -1180,6 +1180,9 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();
     MAEST_WAIT_VMCNT(0);
 
+#ifdef MAEST_ABLATE_NO_EPI
+    if (acc[0][0][0] != 123.456f) return;
+#endif
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int col = j0 + wn * 64 + b * 32 + (lane & 31);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # build (locally) or run (on the GPU box) ablation variants of the gemm256.hip main loops (MAEST_ABLATE_* hooks)
 cd $(dirname $0)
-VARS="FULL NO_DMA NO_DSREAD NO_MFMA NO_DMA_NO_DSREAD"
+VARS="FULL NO_EPI"
 if [ "$1" = build ]; then
   for v in $VARS; do
     d=""
