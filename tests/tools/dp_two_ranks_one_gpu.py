@@ -54,7 +54,11 @@ def worker(rank, world, port, out):
 
 if __name__ == "__main__":
     out = "/tmp/dp_out"; os.makedirs(out, exist_ok=True)
-    mp.spawn(worker, args=(2, 29577, out), nprocs=2, join=True)
+    import socket
+    with socket.socket() as sk:                      # a free rendezvous port on this box
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
     r0, r1 = torch.load(f"{out}/rank0.pt"), torch.load(f"{out}/rank1.pt")
     for n in r0["w"]:
         assert torch.equal(r0["w"][n], r1["w"][n]), f"weights diverged across ranks: {n}"
