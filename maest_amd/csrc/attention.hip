@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(c
     const int head = blk.head, b = blk.b;
     const int q0 = blk.rb * 128 + wave * 32;
     const int q = q0 + (lane & 31);
+    const bool wave_active = q0 < N;   // wave-uniform
     const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
     const T* kbase = qbase + NHEADS * HD;
     const T* vbase = qbase + 2 * NHEADS * HD;
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(c
             tile_load<T>(kr, kbase, QKV_LD, (kt + 1) * 64, N, tid);
             tile_load<T>(vr, vbase, QKV_LD, (kt + 1) * 64, N, tid);
         }
+        if (wave_active) {   // waves whose 32 queries are all padding only help staging the tiles
         // S^T[key][q]
         f32x16_t s[2];
 #pragma unroll
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(c
         // O^T[d][q] += V^T[d][key] P^T[key][q]   (V^T gathered from the row-major V tile)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) mma_transposed<T>(o, v_lds, kb * 32, lane, s[kb]);
+        }
         if (more) {
             char* nk = smem + ((kt + 1) & 1) * 2 * C::TILE;
             tile_store_rows<T>(kr, nk, tid);
@@ -373,6 +376,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
     row_frags_load<T>(kf, kbase, QKV_LD, key, N, h);
     row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
     const bool key_ok = key < N;
+    const bool wave_active = blk.rb * 128 + wave * 32 < N;   // wave-uniform: all 32 keys of this wave are padding otherwise
     const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
 
     f32x16_t dk[2], dv[2];
@@ -413,6 +417,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
         const float* dl_lds = lse_lds + 64;
         const bool more = qt + 1 < ntiles;
         if (more) load_tile(qt + 1);
+        if (wave_active) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16_t s, dp;
@@ -441,6 +446,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
             }
             mma_transposed<T>(dv, do_lds, qb * 32, lane, s);   // dV^T[d][key] += dO^T[d][q] P[q][key]
             mma_transposed<T>(dk, q_lds, qb * 32, lane, dp);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+        }
         }
         if (more) store_tile((qt + 1) & 1);
         __syncthreads();
@@ -473,6 +479,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
     row_frags_load<T>(qf, qbase, QKV_LD, q, N, h);
     row_frags_load<T>(dof, dobase, OUT_LD, q, N, h);
     const bool q_ok = q < N;
+    const bool wave_active = blk.rb * 128 + wave * 32 < N;   // wave-uniform
     const int qc = q_ok ? q : N - 1;
     const float lse_q = lse[((int64_t)b * NHEADS + head) * N + qc] * LOG2E;
     const float dl_q = delta[((int64_t)b * NHEADS + head) * N + qc];
@@ -500,6 +507,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
             tile_load<T>(kr, kbase, QKV_LD, (kt + 1) * 64, N, tid);
             tile_load<T>(vr, vbase, QKV_LD, (kt + 1) * 64, N, tid);
         }
+        if (wave_active) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16_t s, dp;
@@ -523,6 +531,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
                 dp[r] = ds[0]; dp[r + 1] = ds[1];   // dS^T (unscaled)
             }
             mma_transposed<T>(dq, k_lds, kb * 32, lane, dp);   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+        }
         }
         if (more) {
             char* nk = smem + ((kt + 1) & 1) * 2 * C::TILE;
