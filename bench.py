@@ -20,6 +20,8 @@ that also carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,63 +39,125 @@ def flops_per_clip_fwd(N, Tk, C=400):
     return 12 * per_block + 2 * (9 * Tk) * 256 * 768 + 2 * 768 * C
 
 
+PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"
+
+
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE cannot be collected by bench.py on itself); None when the file is absent."""
-    path = os.path.join(REPO, "profiles", "r01g_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
-    except Exception:
-        return None
+    """(HBM bytes per launch of the dominant kernel, where that number comes from).  FETCH_SIZE / WRITE_SIZE cannot
+    be collected by bench.py on itself: the figure is read from the committed summary of separate rocprofv3 --pmc
+    passes over THIS command (scratch/profile_round.sh), i.e. a constant from an earlier run of the same binary,
+    and is labelled as such in the JSON line (`traffic_source`).  (None, reason) when the file is absent."""
+    for name in (PMC_TRAFFIC_FILE, "profiles/r01g_pmc_traffic.json"):
+        try:
+            with open(os.path.join(REPO, name)) as f:
+                return json.load(f)["traffic_bytes_per_launch"], (
+                    f"{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed "
+                    "(2 x FETCH_SIZE + WRITE_SIZE per launch); not measured by this run")
+        except Exception:
+            continue
+    return None, "no committed PMC summary found"
 
 
-def cpu_baseline_infer(batch, T, steps=2):
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU
+    (what Lightning does for the reference, ex_maest.py:49,57).  Rank 0 of the child job prints the JSON line."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def time_mel_kernel(dev, clips, samples, reps=10):
+    """logmel_kernel (csrc/mel.hip) alone, HIP events on its launch stream: algorithmic bytes = fp32 waveform in +
+    fp32 [96, T] out (0.88 MB per 10 s clip) over the average launch time, against the 8 TB/s HBM peak."""
+    from maest_amd.melspectrogram import MelSpectrogram
+    mel = MelSpectrogram()
+    w = torch.rand((clips, samples), device=dev) * 2 - 1
+    for _ in range(2):
+        out = mel(w)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        out = mel(w)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = w.numel() * 4 + out.numel() * 4
+    return {"kernel": "logmel_kernel (framing + Hann + 512-pt FFT + |.|^2 + mel + logC + z-norm, one pass)",
+            "bound": "hbm", "clips": clips, "samples": samples, "frames": int(out.shape[-1]),
+            "avg_launch_ms": round(ms, 4), "algorithmic_bytes": nbytes,
+            "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4), "clips_per_s": round(clips / (ms * 1e-3), 0)}
+
+
+def _median_times(fn, steps):
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        fn(it)
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    return float(np.median(times))
+
+
+def cpu_baseline_infer(batch, T, steps=3):
     """Oracle eval forward on the host cores (B = 8, N = 560)."""
     from oracle import maest_oracle as O
-    sd = O.make_state_dict(625, seed=1234)
+    img_t = 625 if T <= 640 else (T // 5) * 5
+    sd = O.make_state_dict(img_t, seed=1234)
     rng = np.random.Generator(np.random.PCG64(3))
     x = torch.from_numpy(rng.standard_normal((batch, 96, T), dtype=np.float32))
-    times = []
-    with torch.no_grad():
-        for it in range(steps + 1):
-            t0 = time.perf_counter()
-            O.forward(x, sd, (96, 625), melspectrogram_input=True)
-            if it > 0:
-                times.append(time.perf_counter() - t0)
-    t = float(np.median(times))
+
+    def one(it):
+        with torch.no_grad():
+            O.forward(x, sd, (96, img_t), melspectrogram_input=True)
+    t = _median_times(one, steps)
     return {"value": round(batch / t, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle eval forward (fp32) batch={batch} T={T}; median of {steps} passes after 1 warm-up, "
                       f"{t:.2f} s/pass"}
 
 
-def cpu_baseline(batch, T, patchout, steps=2):
-    """Oracle training step (fwd + bwd + AdamW) on the host cores: the reference's algorithm."""
+def cpu_baseline(batch, T, patchout, steps=3, teacher_student=False, waveform=False):
+    """Oracle training step (fwd + bwd + AdamW) on the host cores: the reference's algorithm.  teacher_student:
+    C = 519, separated heads, (BCE + BCE) / 2 (models/module.py:280-316); waveform: the log-mel front end is part
+    of the step (BASELINE configs[4])."""
     from oracle import maest_oracle as O
     torch.manual_seed(0)
-    sd = {k: v.clone().requires_grad_(True) for k, v in O.make_state_dict(625, seed=1234).items()}
-    params = [v for k, v in sd.items() if not k.startswith("head_dist")]
+    img_t = 625 if T <= 640 else (T // 5) * 5
+    C = 519 if teacher_student else 400
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.make_state_dict(img_t, n_classes=C, seed=1234).items()}
+    params = [v for k, v in sd.items() if teacher_student or not k.startswith("head_dist")]
     opt = torch.optim.AdamW(params, lr=2e-5, weight_decay=1e-4)
     rng = np.random.Generator(np.random.PCG64(3))
-    x = torch.from_numpy(rng.standard_normal((batch, 1, 96, T), dtype=np.float32))
-    y = torch.from_numpy((rng.random((batch, 400)) < 0.00625).astype(np.float32))
+    if waveform:
+        wav = torch.from_numpy(rng.random((batch, (T - 1) * 256), dtype=np.float32) * 2 - 1)
+    else:
+        x = torch.from_numpy(rng.standard_normal((batch, 1, 96, T), dtype=np.float32))
+    y = torch.from_numpy((rng.random((batch, C)) < 2.5 / C).astype(np.float32))
+    yt = torch.from_numpy((rng.random((batch, C)) < 2.5 / C).astype(np.float32)) if teacher_student else None
     Tp = (T - 16) // 10 + 1
-    times = []
-    for it in range(steps + 1):
-        t0 = time.perf_counter()
+
+    def one(it):
         perm = torch.randperm(batch)
         lam = torch.from_numpy(np.maximum(b := rng.beta(0.3, 0.3, batch).astype(np.float32), 1 - b))
         keep = torch.randperm(Tp)[: Tp - patchout].sort().values.tolist()
-        loss, _ = O.training_loss(x, y, sd, perm, lam, toffset=0, t_keep=keep)
+        xin = O.logmel(wav).unsqueeze(1) if waveform else x
+        loss = O.training_loss(xin, y, sd, perm, lam, toffset=0, t_keep=keep, y_teacher=yt)[0]
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
-        if it > 0:
-            times.append(time.perf_counter() - t0)
-    t = float(np.median(times))
+    t = _median_times(one, steps)
+    what = ("oracle teacher-student training step (log-mel + fwd + bwd + AdamW, fp32)" if teacher_student
+            else "oracle training step (fwd+bwd+AdamW, fp32)")
     return {"value": round(batch / t, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle training step (fwd+bwd+AdamW, fp32) batch={batch} T={T} patchout={patchout}; "
-                      f"median of {steps} steps after 1 warm-up, {t:.2f} s/step"}
+            "sample": f"{what} batch={batch} T={T} patchout={patchout}; median of {steps} steps after 1 warm-up, "
+                      f"{t:.2f} s/step"}
 
 
 def main():
@@ -101,61 +165,78 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config 3: 256)")
-    ap.add_argument("--frames", type=int, default=626, help="mel frames per clip (10 s @ 16 kHz -> 626)")
-    ap.add_argument("--patchout", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 for the 10 s configs, 128 for ts)")
+    ap.add_argument("--frames", type=int, default=None, help="mel frames per clip (10 s @ 16 kHz -> 626; 30 s -> 1876)")
+    ap.add_argument("--patchout", type=int, default=None)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "ts"],
+                    help="train: BASELINE configs[2] (the headline metric); infer: configs[1]; ts: configs[4] "
+                         "(teacher-student, waveform -> HIP log-mel on the fly -> mixup -> 519-way separated heads, 30 s)")
+    ap.add_argument("--hip-graph", action="store_true", help="replay the forward from a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8, help="clips per oracle step of the CPU baseline (SURVEY 8d: B = 8)")
+    ap.add_argument("--cpu-batch", type=int, default=None, help="clips per oracle step of the CPU baseline (SURVEY 8d: B = 8)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--serial-kernels", action="store_true",
                     help="disable the side-stream overlap of weight-gradient GEMMs (for kernel profiling)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
 
     from maest_amd import get_maest, ops
     from maest_amd.dist import GradReducer, broadcast_parameters, init_from_env
-    from maest_amd.module import Module
+    from maest_amd.module import Module, TeacherStudentModule
 
     rank, local, world = init_from_env()
     if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} ...`")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
 
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)
-    B, T = args.batch, args.frames
-    train = args.mode == "train"
-    net = get_maest("passt_s_swa_p16_128_ap476" if train else "discogs-maest-10s-pw-129e", pretrained=False,
-                    input_t=(T // 5) * 5 if T > 640 else 625,   # time table: 62 columns for 10 s, 187 for the 30 s configs
-                    s_patchout_t=args.patchout if train else 0, precision=args.precision).to(dev)
+    ts = args.mode == "ts"
+    train = args.mode in ("train", "ts")
+    T = args.frames if args.frames is not None else (1876 if ts else 626)
+    B = args.batch if args.batch is not None else (128 if T > 640 else 256)
+    patchout = args.patchout if args.patchout is not None else ((90 if T > 640 else 30) if train else 0)
+    C = 519 if ts else 400
+    img_t = (T // 5) * 5 if T > 640 else 625      # time table: 62 columns for 10 s, 187 for the 30 s configs
+    arch = "discogs-maest-30s-pw-73e-ts" if ts else ("passt_s_swa_p16_128_ap476" if train else "discogs-maest-10s-pw-129e")
+    net = get_maest(arch, pretrained=False, input_t=img_t, n_classes=C, s_patchout_t=patchout,
+                    distilled_type="separated" if ts else "mean", precision=args.precision).to(dev)
     broadcast_parameters(net)
     if args.serial_kernels:
         net._engine.overlap_wgrad = False
-    mod = Module(net=net, mixup_alpha=0.3)
+    mod = (TeacherStudentModule if ts else Module)(net=net, mixup_alpha=0.3)
     Tp = (T - 16) // 10 + 1
-    Tk = Tp - (args.patchout if train else 0)
+    Tk = Tp - patchout
     N = 2 + 9 * Tk
 
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
-    x = torch.randn((B, 1, 96, T), generator=gen, device=dev)                   # synthetic z-normed log-mel
-    y = (torch.rand((B, 400), generator=gen, device=dev) < 0.00625).float()     # ~2.5 labels per clip
+    if ts:   # 30 s of synthetic 16 kHz audio per clip; the log-mel front end runs inside every step
+        x = torch.rand((B, (T - 1) * 256), generator=gen, device=dev) * 2 - 1
+    else:
+        x = torch.randn((B, 1, 96, T), generator=gen, device=dev)               # synthetic z-normed log-mel
+    y = (torch.rand((B, C), generator=gen, device=dev) < 2.5 / C).float()       # ~2.5 labels per clip
+    y_teacher = (torch.rand((B, C), generator=gen, device=dev) < 2.5 / C).float() if ts else None
 
     if train:
         net.train()
+        if args.hip_graph:
+            net.enable_hip_graph()
         opt = mod.configure_optimizers()
         reducer = None
         if world > 1:
-            reducer = GradReducer(net.named_parameters(), skip=("head_dist.weight", "head_dist.bias"))
+            skip = () if ts else ("head_dist.weight", "head_dist.bias")
+            reducer = GradReducer(net.named_parameters(), skip=skip)
             net._grad_sink = reducer
+        batch = (x, None, y, y_teacher) if ts else (x, None, y)
 
         def step():
             if reducer is not None:
                 reducer.reset()
-            loss = mod.training_step((x, None, y), 0)
+            loss = mod.training_step(batch, 0)
             loss.backward()
             if reducer is not None:
                 reducer.finish()
@@ -164,6 +245,8 @@ def main():
             return loss
     else:
         net.eval()
+        if args.hip_graph:
+            net.enable_hip_graph()
 
         def step():
             with torch.no_grad():
@@ -196,7 +279,9 @@ def main():
         # kernels are timed one at a time: with the wgrad GEMMs overlapping the dgrad chain on a second
         # stream, an event pair around one launch would also count the time it shares the CUs with another
         net._engine.overlap_wgrad = False
-        with ops.KernelTimer(kinds={"maest_gemm_nt", "maest_gemm_tn", "maest_attn_fwd", "maest_attn_bwd"}) as timer:
+        net.enable_hip_graph(False)
+        with ops.KernelTimer(kinds={"maest_gemm_nt", "maest_gemm_tn", "maest_attn_fwd", "maest_attn_bwd",
+                                    "maest_layernorm_fwd", "maest_layernorm_bwd", "maest_logmel"}) as timer:
             for _ in range(args.steps):
                 step()
         torch.cuda.synchronize()
@@ -204,22 +289,30 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        fwd = flops_per_clip_fwd(N, Tk)
+        fwd = flops_per_clip_fwd(N, Tk, C) + (2 * 768 * C if ts else 0)
         step_flops = (3 if train else 1) * fwd * B
+        secs = "10s" if T <= 640 else "30s"
+        if ts:
+            workload = ("discogs-maest-30s-pw-73e-ts teacher-student training step (BASELINE configs[4]): waveform -> "
+                        "HIP log-mel on the fly -> mixup -> fwd (separated heads) -> (BCE + BCE)/2 -> bwd -> AdamW")
+        elif train:
+            workload = ("maest_10s_random_weights_pretrain training step (BASELINE configs[2]): mixup + fwd + BCE + bwd + AdamW"
+                        if T <= 640 else f"30 s clips ({T} frames): maest_30s_from_passt_pretrain-shaped training step "
+                        "(BASELINE configs[3], per-GPU shape)")
+        else:
+            workload = ("discogs-maest-10s-pw-129e inference (BASELINE configs[1])" if T <= 640
+                        else f"30 s clips ({T} frames): discogs-maest-30s inference")
         out = {
-            "metric": ("clips/sec (10s@16kHz, 96-mel) MAEST-10s " if T <= 640 else "clips/sec (30s@16kHz, 96-mel) MAEST-30s ")
-                      + ("fwd+bwd" if train else "fwd"),
+            "metric": f"clips/sec ({secs}@16kHz, 96-mel) MAEST-{secs} " + ("fwd+bwd" if train else "fwd"),
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": (("maest_10s_random_weights_pretrain training step (BASELINE configs[2]): "
-                                     "mixup + fwd + BCE + bwd + AdamW" if train else
-                                     "discogs-maest-10s-pw-129e inference (BASELINE configs[1])") if T <= 640 else
-                                    (f"30 s clips ({T} frames): " + ("maest_30s_from_passt_pretrain-shaped training step "
-                                     "(BASELINE configs[3], per-GPU shape)" if train else "discogs-maest-30s inference"))),
-                       "arch": "passt_s_swa_p16_128_ap476 (DeiT-B distilled, 85.9M params), random init",
-                       "per_gpu_batch": B, "global_batch": B * world, "mel": [96, T],
-                       "s_patchout_t": args.patchout if train else 0, "tokens": N, "classes": 400,
+            "config": {"workload": workload,
+                       "arch": f"{arch} (DeiT-B distilled, 85.9M params), random init",
+                       "per_gpu_batch": B, "global_batch": B * world,
+                       "input": [B, (T - 1) * 256] if ts else [B, 96, T], "mel": [96, T],
+                       "s_patchout_t": patchout, "tokens": N, "classes": C,
+                       "hip_graph_forward": bool(args.hip_graph),
                        "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, overlapped)" if world > 1 else "")},
             "model_tflops_per_s": round(step_flops * world / (elapsed / args.steps) / 1e12, 1),
             "model_mfma_frac": round(step_flops / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -229,13 +322,13 @@ def main():
             g = summ.get("maest_gemm_nt")
             if g and g["ms"] > 0:
                 ach = g["work"] / (g["ms"] * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": ("maest_gemm_nt (gemm_nt256w_kernel<bf16>; gemm_nt_kernel<bf16> for the 2 small head GEMMs)"
+                peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
+                traffic, traffic_source = pmc_traffic()
+                out["roofline"] = {"bound": "mfma", "kernel": ("maest_gemm_nt (gemm_nt256w_kernel<bf16>; gemm_nt_kernel<bf16> for the small head GEMMs)"
                                               if args.precision == "bf16" else "maest_gemm_nt (fp32 MFMA)"),
-                                   "achieved": round(ach, 1),
-                                   "peak": PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
-                                   "unit": "TFLOP/s",
-                                   "frac": round(ach / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 4),
-                                   "traffic": pmc_traffic(),
+                                   "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                                   "frac": round(ach / peak, 4),
+                                   "traffic": traffic, "traffic_source": traffic_source,
                                    "launches_per_step": g["launches"] // args.steps,
                                    "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                                    "ms_per_step": round(g["ms"] / args.steps, 3),
@@ -260,10 +353,17 @@ def main():
                 out["attention_set"] = {"what": "12 x (QKV proj + QK^T + PV + out proj)" + (", fwd+bwd" if train else ", fwd"),
                                         "ms_per_step": round(set_ms, 3), "tflops": round(set_flops / set_ms / 1e9, 1),
                                         "mfma_frac": round(set_flops / set_ms / 1e9 / PEAK_BF16_TFLOPS, 4)}
+        if world == 1 and not args.no_kernel_timing:
+            # the HBM-bound front end of the path: the log-mel kernel on a full batch of waveforms
+            try:
+                out["mel"] = time_mel_kernel(dev, B, (T - 1) * 256)
+            except Exception as e:  # pragma: no cover
+                out["mel"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = (cpu_baseline(args.cpu_batch, T, args.patchout) if train
-                                       else cpu_baseline_infer(args.cpu_batch, T))
+                cb = args.cpu_batch if args.cpu_batch is not None else (8 if T <= 640 else 2)
+                out["cpu_baseline"] = (cpu_baseline(cb, T, patchout, teacher_student=ts, waveform=ts) if train
+                                       else cpu_baseline_infer(cb, T))
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MAEST_ABI_VERSION 1
+#define MAEST_ABI_VERSION 2
 
 #define MAEST_OK 0
 #define MAEST_ERR_INVALID 1 /* bad argument (shape / alignment / dtype) */
@@ -46,6 +46,19 @@ extern "C" {
 
 int maest_version(void);
 const char* maest_last_error(void);
+
+/* ---- process-wide tuning / test switches.  Thread-safe (atomics); the defaults are taken from the environment
+ * variables named below, which are read ONCE, at the first use of any switch.  restore_default != 0 ignores `value`.
+ *   MAEST_OPT_GEMM_MIN_M    (env MAEST_GEMM_MIN_M,    default 8192): smallest M routed to the 256-row-tile GEMMs
+ *   MAEST_OPT_GEMM_VARIANT  (env MAEST_GEMM_VARIANT,  default 0):    0 = full-line 256x256 kernel, 1 = 64-byte-slice
+ *                            256x256, 2 = 256x128 two-per-CU, 4 = 256-tile TN kernel at any qualifying shape
+ *   MAEST_OPT_GEMM_EPILOGUE (env MAEST_GEMM_EPILOGUE, default -1):   -1 = per-epilogue choice, 0/1/2 force a C-tile
+ *                            epilogue form of the full-line kernel */
+#define MAEST_OPT_GEMM_MIN_M 0
+#define MAEST_OPT_GEMM_VARIANT 1
+#define MAEST_OPT_GEMM_EPILOGUE 2
+int maest_set_option(int opt, int value, int restore_default);
+int maest_get_option(int opt, int* value);
 
 /* ---- K8, K10-K12, K13 head, K4 (im2col form) and their dgrad / wgrad ---------------------------
  * nn.Linear: models/maest.py:353,355,361,376 ; :197-199,203-206 ; :572,579 ; nn.Conv2d :238-240.
@@ -115,9 +128,14 @@ int maest_attn_bwd(const void* qkv, const void* out, const void* dout, const flo
  * patch tokens and dropped patches are never computed -- mathematically identical to compute-then-drop.
  * x: fp32 [B, F, T]; perm: int32 [B] or NULL; lam: fp32 [B] or NULL (x' = lam*x + (1-lam)*x[perm]).
  * tok_ft: int32 [P, 2] = (frequency patch index f, time patch index t) of each kept token, in sequence
- * order.  out: dtype [B*P, 256], row = b*P + j, col = ky*16 + kx, patch origin (10 f, 10 t). */
+ * order.  out: dtype [B*P, 256], row = b*P + j, col = ky*16 + kx, patch origin (10 f, 10 t).
+ * Optional K17 SpecMasking fused into the same load (helpers/spec_masking.py:27-33; the loader masks each clip
+ * before the batch is mixed up, discogs/datamodule.py:140-152): t_stripes int32 [B, n_t, 2] / f_stripes int32
+ * [B, n_f, 2] = (start, width) per clip, as in maest_spec_mask; a masked sample reads as 0.0 (for the clip and,
+ * with its own stripes, for its mixup partner).  n_t = n_f = 0 (pointers may be NULL) disables it. */
 int maest_patch_im2col(const float* x, int B, int F, int T, const int32_t* perm, const float* lam,
-                       const int32_t* tok_ft, int P, void* out, int dtype, void* stream);
+                       const int32_t* tok_ft, int P, const int32_t* t_stripes, int n_t,
+                       const int32_t* f_stripes, int n_f, void* out, int dtype, void* stream);
 
 /* ---- K5 + K6: positional add + token assembly (models/maest.py:645-675, 769, 785-796) ------------
  * patches: fp32 [B*P, 768] (conv output incl. bias); x0: fp32 [B, 2 + P, 768]
@@ -188,6 +206,13 @@ int maest_augment_mel(const float* wave, int B, int S, const float* window, cons
 
 /* ---- optimizer-side helper: scale a flat fp32 gradient bucket (after the RCCL all-reduce) */
 int maest_scale_f32(float* x, int64_t n, float alpha, void* stream);
+/* x *= *alpha_dev with the factor read from DEVICE memory: the upstream gradient of the scalar loss applied to the
+ * logit gradients (autograd of F.binary_cross_entropy_with_logits, models/module.py:90) without a host round trip */
+int maest_scale_dev_f32(float* x, int64_t n, const float* alpha_dev, void* stream);
+/* dst[r, c] = cast(src[r, c]) for c < cols and 0 for cols <= c < ld_dst: fp32 rows (the logit gradients [B, C]) ->
+ * zero-padded operand rows of the head's dgrad / wgrad GEMMs (K must be a multiple of 64 there) */
+int maest_cast_rows(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols, int dtype,
+                    void* stream);
 /* stochastic weight averaging of n parameters in one launch (HOST arrays of device pointers / sizes):
  * avg[i] += (cur[i] - avg[i]) * inv_count   (Lightning StochasticWeightAveraging.avg_fn, helpers/swa_callback.py) */
 int maest_swa_update_multi(int n, float* const* avg, const float* const* cur, const int64_t* numel,

@@ -31,7 +31,7 @@ SIGNATURES = {
     "maest_layernorm_bwd": [_P, _L, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
     "maest_attn_fwd": [_P, _P, _P, _I, _I, _I, _F, _P],
     "maest_attn_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
-    "maest_patch_im2col": [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P],
+    "maest_patch_im2col": [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "maest_token_assemble": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P, _P],
     "maest_token_assemble_bwd": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "maest_head_pool_fwd": [_P, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P],
@@ -47,7 +47,14 @@ SIGNATURES = {
     "maest_melfile_assemble": [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],
     "maest_logmel": [_P, _I, _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _P],
     "maest_scale_f32": [_P, _L, _F, _P],
+    "maest_scale_dev_f32": [_P, _L, _P, _P],
+    "maest_cast_rows": [_P, _L, _P, _L, _I, _I, _I, _P],
+    "maest_set_option": [_I, _I, _I],
+    "maest_get_option": [_I, _P],
 }
+
+ABI_VERSION = 2
+OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2}
 
 _lib = None
 _host_emulation = False  # set only by tests/emu
@@ -79,7 +86,7 @@ def load():
                 "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
                 "maest_amd has no CPU fallback.")
         _lib = _bind(ctypes.CDLL(LIB_PATH))
-        if _lib.maest_version() != 1:
+        if _lib.maest_version() != ABI_VERSION:
             raise MaestHipError("libmaest_hip.so ABI version mismatch")
     return _lib
 

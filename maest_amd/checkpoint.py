@@ -80,7 +80,9 @@ _RENAMES = [("blocks.", _AST + "encoder.layer."), ("cls_token", _AST + "embeddin
 
 
 def to_hf_ast_state_dict(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-    sd = {k: v for k, v in state_dict.items() if not k.startswith("head_dist.")}
+    # head_dist is dropped like the reference does (push_to_hub.py:111-115); the mel front end's constant tables
+    # (torchaudio buffers) are no AST weights either
+    sd = {k: v for k, v in state_dict.items() if not k.startswith(("head_dist.", "melspectrogram."))}
     pos = (sd.pop("freq_new_pos_embed") + sd.pop("time_new_pos_embed")).flatten(2, 3).transpose(1, 2)
     sd[_AST + "embeddings.position_embeddings"] = torch.cat((sd.pop("new_pos_embed"), pos), dim=1)
     for a, b in _RENAMES:                            # same order as the reference: "norm." before "norm1."

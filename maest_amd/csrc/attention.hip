@@ -547,12 +547,8 @@ template <typename T>
 static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, hipStream_t st) {
     using C = AttnCfg<T>;
     const int smem_bytes = 4 * C::TILE;
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-        once = true;
-    }
+    static DeviceOnce once;
+    ensure_dynamic_lds(once, &attn_fwd_kernel<T>, smem_bytes);
     dim3 grid(((N + 127) / 128) * NHEADS * B);
     hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, B, N, scale);
     return check_launch("maest_attn_fwd");
@@ -564,14 +560,9 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
     using C = AttnCfg<T>;
     const int smem_a = 2 * (2 * C::TILE + 512);
     const int smem_b = 4 * C::TILE;
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem_a);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem_b);
-        once = true;
-    }
+    static DeviceOnce once_a, once_b;
+    ensure_dynamic_lds(once_a, &attn_bwd_dkdv_kernel<T>, smem_a);
+    ensure_dynamic_lds(once_b, &attn_bwd_dq_kernel<T>, smem_b);
     const int64_t items = (int64_t)B * N * NHEADS * 4;
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
                        (const T*)out, (const T*)dout, delta, B, N);

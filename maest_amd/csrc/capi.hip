@@ -1,6 +1,9 @@
 // Error plumbing and version of the C ABI (include/maest_hip.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+
+#include <mutex>
 
 #include "common.h"
 
@@ -24,7 +27,42 @@ int check_launch(const char* what) {
     return MAEST_OK;
 }
 
+// ---- process-wide switches: environment read ONCE (first use), then lock-free atomics
+static constexpr int kNumOptions = 3;
+static const int kOptionDefault[kNumOptions] = {8192, 0, -1};
+static const char* const kOptionEnv[kNumOptions] = {"MAEST_GEMM_MIN_M", "MAEST_GEMM_VARIANT", "MAEST_GEMM_EPILOGUE"};
+static std::atomic<int> g_option[kNumOptions];
+static int g_option_env[kNumOptions];
+static std::once_flag g_option_once;
+
+static void options_init() {
+    std::call_once(g_option_once, [] {
+        for (int i = 0; i < kNumOptions; ++i) {
+            const char* e = getenv(kOptionEnv[i]);
+            g_option_env[i] = e ? atoi(e) : kOptionDefault[i];
+            g_option[i].store(g_option_env[i], std::memory_order_relaxed);
+        }
+    });
+}
+
+int option(int opt) {
+    options_init();
+    return g_option[opt].load(std::memory_order_relaxed);
+}
+
 }  // namespace maest
+
+extern "C" int maest_set_option(int opt, int value, int restore_default) {
+    MAEST_REQUIRE(opt >= 0 && opt < maest::kNumOptions, "maest_set_option: unknown option %d", opt);
+    maest::options_init();
+    maest::g_option[opt].store(restore_default ? maest::g_option_env[opt] : value, std::memory_order_relaxed);
+    return MAEST_OK;
+}
+extern "C" int maest_get_option(int opt, int* value) {
+    MAEST_REQUIRE(opt >= 0 && opt < maest::kNumOptions && value, "maest_get_option: unknown option %d", opt);
+    *value = maest::option(opt);
+    return MAEST_OK;
+}
 
 extern "C" int maest_version(void) { return MAEST_ABI_VERSION; }
 extern "C" const char* maest_last_error(void) { return maest::g_error; }

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/maest_hip.h"
 
 namespace maest {
@@ -223,6 +225,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ------------------------------------------------------------------ host-side error plumbing
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+
+// Process-wide tuning / test switches (include/maest_hip.h: maest_set_option).  Defaults come from the
+// environment (MAEST_GEMM_MIN_M / MAEST_GEMM_VARIANT / MAEST_GEMM_EPILOGUE), read ONCE; lock-free reads.
+int option(int opt);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: raise it once per
+// (kernel, device), not once per process -- a process that touches a second GPU would otherwise fail to
+// launch every kernel that needs more than 64 KiB of LDS there.  One DeviceOnce per kernel instantiation;
+// safe to call concurrently (forward thread + autograd thread): the worst case sets the attribute twice.
+struct DeviceOnce {
+    std::atomic<uint64_t> done{0};
+};
+template <typename K>
+static inline void ensure_dynamic_lds(DeviceOnce& once, K kernel, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (dev < 64 && (once.done.load(std::memory_order_acquire) & bit)) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (dev < 64) once.done.fetch_or(bit, std::memory_order_release);
+}
 
 }  // namespace maest
 

@@ -16,11 +16,40 @@ constexpr int PE_D = 768;
 constexpr int PE_K = 16;   // patch edge
 constexpr int PE_S = 10;   // stride
 
+// SpecMasking as a predicate of the operand load (helpers/spec_masking.py:27-33, applied per sample by the loader
+// after normalisation and BEFORE the batch is mixed up: discogs/datamodule.py:140-152 then models/module.py:77-83):
+// bit i of the result is set when time column tcol + i of clip b lies inside one of its time stripes; the whole row
+// is dropped (all 16 bits) when frequency row `frow` lies inside one of its frequency stripes.  Stripes are
+// (start, width) pairs, clamped like spec_mask_kernel below.
+__device__ __forceinline__ uint32_t stripe_bits(const int32_t* __restrict__ t_stripes, int n_t,
+                                                const int32_t* __restrict__ f_stripes, int n_f, int b, int frow,
+                                                int tcol) {
+    for (int k = 0; k < n_f; ++k) {
+        int st = f_stripes[((int64_t)b * n_f + k) * 2];
+        const int w = f_stripes[((int64_t)b * n_f + k) * 2 + 1];
+        st = st < 0 ? 0 : st;
+        if (frow >= st && frow < st + w) return 0xffffu;
+    }
+    uint32_t bits = 0;
+    for (int k = 0; k < n_t; ++k) {
+        int st = t_stripes[((int64_t)b * n_t + k) * 2];
+        const int w = t_stripes[((int64_t)b * n_t + k) * 2 + 1];
+        st = st < 0 ? 0 : st;
+        int lo = st - tcol, hi = st + w - tcol;        // masked columns [lo, hi) relative to this patch row
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > 16 ? 16 : hi;
+        if (hi > lo) bits |= ((1u << (hi - lo)) - 1u) << lo;
+    }
+    return bits;
+}
+
 // one thread = one (patch row, ky): 16 contiguous input samples -> 16 contiguous operand elements
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ x, int B, int F, int T,
                                                            const int32_t* __restrict__ perm,
                                                            const float* __restrict__ lam,
                                                            const int32_t* __restrict__ tok_ft, int P,
+                                                           const int32_t* __restrict__ t_stripes, int n_t,
+                                                           const int32_t* __restrict__ f_stripes, int n_f,
                                                            void* __restrict__ out, int dtype) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)B * P * PE_K;
@@ -31,15 +60,31 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
     const int b = (int)(prow / P);
     const int f = tok_ft[2 * j];
     const int tcol = tok_ft[2 * j + 1] * PE_S;
-    const float* src = x + ((int64_t)b * F + f * PE_S + ky) * T + tcol;
+    const int frow = f * PE_S + ky;
+    const bool masked = n_t + n_f > 0;
+    const float* src = x + ((int64_t)b * F + frow) * T + tcol;
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = src[i];
+    if (masked) {
+        const uint32_t bits = stripe_bits(t_stripes, n_t, f_stripes, n_f, b, frow, tcol);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (bits >> i) & 1u ? 0.0f : v[i];
+    }
     if (lam != nullptr) {
         const float l = lam[b];
-        const float* src2 = x + ((int64_t)perm[b] * F + f * PE_S + ky) * T + tcol;
+        const int b2 = perm[b];
+        const float* src2 = x + ((int64_t)b2 * F + frow) * T + tcol;
+        float u[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = v[i] * l + src2[i] * (1.0f - l);
+        for (int i = 0; i < 16; ++i) u[i] = src2[i];
+        if (masked) {
+            const uint32_t bits = stripe_bits(t_stripes, n_t, f_stripes, n_f, b2, frow, tcol);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) u[i] = (bits >> i) & 1u ? 0.0f : u[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = v[i] * l + u[i] * (1.0f - l);
     }
     const int64_t o = prow * 256 + ky * 16;
     if (dtype == MAEST_BF16) {
@@ -217,15 +262,18 @@ __global__ __launch_bounds__(256) void melfile_assemble_kernel(const uint16_t* _
 using namespace maest;
 
 extern "C" int maest_patch_im2col(const float* x, int B, int F, int T, const int32_t* perm, const float* lam,
-                                  const int32_t* tok_ft, int P, void* out, int dtype, void* stream) {
+                                  const int32_t* tok_ft, int P, const int32_t* t_stripes, int n_t,
+                                  const int32_t* f_stripes, int n_f, void* out, int dtype, void* stream) {
     MAEST_REQUIRE(x && out && tok_ft, "maest_patch_im2col: null pointer");
     MAEST_REQUIRE(B > 0 && P > 0, "maest_patch_im2col: bad shape B=%d P=%d", B, P);
     MAEST_REQUIRE(F >= PE_K && T >= PE_K, "maest_patch_im2col: input %dx%d smaller than a patch", F, T);
     MAEST_REQUIRE((perm == nullptr) == (lam == nullptr), "maest_patch_im2col: perm and lam go together");
     MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_patch_im2col: bad dtype");
+    MAEST_REQUIRE(n_t >= 0 && n_f >= 0 && (n_t == 0 || t_stripes) && (n_f == 0 || f_stripes),
+                  "maest_patch_im2col: bad stripe lists");
     const int64_t total = (int64_t)B * P * PE_K;
     hipLaunchKernelGGL(patch_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       x, B, F, T, perm, lam, tok_ft, P, out, dtype);
+                       x, B, F, T, perm, lam, tok_ft, P, t_stripes, n_t, f_stripes, n_f, out, dtype);
     return check_launch("maest_patch_im2col");
 }
 

@@ -524,12 +524,8 @@ int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int d
 
 template <typename T>
 static int launch_gemm_nt(GemmParams& p, int split_k, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES);
-        attr_done = true;
-    }
+    static DeviceOnce once;
+    ensure_dynamic_lds(once, &gemm_nt_kernel<T>, GEMM_SMEM_BYTES);
     dim3 grid(p.tiles_m * p.tiles_n, split_k, 1);
     hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(256), GEMM_SMEM_BYTES, stream, p);
     return check_launch("maest_gemm_nt");
@@ -537,12 +533,8 @@ static int launch_gemm_nt(GemmParams& p, int split_k, hipStream_t stream) {
 
 template <typename T>
 static int launch_gemm_tn(GemmParams& p, int split_k, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, TnCfg<T>::SMEM);
-        attr_done = true;
-    }
+    static DeviceOnce once;
+    ensure_dynamic_lds(once, &gemm_tn_kernel<T>, TnCfg<T>::SMEM);
     dim3 grid(p.tiles_m * p.tiles_n, split_k, 1);
     hipLaunchKernelGGL(gemm_tn_kernel<T>, grid, dim3(256), TnCfg<T>::SMEM, stream, p);
     return check_launch("maest_gemm_tn");

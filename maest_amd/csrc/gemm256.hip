@@ -381,12 +381,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(Gemm256Params p) {
 
 template <typename T>
 static int launch256(Gemm256Params& p, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
-        attr_done = true;
-    }
+    static DeviceOnce once;
+    ensure_dynamic_lds(once, &gemm_nt256_kernel<T>, G2_SMEM);
     hipLaunchKernelGGL(gemm_nt256_kernel<T>, dim3(p.tiles_m * p.tiles_n), dim3(512), G2_SMEM, stream, p);
     return check_launch("maest_gemm_nt(256)");
 }
@@ -767,12 +763,8 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
 
 template <typename T, int EPIV>
 static int launch256w(Gemm256Params& p, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256w_kernel<T, EPIV>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, W2_SMEM);
-        attr_done = true;
-    }
+    static DeviceOnce once;
+    ensure_dynamic_lds(once, &gemm_nt256w_kernel<T, EPIV>, W2_SMEM);
     hipLaunchKernelGGL((gemm_nt256w_kernel<T, EPIV>), dim3(p.tiles_m * p.tiles_n), dim3(512), W2_SMEM, stream, p);
     return check_launch("maest_gemm_nt(256w)");
 }
@@ -908,12 +900,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt256x128_kernel(Gemm256Params p)
 
 template <typename T>
 static int launch256x128(Gemm256Params& p, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256x128_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, H2_SMEM);
-        attr_done = true;
-    }
+    static DeviceOnce once;
+    ensure_dynamic_lds(once, &gemm_nt256x128_kernel<T>, H2_SMEM);
     hipLaunchKernelGGL(gemm_nt256x128_kernel<T>, dim3(p.tiles_m * p.tiles_n), dim3(256), H2_SMEM, stream, p);
     return check_launch("maest_gemm_nt(256x128)");
 }
@@ -925,13 +913,11 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
     if (epi == MAEST_EPI_ATOMIC) return -1;
     // below ~8k rows the 256-row tiles leave most CUs idle (M = 560: 9-36 workgroups); the 128x128 kernel's finer
     // grid wins there (measured: one 10 s clip 2.13 -> 1.50 ms, batch 8 2.44 -> 2.23 ms, batch 16 equal).
-    // MAEST_GEMM_MIN_M overrides the threshold (the emulator tests run the big kernels at M = 512).
-    const char* menv = getenv("MAEST_GEMM_MIN_M");
-    const int min_m = menv ? atoi(menv) : 8192;
+    // MAEST_OPT_GEMM_MIN_M overrides the threshold (the emulator tests run the big kernels at M = 512).
+    const int min_m = option(MAEST_OPT_GEMM_MIN_M);
     if (M < (min_m > 512 ? min_m : 512) || N < 128 || (N % 128) != 0) return -1;
     if ((K * (in_dtype == MAEST_BF16 ? 2 : 4)) % G2_ROWB != 0) return -1;
-    const char* venv = getenv("MAEST_GEMM_VARIANT");   // experiment switch (A/B timing, tests)
-    const int variant = venv ? atoi(venv) : 0;
+    const int variant = option(MAEST_OPT_GEMM_VARIANT);   // experiment switch (A/B timing, tests)
     Gemm256Params p;
     p.A = (const char*)A; p.B = (const char*)B; p.C = C;
     p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
@@ -946,9 +932,9 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
         p.tiles_n = N / 256;
         // epilogue form, measured side by side in one run (scratch/gemm_ab.py): the two-pass form wins for bf16
         // outputs by 1-5 %, the four-pass double-buffered form for the fp32 residual outputs by 3-5 %, the
-        // one-pass form never.  MAEST_GEMM_EPILOGUE = 0 / 1 / 2 forces one of them.
-        const char* eenv = getenv("MAEST_GEMM_EPILOGUE");
-        const int ev = eenv ? atoi(eenv) : (epi == MAEST_EPI_RESIDUAL ? 1 : 0);
+        // one-pass form never.  MAEST_OPT_GEMM_EPILOGUE = 0 / 1 / 2 forces one of them (-1 = this default).
+        const int eopt = option(MAEST_OPT_GEMM_EPILOGUE);
+        const int ev = eopt >= 0 ? eopt : (epi == MAEST_EPI_RESIDUAL ? 1 : 0);
         if (ev == 1) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 1>(p, stream) : launch256w<float, 1>(p, stream);
         if (ev == 2) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 2>(p, stream) : launch256w<float, 2>(p, stream);
         return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 0>(p, stream) : launch256w<float, 0>(p, stream);
@@ -1202,12 +1188,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
 
 template <typename T>
 static int launch_tn256(GemmTn256Params& p, int split_k, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn256_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
-        attr_done = true;
-    }
+    static DeviceOnce once;
+    ensure_dynamic_lds(once, &gemm_tn256_kernel<T>, G2_SMEM);
     p.split_k = split_k;
     hipLaunchKernelGGL(gemm_tn256_kernel<T>, dim3(p.tiles_m * p.tiles_n * split_k), dim3(512), G2_SMEM, stream, p);
     return check_launch("maest_gemm_tn(256)");
@@ -1218,8 +1200,8 @@ int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int d
                    int N, int K, float* colsum, int split_k, hipStream_t stream) {
     const int ks = dtype == MAEST_BF16 ? Tn256<bf16_t>::KS : Tn256<float>::KS;
     if ((M % 256) != 0 || (N % 256) != 0 || (K % ks) != 0 || K < 8 * ks) return -1;
-    const char* venv = getenv("MAEST_GEMM_VARIANT");       // "4": take any qualifying shape (emulator tests)
-    if ((int64_t)M * N < (int64_t)8 * 65536 && !(venv && atoi(venv) == 4))
+    // variant 4: take any qualifying shape (emulator tests)
+    if ((int64_t)M * N < (int64_t)8 * 65536 && option(MAEST_OPT_GEMM_VARIANT) != 4)
         return -1;                                         // few output tiles: the 128x128 kernel splits K finer
     GemmTn256Params p;
     p.A = (const char*)A; p.B = (const char*)B; p.C = C; p.colsum = colsum;

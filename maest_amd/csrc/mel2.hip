@@ -137,12 +137,8 @@ extern "C" int maest_augment_mel(const float* wave, int B, int S, const float* w
     MAEST_REQUIRE(n_mels > 0 && n_mels <= M2_MAXBANDS && fb_stride > 0, "maest_augment_mel: bad filterbank n_mels=%d", n_mels);
     const int T = 1 + (S - 1) / M2_HOP;
     const int smem_bytes = (2048 + M2_MAXBANDS * M2_OUT_LD) * 4 + 4 * M2_NFFT * 8 + 4 * 516 * 4;
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&augment_mel_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-        once = true;
-    }
+    static DeviceOnce once;
+    ensure_dynamic_lds(once, &augment_mel_kernel, smem_bytes);
     dim3 grid((T + M2_FPB - 1) / M2_FPB, B);
     hipLaunchKernelGGL(augment_mel_kernel, grid, dim3(256), smem_bytes, (hipStream_t)stream, wave, S, T, window, twiddle,
                        fb_start, fb_len, fb_w, fb_stride, n_mels, pre0, pre1, log_eps, norm_add, norm_div, out);

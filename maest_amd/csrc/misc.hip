@@ -162,6 +162,26 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= alpha;
 }
 
+// x *= *alpha_dev (a device scalar: the upstream gradient of the loss; no host round trip)
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ alpha_dev) {
+    const float alpha = *alpha_dev;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= alpha;
+}
+
+// dst[r, c] = cast(src[r, c]) for c < cols, 0 for cols <= c < ld_dst  (fp32 rows -> zero-padded operand rows)
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                        void* __restrict__ dst, int64_t ld_dst, int rows, int cols,
+                                                        int dtype) {
+    const int64_t total = (int64_t)rows * ld_dst;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ld_dst;
+        const int c = (int)(i - r * ld_dst);
+        const float v = c < cols ? src[r * ld_src + c] : 0.0f;
+        if (dtype == MAEST_BF16) reinterpret_cast<bf16_t*>(dst)[i] = f2bf(v);
+        else reinterpret_cast<float*>(dst)[i] = v;
+    }
+}
+
 // ---- stochastic weight averaging over MANY parameters in one launch: avg += (w - avg) * inv_count
 // (Lightning's StochasticWeightAveraging.avg_fn as used by helpers/swa_callback.py)
 struct SwaTable {
@@ -297,6 +317,27 @@ extern "C" int maest_scale_f32(float* x, int64_t n, float alpha, void* stream) {
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, alpha);
     return check_launch("maest_scale_f32");
+}
+
+extern "C" int maest_scale_dev_f32(float* x, int64_t n, const float* alpha_dev, void* stream) {
+    MAEST_REQUIRE(x && alpha_dev && n >= 0, "maest_scale_dev_f32: bad arguments");
+    if (n == 0) return MAEST_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scale_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, alpha_dev);
+    return check_launch("maest_scale_dev_f32");
+}
+
+extern "C" int maest_cast_rows(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols,
+                               int dtype, void* stream) {
+    MAEST_REQUIRE(src && dst, "maest_cast_rows: null pointer");
+    MAEST_REQUIRE(rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols, "maest_cast_rows: bad shape");
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_cast_rows: bad dtype");
+    int64_t blocks = ((int64_t)rows * ld_dst + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst,
+                       ld_dst, rows, cols, dtype);
+    return check_launch("maest_cast_rows");
 }
 
 extern "C" int maest_affine_f32(float* x, int64_t n, float add, float div, void* stream) {

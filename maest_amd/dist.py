@@ -130,5 +130,9 @@ def init_from_env(backend: Optional[str] = None):
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):
     """Make every rank start from rank `src`'s weights (what DDP does at construction)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        for p in module.parameters():
-            dist.broadcast(p.data, src)
+        with torch.no_grad():
+            for p in module.parameters():
+                dist.broadcast(p.detach(), src)      # in-place on a detached alias: bumps p's version counter
+        eng = getattr(module, "_engine", None)
+        if eng is not None:                          # operand copies cast from the pre-broadcast weights are stale
+            eng.w.clear()

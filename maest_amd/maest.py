@@ -27,6 +27,7 @@ from __future__ import annotations
 import logging
 import math
 import warnings
+import weakref
 from functools import partial
 from typing import Optional, Tuple
 
@@ -116,9 +117,9 @@ class _Weights:
     def get(self, p: torch.Tensor, dtype, transposed=False, pad_cols_to: int = 0):
         key = (id(p), dtype, transposed, pad_cols_to)
         ver = p._version
-        hit = self._cache.get(key)
-        if hit is not None and hit[0] == ver and hit[1].device == p.device:
-            return hit[1]
+        hit = self._fresh(key, p)
+        if hit is not None:
+            return hit
         src = p.detach()
         w2 = src.reshape(src.shape[0], -1)
         if not transposed:
@@ -132,8 +133,16 @@ class _Weights:
                 out = ops.transpose(lp, ops.round_up(w2.shape[0], pad_cols_to))
             else:
                 _, out = ops.cast_weights(w2, dtype, want=False, want_t=True)
-        self._cache[key] = (ver, out)
+        self._cache[key] = (ver, out, weakref.ref(p))
         return out
+
+    def _fresh(self, key, p):
+        """The cached copy under `key` if it was made from THIS parameter object (id() of a freed parameter can be
+        reused by a new one) at its current version and device; None otherwise."""
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == p._version and hit[2]() is p and hit[1].device == p.device:
+            return hit[1]
+        return None
 
     def refresh(self, params, dtype, with_t: bool):
         """Bring the plain (and, for training, transposed) operand copies of `params` up to date in one launch."""
@@ -141,10 +150,8 @@ class _Weights:
             return
         stale = []
         for p in params:
-            ver = p._version
             for tr in ((False, True) if with_t else (False,)):
-                hit = self._cache.get((id(p), dtype, tr, 0))
-                if hit is None or hit[0] != ver or hit[1].device != p.device:
+                if self._fresh((id(p), dtype, tr, 0), p) is None:
                     stale.append(p)
                     break
         if not stale:
@@ -152,9 +159,9 @@ class _Weights:
         outs = ops.cast_weights_multi([p.detach() for p in stale], dtype, want=dtype != torch.float32, want_t=with_t)
         for p, (o, ot) in zip(stale, outs):
             if o is not None:
-                self._cache[(id(p), dtype, False, 0)] = (p._version, o)
+                self._cache[(id(p), dtype, False, 0)] = (p._version, o, weakref.ref(p))
             if ot is not None:
-                self._cache[(id(p), dtype, True, 0)] = (p._version, ot)
+                self._cache[(id(p), dtype, True, 0)] = (p._version, ot, weakref.ref(p))
 
     def clear(self):
         self._cache.clear()
@@ -204,7 +211,7 @@ class _Engine:
         return self._side[key]
 
     # ---- forward ----------------------------------------------------------------------------
-    def forward(self, x3: torch.Tensor, dt, *, toffset: int, tok_ft: torch.Tensor, perm, lam,
+    def forward(self, x3: torch.Tensor, dt, *, toffset: int, tok_ft: torch.Tensor, perm, lam, stripes=None,
                 stop_block: int = -1, return_self_attention: bool = False, save: bool = False):
         """x3: fp32 [B, F, T] on the device; tok_ft: int32 [P, 2] kept patch tokens.  Returns (outputs, ctx)."""
         m, W = self.m, self.w
@@ -226,7 +233,8 @@ class _Engine:
             mats.append(m.head_dist.weight)
         W.refresh(mats, dt, with_t=save)
 
-        cols = ops.patch_im2col(x3, tok_ft, dt, perm=perm, lam=lam)
+        t_str, f_str = stripes if stripes is not None else (None, None)
+        cols = ops.patch_im2col(x3, tok_ft, dt, perm=perm, lam=lam, t_stripes=t_str, f_stripes=f_str)
         patches = ops.gemm_nt(cols, W.get(m.patch_embed.proj.weight, dt), m.patch_embed.proj.bias,
                               out_dtype=torch.float32)
         Tt = m.time_new_pos_embed.shape[-1]
@@ -356,16 +364,11 @@ class _Engine:
         cpad = ops.round_up(C, 64)
         hn, hw = m.head[0], m.head[1]
 
-        def lp_padded(d):  # fp32 [B, C] -> operand dtype [B, cpad], zero padded (K of the dgrad GEMM)
-            b = torch.zeros((B, cpad), dtype=dt, device=dev)
-            b[:, :C] = d
-            return b
-
-        def head_linear_bwd(dlogits, inp_lp, lin, prefix):
-            dl = lp_padded(dlogits)
+        def head_linear_bwd(dlogits, inp_lp, lin, prefix, out_dtype):
+            dl = ops.cast_rows(dlogits, dt, cpad)     # fp32 [B, C] -> operand dtype [B, cpad], zero padded (K of the dgrad GEMM)
             wgrad(prefix + ".weight", prefix + ".bias", dl, inp_lp, C, EMBED_DIM)
             wt = W.get(lin.weight, dt, transposed=True, pad_cols_to=64)          # [768, cpad]
-            return ops.gemm_nt(dl, wt, None, out_dtype=dt, M=B, N=EMBED_DIM, K=cpad)
+            return ops.gemm_nt(dl, wt, None, out_dtype=out_dtype, M=B, N=EMBED_DIM, K=cpad)
 
         d_cls = d_dist = None
         g_h0w, g_h0b = buf("head.0.weight", EMBED_DIM), buf("head.0.bias", EMBED_DIM)
@@ -373,7 +376,7 @@ class _Engine:
             dlogits, dfeat_out = grads_out
             dfeat = None
             if dlogits is not None:
-                dhl = head_linear_bwd(dlogits.contiguous(), ctx["hl"], hw, "head.1")
+                dhl = head_linear_bwd(dlogits.contiguous(), ctx["hl"], hw, "head.1", dt)
                 dres = None if dfeat_out is None else dfeat_out.contiguous()
                 dfeat, _ = ops.layernorm_bwd(dhl, ctx["feat"], hn.weight, ctx["hmean"], ctx["hrstd"], dres,
                                              g_h0w, g_h0b)
@@ -383,12 +386,12 @@ class _Engine:
             dlogits, dlogits_d, dfeat_out = grads_out
             dfeat = None if dfeat_out is None else dfeat_out.contiguous()
             if dlogits is not None:
-                dhl = head_linear_bwd(dlogits.contiguous(), ctx["hl"], hw, "head.1")
+                dhl = head_linear_bwd(dlogits.contiguous(), ctx["hl"], hw, "head.1", dt)
                 d_cls, _ = ops.layernorm_bwd(dhl, ctx["cls"], hn.weight, ctx["hmean"], ctx["hrstd"], None,
                                              g_h0w, g_h0b)
             if dlogits_d is not None:
-                dd = head_linear_bwd(dlogits_d.contiguous(), ctx["dist_lp"], m.head_dist, "head_dist")
-                d_dist = dd if dt == torch.float32 else dd.float()
+                # head_dist is a bare Linear: its input gradient feeds head_pool_bwd directly, in fp32
+                d_dist = head_linear_bwd(dlogits_d.contiguous(), ctx["dist_lp"], m.head_dist, "head_dist", torch.float32)
         done("head.0.weight", g_h0w)
         done("head.0.bias", g_h0b)
         g_nw, g_nb = buf("norm.weight", EMBED_DIM), buf("norm.bias", EMBED_DIM)
@@ -454,7 +457,10 @@ class _MaestFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x3, dt, kw, names, *params):
-        outs, saved = model._engine.forward(x3, dt, save=True, **kw)
+        if model.hip_graph and x3.is_cuda:
+            outs, saved = model._graph_train_forward(x3, dt, kw)
+        else:
+            outs, saved = model._engine.forward(x3, dt, save=True, **kw)
         ctx.saved = saved
         ctx.model = model
         ctx.names = names
@@ -487,6 +493,15 @@ class MAEST(nn.Module):
                  depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True, distilled=True, distilled_type="mean",
                  precision="auto"):
         super().__init__()
+        self._init_kwargs = dict(u_patchout=u_patchout, s_patchout_t=s_patchout_t, s_patchout_f=s_patchout_f,
+                                 s_patchout_f_indices=s_patchout_f_indices,
+                                 s_patchout_f_interleaved=s_patchout_f_interleaved,
+                                 s_patchout_t_indices=s_patchout_t_indices,
+                                 s_patchout_t_interleaved=s_patchout_t_interleaved, img_size=tuple(img_size),
+                                 patch_size=patch_size, stride=stride, in_chans=in_chans, num_classes=num_classes,
+                                 embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                                 qkv_bias=qkv_bias, distilled=distilled, distilled_type=distilled_type,
+                                 precision=precision)
         if embed_dim != EMBED_DIM or num_heads != NUM_HEADS or patch_size != PATCH or in_chans != 1:
             raise NotImplementedError("maest_amd kernels are specialised for the MAEST geometry: "
                                       "embed_dim=768, 12 heads x 64, 16x16 patches, mono input")
@@ -538,6 +553,28 @@ class MAEST(nn.Module):
         self._param_list = None
         self._grad_sink = None   # set to a maest_amd.dist.GradReducer for data-parallel training
 
+    def clone_weights(self) -> "MAEST":
+        """A fresh model of the same architecture, on the same device and in the same mode, holding copies of the
+        parameters -- and NOTHING of the engine's run-time state (operand-copy caches keyed on the old parameters,
+        side streams, captured HIP graphs, the data-parallel gradient sink with its flat buffer)."""
+        twin = type(self)(**self._init_kwargs)
+        twin.precision = self.precision
+        dev = next(self.parameters()).device
+        twin.to(dev)
+        with torch.no_grad():
+            for a, b in zip(twin.parameters(), self.parameters()):
+                a.copy_(b)
+                a.requires_grad_(b.requires_grad)
+        twin.train(self.training)
+        return twin
+
+    def __deepcopy__(self, memo):
+        # copy.deepcopy of a live model (Lightning's StochasticWeightAveraging does exactly that, helpers/
+        # swa_callback.py:9-44) must not drag CUDA graphs, streams, process groups or 344 MB gradient buckets along
+        twin = self.clone_weights()
+        memo[id(self)] = twin
+        return twin
+
     # ---- reference API odds and ends --------------------------------------------------------
     def init_weights(self, mode=""):
         assert mode in ("jax", "jax_nlhb", "nlhb", "")
@@ -553,10 +590,13 @@ class MAEST(nn.Module):
     def get_classifier(self):
         return self.head, self.head_dist
 
-    def _compute_dtype(self):
+    def _compute_dtype(self, recording: bool = True):
         p = self.precision
         if p == "auto":
-            p = "bf16" if self.training else "fp32"
+            # bf16 is the TRAINING mode (the reference trains under 16-bit autocast, ex_maest.py:51); any forward
+            # that records no graph -- eval(), no_grad, predict_labels on a fresh train-mode model -- is inference,
+            # which the reference computes in fp32
+            p = "bf16" if (self.training and recording) else "fp32"
         if p in ("fp32", "float32"):
             return torch.float32
         if p in ("bf16", "bfloat16"):
@@ -651,12 +691,13 @@ class MAEST(nn.Module):
 
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, x, transformer_block: int = -1, return_self_attention: bool = False,
-                melspectrogram_input: bool = False, *, _mixup=None, _patchout=None
+                melspectrogram_input: bool = False, *, _mixup=None, _patchout=None, _specmask=None
                 ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
         """Same contract as the reference's ``MAEST.forward`` (maest.py:831-933).
 
-        ``_mixup=(perm, lam)`` and ``_patchout=(toffset, kept_time_columns)`` are private hooks used by
-        ``maest_amd.module.Module.training_step`` (fused mixup) and by the parity tests (pinned draws)."""
+        ``_mixup=(perm, lam)``, ``_specmask=(t_stripes, f_stripes)`` and ``_patchout=(toffset, kept_time_columns)``
+        are private hooks used by ``maest_amd.module.Module.training_step`` (mixup and SpecMasking fused into the
+        patch-embedding operand load) and by the parity tests (pinned draws)."""
         x = self._prepare_input(x, melspectrogram_input)
         if x.dim() != 4 or x.shape[1] != 1:
             raise Exception(f"expected input of shape [B, 1, F, T], got {tuple(x.shape)}")
@@ -670,7 +711,9 @@ class MAEST(nn.Module):
         if x3.dtype != torch.float32:
             x3 = x3.float()
         x3 = x3.contiguous()
-        dt = self._compute_dtype()
+        need_grad = (transformer_block == -1 and torch.is_grad_enabled()
+                     and any(p.requires_grad for p in self.parameters()))
+        dt = self._compute_dtype(need_grad)
 
         Fp = (F - PATCH) // self.patch_embed.stride[0] + 1
         if Fp > self.freq_new_pos_embed.shape[2]:
@@ -694,7 +737,11 @@ class MAEST(nn.Module):
             perm, lam = _mixup
             perm = perm.to(device=x3.device, dtype=torch.int32).contiguous()
             lam = lam.to(device=x3.device, dtype=torch.float32).contiguous()
-        kw = dict(toffset=int(toffset), tok_ft=tok_ft, perm=perm, lam=lam)
+        stripes = None
+        if _specmask is not None:
+            stripes = tuple(None if t is None else t.to(device=x3.device, dtype=torch.int32).contiguous()
+                            for t in _specmask)
+        kw = dict(toffset=int(toffset), tok_ft=tok_ft, perm=perm, lam=lam, stripes=stripes)
 
         if transformer_block != -1:
             with torch.no_grad():
@@ -702,7 +749,6 @@ class MAEST(nn.Module):
                                               return_self_attention=return_self_attention, **kw)
             return None, emb
 
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if need_grad:
             if self._param_names is None:
                 named = list(self.named_parameters())
@@ -711,7 +757,8 @@ class MAEST(nn.Module):
             outs = _MaestFn.apply(self, x3, dt, kw, self._param_names, *self._param_list)
         else:
             with torch.no_grad():
-                if self.hip_graph and x3.is_cuda and not self.training and _mixup is None and _patchout is None:
+                if (self.hip_graph and x3.is_cuda and not self.training and _mixup is None and _patchout is None
+                        and _specmask is None):
                     outs = self._graph_forward(x3, dt, kw)
                 else:
                     outs, _ = self._engine.forward(x3, dt, **kw)
@@ -719,10 +766,11 @@ class MAEST(nn.Module):
 
     # ---- hipGraph-captured inference forward (north_star / BASELINE configs[4]) ---------------------------
     def enable_hip_graph(self, on: bool = True):
-        """Eval-mode forwards of a fixed input shape are captured into a HIP graph on their second call and
-        replayed afterwards: one graph launch instead of ~170 kernel launches (the C ABI does no allocation and
-        no synchronisation, so the whole forward is capturable).  Outputs are bit-identical to the eager path.
-        A parameter update (version counters) or a new shape triggers a fresh capture."""
+        """Forwards of a fixed input shape are captured into a HIP graph on their second call and replayed
+        afterwards: one graph launch instead of ~170 kernel launches (the C ABI does no allocation and no
+        synchronisation, so the whole forward is capturable).  Outputs are bit-identical to the eager path.
+        Eval mode: a parameter update (version counters) or a new shape triggers a fresh capture.  Training mode
+        (forward with activations saved for backward, weight recast inside the graph): see _graph_train_forward."""
         self.hip_graph = bool(on)
         if not on:
             self._graphs.clear()
@@ -752,8 +800,54 @@ class MAEST(nn.Module):
         st["graph"].replay()
         return tuple(o.clone() for o in st["outs"])
 
+    def _graph_train_forward(self, x3, dt, kw):
+        """Training-mode forward (activations saved for the hand-written backward) replayed from a HIP graph
+        (BASELINE configs[4]: "hipGraph-captured forward").  Per input signature: call 1 runs eagerly, call 2 captures,
+        later calls copy the step's inputs (batch, kept-token list, mixup / stripe draws) into the graph's static
+        buffers and replay ~190 launches (weight recast included) as one.  The saved activations live in the graph's
+        private pool and are rewritten by every replay, so ONE training step may be in flight at a time -- which is
+        what forward / backward / optimizer.step() is."""
+        eng = self._engine
+        stripes = kw.get("stripes")
+        dyn = {"tok_ft": kw["tok_ft"], "perm": kw["perm"], "lam": kw["lam"],
+               "t_stripes": None if stripes is None else stripes[0], "f_stripes": None if stripes is None else stripes[1]}
+        key = ("train", tuple(x3.shape), dt, kw["toffset"], str(x3.device),
+               tuple((k, None if v is None else tuple(v.shape)) for k, v in dyn.items()))
+        st = self._graphs.get(key)
+        if st is None:
+            if len(self._graphs) >= 8:
+                self._graphs.clear()
+            self._graphs[key] = {"graph": None}
+            return eng.forward(x3, dt, save=True, **kw)
+        if st["graph"] is None:
+            sx = x3.clone()
+            sdyn = {k: None if v is None else v.clone() for k, v in dyn.items()}
+            skw = dict(toffset=kw["toffset"], tok_ft=sdyn["tok_ft"], perm=sdyn["perm"], lam=sdyn["lam"],
+                       stripes=None if stripes is None else (sdyn["t_stripes"], sdyn["f_stripes"]))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs, ctx = eng.forward(sx, dt, save=True, **skw)
+            # the operand copies cast inside the graph are static buffers too: keep them as THE cache entries
+            st.update(graph=g, x=sx, dyn=sdyn, outs=outs, ctx=ctx, wcache=dict(eng.w._cache))
+        else:
+            st["x"].copy_(x3)
+            for k, v in dyn.items():
+                if v is not None:
+                    st["dyn"][k].copy_(v)
+            # what an eager training forward does first (W.clear()): forget copies made outside the graph (the padded
+            # head transposes of the last backward) -- fused optimizers update parameters without a version bump
+            eng.w._cache = {k: (v[2]()._version if v[2]() is not None else v[0], v[1], v[2])
+                            for k, v in st["wcache"].items()}
+            eng.w.epoch += 1
+            eng._weights_dirty = True
+        st["graph"].replay()
+        ctx = dict(st["ctx"])
+        ctx["blocks"] = [dict(b) for b in st["ctx"]["blocks"]]      # backward empties these dicts as it goes
+        return tuple(o.clone() for o in st["outs"]), ctx
+
     def predict_labels(self, x):
-        logits = self.forward(x)[0]
+        with torch.no_grad():      # the result is detached anyway (maest.py:936-938): take the inference path
+            logits = self.forward(x)[0]
         activations = ops.sigmoid_mean(logits.detach().contiguous())
         return activations.cpu().numpy(), self.labels
 

@@ -86,6 +86,22 @@ class MelConstants:
         self.norm_2std = float(norm_std * 2)
 
 
+class _ConstantBuffers(Module):
+    """Holds the persistent buffers torchaudio's transforms register, so that state_dict keys / shapes equal the
+    reference's (``melspectrogram.spec.window`` [512] from torchaudio Spectrogram, ``melspectrogram.mel_scale.fb``
+    [257, 96] from MelScale).  They are constants of the algorithm: a state_dict that carries them loads cleanly
+    (strict), one that lacks them (a checkpoint written with the mel module excluded, the oracle's spec) does too,
+    and the values in a checkpoint never override the tables the kernel uses."""
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        for name, buf in self._buffers.items():
+            v = state_dict.get(prefix + name)
+            if v is not None and tuple(v.shape) != tuple(buf.shape):
+                error_msgs.append(f"size mismatch for {prefix + name}: checkpoint {tuple(v.shape)}, "
+                                  f"model {tuple(buf.shape)}")
+
+
 class MelSpectrogram(Module):
     """Extract z-normalised log-mel spectrograms (drop-in for the reference module)."""
 
@@ -102,6 +118,13 @@ class MelSpectrogram(Module):
     def __init__(self):
         super().__init__()
         self._consts = {}
+        n = np.arange(self.win_len, dtype=np.float64)
+        self.spec = _ConstantBuffers()                   # reference: torchaudio Spectrogram (melspectrogram.py:29-34)
+        self.spec.register_buffer("window", torch.from_numpy(
+            (0.5 - 0.5 * np.cos(2.0 * np.pi * n / self.win_len)).astype(np.float32)))
+        self.mel_scale = _ConstantBuffers()              # reference: torchaudio MelScale (melspectrogram.py:36-42)
+        self.mel_scale.register_buffer("fb", torch.from_numpy(
+            slaney_filterbank(self.win_len // 2 + 1, self.n_mel, self.sr)))
 
     def _constants(self, device):
         key = str(device)

@@ -31,7 +31,8 @@ class _BCEWithLogitsFn(torch.autograd.Function):
     def backward(ctx, g):
         dz = ctx.dz
         ctx.dz = None
-        return dz * g, None, None, None, None
+        # dz already carries weight / (rows * cols); times the upstream gradient of the scalar loss (a device scalar)
+        return ops.scale_dev_(dz, g.to(torch.float32).reshape(1).contiguous()), None, None, None, None
 
 
 def _mix_to_device(mix, device):
@@ -63,8 +64,13 @@ def bce_with_logits(z, y, perm=None, lam=None, weight=1.0):
 class Module(nn.Module):
     """Mirror of ``models.module.Module`` (reference models/module.py:44-102, optimizer :237-254)."""
 
-    def __init__(self, net=None, mixup_alpha=0.3, lr=2e-5, weight_decay=1e-4, **maest_kwargs):
+    def __init__(self, net=None, mixup_alpha=0.3, lr=2e-5, weight_decay=1e-4, spec_masking=None, **maest_kwargs):
+        """``spec_masking``: a ``maest_amd.spec_masking.SpecMasking`` (or None).  The reference applies it per clip in
+        the loader workers (discogs/datamodule.py:140-152), i.e. before mixup; here its stripes are drawn on the
+        host each step and applied as a predicate of the patch-embedding operand load (no extra pass over the
+        batch).  Default None: with current torchaudio the reference's call is a no-op."""
         super().__init__()
+        self.spec_masking = spec_masking
         self.mixup_alpha = mixup_alpha
         self.lr = lr
         self.weight_decay = weight_decay
@@ -75,6 +81,16 @@ class Module(nn.Module):
         # the reference hard-codes transformer_block=-1 here (models/module.py:68-71)
         return self.net.forward(batch, transformer_block=-1, return_self_attention=False, **kw)
 
+    def _specmask(self, x):
+        if self.spec_masking is None:
+            return None
+        if x.dim() == 2:       # waveform batch: the mel front end runs inside the forward
+            from .melspectrogram import MelSpectrogram
+            n_f, n_t = self.net.img_size[0], 1 + x.shape[-1] // MelSpectrogram.hop_len
+        else:
+            n_f, n_t = x.shape[-2], x.shape[-1]
+        return self.spec_masking.draw(x.shape[0], n_f, n_t)
+
     def _mixup(self, batch_size):
         if self.mixup_alpha > 0:
             rn_indices, lam = my_mixup(batch_size, self.mixup_alpha)
@@ -83,12 +99,13 @@ class Module(nn.Module):
         self.last_mixup = None
         return None
 
-    def training_step(self, batch, batch_idx=0, *, _mixup=None, _patchout=None):
+    def training_step(self, batch, batch_idx=0, *, _mixup=None, _patchout=None, _specmask=None):
         x, f, y = batch
         batch_size = len(y)
+        sm = _specmask if _specmask is not None else self._specmask(x)    # loader-side augmentation: drawn first
         mix = _mixup if _mixup is not None else self._mixup(batch_size)
         mix = _mix_to_device(mix, x.device)
-        y_hat, embed = self.forward(x, _mixup=mix, _patchout=_patchout)
+        y_hat, embed = self.forward(x, _mixup=mix, _patchout=_patchout, _specmask=sm)
         perm, lam = mix if mix is not None else (None, None)
         return bce_with_logits(y_hat, y, perm, lam)
 
@@ -105,12 +122,13 @@ class TeacherStudentModule(Module):
     """Mirror of ``TeacherStudentModule.training_step`` (reference models/module.py:280-316):
     ``distilled_type="separated"`` net, loss = (BCE(cls head, y) + BCE(dist head, y_teacher)) / 2."""
 
-    def training_step(self, batch, batch_idx=0, *, _mixup=None, _patchout=None):
+    def training_step(self, batch, batch_idx=0, *, _mixup=None, _patchout=None, _specmask=None):
         x, f, y, y_teacher = batch
         batch_size = len(y)
+        sm = _specmask if _specmask is not None else self._specmask(x)
         mix = _mixup if _mixup is not None else self._mixup(batch_size)
         mix = _mix_to_device(mix, x.device)
-        y_hat, y_hat_teacher, _ = self.forward(x, _mixup=mix, _patchout=_patchout)
+        y_hat, y_hat_teacher, _ = self.forward(x, _mixup=mix, _patchout=_patchout, _specmask=sm)
         perm, lam = mix if mix is not None else (None, None)
         loss_standard = bce_with_logits(y_hat, y, perm, lam, weight=0.5)
         loss_teacher = bce_with_logits(y_hat_teacher, y_teacher, perm, lam, weight=0.5)

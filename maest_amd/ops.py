@@ -228,14 +228,23 @@ def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float):
     return dqkv
 
 
-def patch_im2col(x: torch.Tensor, tok_ft: torch.Tensor, dtype, perm=None, lam=None):
-    """x fp32 [B, F, T], tok_ft int32 [P, 2] -> im2col operand [B*P, 256] (mixup and patchout fused)."""
-    _chk(x, tok_ft, perm, lam)
+def patch_im2col(x: torch.Tensor, tok_ft: torch.Tensor, dtype, perm=None, lam=None, t_stripes=None, f_stripes=None):
+    """x fp32 [B, F, T], tok_ft int32 [P, 2] -> im2col operand [B*P, 256] (SpecMasking stripes, mixup and patchout
+    fused).  t_stripes / f_stripes: int32 [B, n, 2] = (start, width) per clip, or None."""
+    _chk(x, tok_ft, perm, lam, t_stripes, f_stripes)
     assert x.dtype == torch.float32 and x.dim() == 3 and tok_ft.dtype == torch.int32
     B, F, T = x.shape
     P = tok_ft.shape[0]
+    n_t = n_f = 0
+    if t_stripes is not None:
+        assert t_stripes.dtype == torch.int32 and t_stripes.dim() == 3 and t_stripes.shape[0] == B and t_stripes.shape[2] == 2
+        n_t = int(t_stripes.shape[1])
+    if f_stripes is not None:
+        assert f_stripes.dtype == torch.int32 and f_stripes.dim() == 3 and f_stripes.shape[0] == B and f_stripes.shape[2] == 2
+        n_f = int(f_stripes.shape[1])
     out = torch.empty((B * P, 256), dtype=dtype, device=x.device)
-    call("maest_patch_im2col", _p(x), B, F, T, _p(perm), _p(lam), _p(tok_ft), P, _p(out), DT[dtype], _s(x))
+    call("maest_patch_im2col", _p(x), B, F, T, _p(perm), _p(lam), _p(tok_ft), P, _p(t_stripes) if n_t else None, n_t,
+         _p(f_stripes) if n_f else None, n_f, _p(out), DT[dtype], _s(x))
     return out
 
 
@@ -364,6 +373,25 @@ def scale_(x: torch.Tensor, alpha: float):
     return x
 
 
+def scale_dev_(x: torch.Tensor, alpha: torch.Tensor):
+    """x *= alpha in place, `alpha` a one-element fp32 DEVICE tensor (no host round trip)."""
+    _chk(x, alpha)
+    assert x.dtype == torch.float32 and alpha.dtype == torch.float32 and alpha.numel() == 1
+    call("maest_scale_dev_f32", _p(x), x.numel(), _p(alpha), _s(x))
+    return x
+
+
+def cast_rows(src: torch.Tensor, dtype, ld_dst: Optional[int] = None) -> torch.Tensor:
+    """fp32 [rows, cols] -> dtype [rows, ld_dst], columns cols..ld_dst zero filled."""
+    _chk(src)
+    assert src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1
+    rows, cols = src.shape
+    ld_dst = ld_dst or cols
+    out = torch.empty((rows, ld_dst), dtype=dtype, device=src.device)
+    call("maest_cast_rows", _p(src), src.stride(0), _p(out), ld_dst, rows, cols, DT[dtype], _s(src))
+    return out
+
+
 def affine_(x: torch.Tensor, add: float, div: float):
     """x = (x + add) / div in place (fp32)."""
     _chk(x)
@@ -397,3 +425,34 @@ def swa_update_multi(avgs, curs, inv_count: float):
     a_n = (ctypes.c_int64 * n)(*[a.numel() for a in avgs])
     call("maest_swa_update_multi", n, ctypes.cast(a_avg, ctypes.c_void_p), ctypes.cast(a_cur, ctypes.c_void_p),
          ctypes.cast(a_n, ctypes.c_void_p), float(inv_count), _s(avgs[0]))
+
+
+# ------------------------------------------------------------------------------------ process-wide switches
+def set_option(name: str, value: Optional[int]):
+    """maest_set_option: `value` None restores the default (environment, read once at first use)."""
+    opt = _lib.OPTIONS[name]
+    call("maest_set_option", opt, 0 if value is None else int(value), 1 if value is None else 0)
+
+
+def get_option(name: str) -> int:
+    v = ctypes.c_int(0)
+    call("maest_get_option", _lib.OPTIONS[name], ctypes.byref(v))
+    return v.value
+
+
+class options:
+    """``with ops.options(gemm_min_m=512): ...`` -- set switches for a block, restore the previous values after."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self.prev = {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.prev[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.prev.items():
+            set_option(k, v)

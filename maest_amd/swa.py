@@ -8,8 +8,6 @@ Here the running mean of all 85.9 M parameters is ONE kernel launch (csrc/misc.h
 """
 from __future__ import annotations
 
-from copy import deepcopy
-
 import torch
 
 from . import ops
@@ -18,7 +16,10 @@ from . import ops
 class WeightAverager:
     def __init__(self, net: torch.nn.Module):
         self.net = net
-        self.net_swa = deepcopy(net)                    # what the reference stores as pl_module.net_swa
+        # what the reference stores as pl_module.net_swa.  Built from a fresh constructor + the current weights, never
+        # by copying the live object: SWA starts MID-training (swa_epoch_start), when `net` carries engine state
+        # (operand-copy caches, streams, captured graphs, the GradReducer's flat buffer and process group)
+        self.net_swa = net.clone_weights() if hasattr(net, "clone_weights") else __import__("copy").deepcopy(net)
         for p in self.net_swa.parameters():
             p.requires_grad_(False)
         self.n_averaged = 0

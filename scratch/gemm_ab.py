@@ -25,7 +25,7 @@ for M in (256 * 290, 256 * 560):
         for cn, fn in cases:
             r = []
             for v in ("0", "1", "2"):
-                os.environ["MAEST_GEMM_EPILOGUE"] = v
+                ops.set_option("gemm_epilogue", int(v))
                 ms = bench(fn); r.append(ms)
             fl = 2.0 * M * N * K
             print(f"  {nm:5s} {cn:11s} 2pass: {r[0]:7.3f} ms | 4pass-dbuf: {r[1]:7.3f} ms | 1pass: {r[2]:7.3f} ms   best {fl/min(r)/1e9:7.1f} TF/s")

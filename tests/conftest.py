@@ -24,3 +24,19 @@ def emu():
     _lib._testing_override(path)
     yield "cpu"
     _lib._testing_restore()
+
+
+@pytest.fixture
+def gemm_options():
+    """``gemm_options(gemm_min_m=512)``: set library switches (maest_set_option) for one test, restored afterwards.
+    Request it AFTER `emu` so that it acts on the emulator build and is undone before that is unbound."""
+    from maest_amd import ops
+    stack = []
+
+    def set_(**kw):
+        o = ops.options(**kw)
+        o.__enter__()
+        stack.append(o)
+    yield set_
+    for o in reversed(stack):
+        o.__exit__()

@@ -48,6 +48,7 @@ typedef void* hipStream_t;
 #define hipSuccess 0
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 template <typename F>

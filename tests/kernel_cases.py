@@ -184,7 +184,7 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2):
 
 
 # ----------------------------------------------------------------------------- patch embed pieces
-def case_patch_embed(dev, dtype, B, T, patchout=0, mix=False, seed=30):
+def case_patch_embed(dev, dtype, B, T, patchout=0, mix=False, seed=30, masked=False):
     Fdim = 96
     x = rnd((B, Fdim, T), seed)
     Tp = (T - 16) // 10 + 1
@@ -195,14 +195,30 @@ def case_patch_embed(dev, dtype, B, T, patchout=0, mix=False, seed=30):
     t_list = torch.arange(Tp) if keep is None else torch.from_numpy(keep).long()
     tok = torch.stack(torch.meshgrid(torch.arange(Fp), t_list, indexing="ij"), -1).reshape(-1, 2).to(torch.int32)
     tok_dev = tok.contiguous().to(dev)
-    perm = lam = None
+    perm = lam = t_str = f_str = None
     xm = x
+    if masked:
+        # SpecMasking stripes per clip (helpers/spec_masking.py:27-33), applied by the loader BEFORE mixup; explicit
+        # (start, width) lists incl. zero-width, edge-touching and overlapping stripes
+        n_t, n_f = 5, 3
+        t_str = torch.from_numpy(np.stack([rng.integers(0, T - 8, (B, n_t)), rng.integers(0, 9, (B, n_t))], -1).astype(np.int32))
+        f_str = torch.from_numpy(np.stack([rng.integers(0, Fdim - 5, (B, n_f)), rng.integers(0, 6, (B, n_f))], -1).astype(np.int32))
+        t_str[0, 0] = torch.tensor([T - 3, 8])          # runs past the right edge: clamped
+        f_str[0, 0] = torch.tensor([Fdim - 2, 5])
+        xm = torch.stack([O.spec_masking(x[b], [tuple(v) for v in t_str[b].tolist()], [tuple(v) for v in f_str[b].tolist()])
+                          for b in range(B)])
     if mix:
         perm = torch.from_numpy(rng.permutation(B).astype(np.int32))
         lam = torch.from_numpy(rng.random(B).astype(np.float32))
-        xm = O.mixup(x, perm.long(), lam)
+        xm = O.mixup(xm, perm.long(), lam)
     cols = ops.patch_im2col(x.to(dev), tok_dev, dtype,
-                            perm=None if perm is None else perm.to(dev), lam=None if lam is None else lam.to(dev))
+                            perm=None if perm is None else perm.to(dev), lam=None if lam is None else lam.to(dev),
+                            t_stripes=None if t_str is None else t_str.to(dev), f_stripes=None if f_str is None else f_str.to(dev))
+    if masked and not mix and dtype == torch.float32:
+        # the fused predicate must equal the stand-alone kernel (maest_spec_mask) bit for bit
+        xs = ops.spec_mask_(x.clone().to(dev), t_str.to(dev), f_str.to(dev))
+        cols2 = ops.patch_im2col(xs, tok_dev, dtype)
+        assert torch.equal(cols, cols2), "fused SpecMasking differs from spec_mask_ + im2col"
     ref = F.unfold(xm.unsqueeze(1), kernel_size=16, stride=10)          # [B, 256, Fp*Tp]
     ref = ref.reshape(B, 256, Fp, Tp)
     if keep is not None:

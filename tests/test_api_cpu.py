@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/maest_hip.h but not exported"
     lib.maest_version.restype = ctypes.c_int
-    assert lib.maest_version() == 1
+    assert lib.maest_version() == _lib.ABI_VERSION
 
 
 def test_argument_validation_returns_status_and_message():
@@ -97,9 +97,16 @@ def test_state_dict_matches_reference_layout():
     m = get_maest("discogs-maest-10s-pw-129e", pretrained=False)
     sd = m.state_dict()
     spec = O.state_dict_spec(625, 400)
-    assert list(sd.keys()) == [n for n, _ in spec]
-    for n, shape in spec:
+    # the oracle's spec was probed with torchaudio stubbed out; the genuine reference additionally carries the two
+    # persistent buffers torchaudio's Spectrogram / MelScale register (models/helpers/melspectrogram.py:29-42)
+    mel_buffers = [("melspectrogram.spec.window", (512,)), ("melspectrogram.mel_scale.fb", (257, 96))]
+    assert list(sd.keys()) == [n for n, _ in spec] + [n for n, _ in mel_buffers]
+    for n, shape in spec + mel_buffers:
         assert tuple(sd[n].shape) == tuple(shape), n
+    full = dict(O.make_state_dict(625))
+    full.update({n: torch.zeros(s) for n, s in mel_buffers})
+    m.load_state_dict(full, strict=True)         # a genuine reference state_dict (with the buffers) loads strictly
+    assert float(m.melspectrogram.spec.window.abs().max()) > 0.5, "checkpoint values never replace the constant tables"
     assert sum(p.numel() for p in m.parameters()) == 85927712
     assert m.training, "get_maest returns the model in train mode like the reference (maest.py:1552)"
     m.load_state_dict(O.make_state_dict(625), strict=True)

@@ -22,28 +22,28 @@ def test_emu_gemm_ragged_n_scalar_epilogue(emu, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype, monkeypatch):
+def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype, gemm_options):
     """The 64-byte-slice kernels of gemm256.hip: 256x128 two-per-CU (N % 256 != 0) and 256x256 (variant 1)."""
     # 6 K slices: the 3- / 4-deep rings wrap
     K = 96 if dtype == torch.float32 else 192
-    monkeypatch.setenv("MAEST_GEMM_MIN_M", "512")
+    gemm_options(gemm_min_m=512)
     KC.case_gemm(emu, dtype, 512, 128, K, identity=False)   # (orientation is pinned by the small-shape cases)
-    monkeypatch.setenv("MAEST_GEMM_VARIANT", "1")
+    gemm_options(gemm_variant=1)
     KC.case_gemm(emu, dtype, 512, 256, K, identity=False)
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_emu_gemm_256_tile_full_line_stages(emu, dtype, monkeypatch):
+def test_emu_gemm_256_tile_full_line_stages(emu, dtype, gemm_options):
     """gemm_nt256w_kernel (the default for M >= 512, N % 256 == 0): 128-byte K stages through a 5-buffer unit
     ring (6 stages: the ring wraps)."""
-    monkeypatch.setenv("MAEST_GEMM_MIN_M", "512")
+    gemm_options(gemm_min_m=512)
     KC.case_gemm(emu, dtype, 512, 256, 192 if dtype == torch.float32 else 384, identity=False)   # 6 stages > 5 buffers
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_emu_gemm_tn_256_tile_lds_dma_kernel(emu, dtype, monkeypatch):
+def test_emu_gemm_tn_256_tile_lds_dma_kernel(emu, dtype, gemm_options):
     """M, N multiples of 256 and K a multiple of the slice route to gemm256.hip:gemm_tn256_kernel."""
-    monkeypatch.setenv("MAEST_GEMM_VARIANT", "4")   # take the 256-tile kernel although there are only 2 tiles
+    gemm_options(gemm_variant=4)   # take the 256-tile kernel although there are only 2 tiles
     KC.case_gemm_tn(emu, dtype, 288 if dtype == torch.bfloat16 else 144, 256, 512)
 
 
@@ -80,6 +80,11 @@ def test_emu_patch_embed(emu, dtype):
 
 def test_emu_patch_embed_eval(emu):
     KC.case_patch_embed(emu, torch.float32, 1, 56)
+
+
+@pytest.mark.parametrize("mix", [False, True])
+def test_emu_patch_embed_spec_masking_fused(emu, mix):
+    KC.case_patch_embed(emu, torch.float32, 3, 66, patchout=1, mix=mix, masked=True, seed=33)
 
 
 def test_emu_head(emu):

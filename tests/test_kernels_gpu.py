@@ -19,9 +19,9 @@ def test_gemm(dtype, shape):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("shape", [(1120, 2304, 768), (2560, 768, 3072), (1024, 768, 256)])
-def test_gemm_big_tile_kernels_at_small_m(dtype, shape, monkeypatch):
+def test_gemm_big_tile_kernels_at_small_m(dtype, shape, gemm_options):
     """the 256-row-tile kernels (normally taken from 8192 rows up) forced onto small and ragged M"""
-    monkeypatch.setenv("MAEST_GEMM_MIN_M", "512")
+    gemm_options(gemm_min_m=512)
     KC.case_gemm(DEV, dtype, *shape)
 
 
@@ -66,6 +66,13 @@ def test_attention_rescale_branch():
 def test_patch_embed(dtype):
     KC.case_patch_embed(DEV, dtype, 3, 626, patchout=30, mix=True)
     KC.case_patch_embed(DEV, dtype, 2, 625)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("mix", [False, True])
+def test_patch_embed_spec_masking_fused(dtype, mix):
+    """SpecMasking stripes as a predicate of the patch-embedding operand load (per clip, before mixup)."""
+    KC.case_patch_embed(DEV, dtype, 4, 626, patchout=30, mix=mix, masked=True, seed=34)
 
 
 def test_head():

@@ -514,3 +514,193 @@ def test_30s_training_step_matches_the_oracle_fp32():
     for n in ("blocks.0.attn.qkv.weight", "blocks.6.attn.proj.weight", "blocks.11.mlp.fc1.weight", "time_new_pos_embed",
               "patch_embed.proj.weight", "blocks.3.norm2.weight"):
         assert rel_err(dict(net.named_parameters())[n].grad, sdo[n].grad) < 1e-3, n
+
+
+def test_training_step_with_fused_spec_masking_matches_the_oracle_fp32():
+    """SpecMasking (helpers/spec_masking.py:27-33) wired into the training input path: explicit per-clip stripes, applied
+    before mixup as the loader does (discogs/datamodule.py:140-152), fused into the patch-embedding operand load --
+    loss and gradients against the oracle fed with spec_masking(x) computed on the host."""
+    from maest_amd.spec_masking import SpecMasking
+    rng = np.random.Generator(np.random.PCG64(4040))
+    sd = O.make_state_dict(625, seed=4040)
+    net = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30, precision="fp32")
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    sm = SpecMasking()
+    mod = Module(net=net, mixup_alpha=0.3, spec_masking=sm)
+    B, T = 3, 626
+    x = torch.from_numpy(rng.standard_normal((B, 1, 96, T), dtype=np.float32))
+    y = torch.from_numpy((rng.random((B, 400)) < 0.02).astype(np.float32))
+    perm = torch.from_numpy(rng.permutation(B))
+    lam = torch.from_numpy(rng.uniform(0.5, 1, B).astype(np.float32))
+    keep = sorted(rng.permutation(62)[:32].tolist())
+    torch.manual_seed(77)
+    t_str, f_str = sm.draw(B, 96, T)                  # the reference's parameters: 20 time stripes <= 8, 8 freq stripes <= 5
+    assert t_str.shape == (B, 20, 2) and f_str.shape == (B, 8, 2) and int(t_str[..., 1].max()) <= 8
+    loss = mod.training_step((x.to(DEV), None, y.to(DEV)), 0, _mixup=(perm, lam), _patchout=(0, torch.tensor(keep)),
+                             _specmask=(t_str, f_str))
+    loss.backward()
+    xm = torch.stack([O.spec_masking(x[b], [tuple(v) for v in t_str[b].tolist()], [tuple(v) for v in f_str[b].tolist()])
+                      for b in range(B)])
+    assert float((xm == 0).float().mean()) > 0.2, "the stripes must actually mask something"
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want, _ = O.training_loss(xm, y, sdo, perm, lam, toffset=0, t_keep=keep)
+    want.backward()
+    assert abs(loss.item() - want.item()) < 1e-5 * abs(want.item())
+    for n in ("patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "time_new_pos_embed"):
+        assert rel_err(dict(net.named_parameters())[n].grad, sdo[n].grad) < 1e-3, n
+    # drawn inside training_step when no stripes are pinned (RNG: torch.rand, like torchaudio's mask_along_axis_iid)
+    torch.manual_seed(77)
+    l2 = mod.training_step((x.to(DEV), None, y.to(DEV)), 0, _mixup=(perm, lam), _patchout=(0, torch.tensor(keep)))
+    assert abs(l2.item() - loss.item()) < 1e-6 * abs(loss.item())
+
+
+def test_config4_teacher_student_waveform_composite_matches_the_oracle_fp32():
+    """BASELINE configs[4] as ONE step: 30 s waveforms [B, 480000] -> HIP log-mel on the fly -> mixup (fused) ->
+    patchout 90 -> 875-token ViT with separated heads (C = 519) -> (BCE(cls, y) + BCE(dist, y_teacher)) / 2
+    (models/module.py:280-316), against the oracle's logmel + training_loss on the host."""
+    rng = np.random.Generator(np.random.PCG64(5050))
+    sd = O.make_state_dict(1875, n_classes=519, seed=5050)
+    net = get_maest("discogs-maest-30s-pw-73e-ts", pretrained=False, n_classes=519, input_t=1875, s_patchout_t=90,
+                    distilled_type="separated", precision="fp32")
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    mod = TeacherStudentModule(net=net, mixup_alpha=0.3)
+    B, S = 2, 480000
+    w = torch.from_numpy((rng.random((B, S), dtype=np.float32) * 2 - 1) * 0.7)
+    y = torch.from_numpy((rng.random((B, 519)) < 0.01).astype(np.float32))
+    yt = torch.from_numpy((rng.random((B, 519)) < 0.01).astype(np.float32))
+    perm = torch.tensor([1, 0])
+    lam = torch.tensor([0.85, 0.6])
+    Tp = (1876 - 16) // 10 + 1
+    keep = sorted(rng.permutation(Tp)[: Tp - 90].tolist())
+    loss = mod.training_step((w.to(DEV), None, y.to(DEV), yt.to(DEV)), 0, _mixup=(perm, lam),
+                             _patchout=(0, torch.tensor(keep)))
+    loss.backward()
+    mel = O.logmel(w).unsqueeze(1)
+    assert mel.shape == (B, 1, 96, 1876)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want = O.training_loss(mel, y, sdo, perm, lam, toffset=0, t_keep=keep, y_teacher=yt)[0]
+    want.backward()
+    rel = abs(loss.item() - want.item()) / abs(want.item())
+    print(f"configs[4] composite: loss {loss.item():.6f} oracle {want.item():.6f} rel {rel:.2e}")
+    assert rel < 1e-4
+    for n in ("head_dist.weight", "head.1.weight", "blocks.11.attn.qkv.weight", "blocks.0.mlp.fc1.weight",
+              "patch_embed.proj.weight", "time_new_pos_embed", "dist_token"):
+        assert rel_err(dict(net.named_parameters())[n].grad, sdo[n].grad) < 1e-3, n
+
+
+def test_hip_graph_captured_training_forward_equals_eager():
+    """configs[4] "hipGraph-captured forward", training mode: eager call, capturing call and replays give the same
+    loss bit for bit (the forward has no atomics) and the same gradients up to the order of the split-K atomics; new
+    inputs and new draws on a replay follow the eager model."""
+    g = np.load(os.path.join(GOLD, "g5_train_step.npz"))
+    net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision="bf16").train()
+    mod = Module(net=net, mixup_alpha=0.3)
+    x, y, mix, po = _g5_batch(g)
+
+    def step(xs, mixs, pos):
+        net.zero_grad(set_to_none=True)
+        loss = mod.training_step((xs, None, y), 0, _mixup=mixs, _patchout=pos)
+        loss.backward()
+        return loss.item(), net.blocks[5].mlp.fc1.weight.grad.clone(), net.patch_embed.proj.weight.grad.clone()
+
+    x2 = randn((4, 1, 96, 625), 99).to(DEV)
+    mix2 = (torch.tensor([2, 3, 0, 1]), torch.tensor([0.9, 0.55, 0.7, 1.0]))
+    po2 = (0, torch.from_numpy(np.sort(np.random.Generator(np.random.PCG64(8)).permutation(61)[:31])))
+    e1, e2 = step(x, mix, po), step(x2, mix2, po2)
+    net.enable_hip_graph()
+    outs = [step(x, mix, po), step(x, mix, po), step(x2, mix2, po2), step(x, mix, po)]   # eager, capture, replay, replay
+    assert any(st.get("graph") is not None for k, st in net._graphs.items() if k[0] == "train"), "nothing was captured"
+    for (l, g1, g2), (le, ge1, ge2) in zip(outs, [e1, e1, e2, e1]):
+        assert l == le, (l, le)
+        assert rel_err(g1, ge1) < 1e-4 and rel_err(g2, ge2) < 1e-4
+    # an optimizer step between replays: the recast inside the graph must pick the new weights up
+    opt = mod.configure_optimizers()
+    l0 = step(x, mix, po)[0]
+    for _ in range(3):
+        opt.step()
+        l1 = step(x, mix, po)[0]
+    assert l1 < l0, "three AdamW steps on one batch must reduce the (graph-replayed) loss"
+    net.enable_hip_graph(False)
+    assert step(x, mix, po)[0] == l1, "eager forward on the updated weights must equal the last replay"
+
+
+def test_checkpoint_interop_on_the_device(tmp_path):
+    """SURVEY 8f row 2 on the GPU: a Lightning-layout .ckpt (net. / net_swa. prefixes) loaded through
+    get_maest(checkpoint=...) and run by the HIP forward equals the oracle on the same weights; the same 10 s
+    checkpoint adapted to the 30 s model (position tables re-interpolated as the reference's checkpoint_filter_fn
+    does, pinned on the CPU by fixture g9) equals the oracle on the adapted weights."""
+    from maest_amd import checkpoint as C
+    sd = O.make_state_dict(625, seed=606)
+    ckpt = {"state_dict": {**{"net." + k: torch.zeros_like(v) for k, v in sd.items()},
+                           **{"net_swa." + k: v for k, v in sd.items()}}}
+    path = str(tmp_path / "last.ckpt")
+    torch.save(ckpt, path)
+    m = get_maest("discogs-maest-10s-pw-129e", pretrained=False, checkpoint=path, precision="fp32").to(DEV).eval()
+    x = randn((2, 96, 626), 607)
+    want, wf = O.forward(x, sd, (96, 625))
+    got, gf = m(x.to(DEV))
+    assert rel_err(got, want) < 1e-3 and rel_err(gf, wf) < 1e-3
+    assert torch.equal(got.cpu().argsort(dim=1, descending=True)[:, :10], want.argsort(dim=1, descending=True)[:, :10])
+    m30 = get_maest("discogs-maest-30s-pw-129e", pretrained=False, precision="fp32")
+    C.load_lightning_checkpoint(m30, path, adapt=True)
+    adapted = C.adapt_state_dict(sd, m30)
+    assert adapted["time_new_pos_embed"].shape[-1] == 187
+    m30 = m30.to(DEV).eval()
+    x30 = randn((1, 96, 1876), 608)
+    want30, wf30 = O.forward(x30, adapted, (96, 1875))
+    got30, gf30 = m30(x30.to(DEV))
+    assert rel_err(got30, want30) < 1e-3 and rel_err(gf30, wf30) < 1e-3
+
+
+def test_weight_averager_built_mid_training_with_a_gradient_sink():
+    """SWA starts mid-training (swa_epoch_start), when the live model carries engine state: operand-copy
+    caches, a side stream, a captured graph and the data-parallel gradient sink.  The averaged twin must be a clean
+    model (no sink, no graphs, its own parameters) and track the running mean."""
+    from maest_amd.dist import GradReducer
+    from maest_amd.swa import WeightAverager
+    g = np.load(os.path.join(GOLD, "g5_train_step.npz"))
+    net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision="bf16").train()
+    mod = Module(net=net, mixup_alpha=0.3, lr=1e-3)
+    opt = mod.configure_optimizers()
+    red = GradReducer(net.named_parameters(), skip=("head_dist.weight", "head_dist.bias"))
+    net._grad_sink = red
+    net.enable_hip_graph()
+    x, y, mix, po = _g5_batch(g)
+    for _ in range(3):                                   # eager, capture, replay
+        red.reset()
+        mod.training_step((x, None, y), 0, _mixup=mix, _patchout=po).backward()
+        red.finish()
+        opt.step()
+    wa = WeightAverager(net)
+    twin = wa.net_swa
+    assert twin._grad_sink is None and not twin._graphs and twin.s_patchout_t == 30
+    assert twin.blocks[0].attn.qkv.weight.data_ptr() != net.blocks[0].attn.qkv.weight.data_ptr()
+    w0 = net.blocks[0].attn.qkv.weight.detach().clone()
+    wa.update()
+    red.reset()
+    mod.training_step((x, None, y), 0, _mixup=mix, _patchout=po).backward()
+    red.finish()
+    opt.step()
+    wa.update()
+    w1 = net.blocks[0].attn.qkv.weight.detach()
+    assert torch.allclose(twin.blocks[0].attn.qkv.weight, (w0 + w1) / 2, rtol=1e-6, atol=1e-8)
+    twin.eval()
+    with torch.no_grad():
+        out = twin(x)[0]
+    assert torch.isfinite(out).all()
+
+
+def test_data_parallel_two_gpus_over_rccl():
+    """The nccl (= RCCL) branch of the data-parallel path on two real devices: weights identical across ranks after 3
+    steps and reduced gradients equal to the single-process mean.  Needs >= 2 GPUs (skipped on the 1-GPU test boxes;
+    the same code path runs there with gloo carrying the device tensors, test_data_parallel_two_ranks_sharing_the_gpu)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "dp_two_ranks_one_gpu.py")
+    r = subprocess.run([sys.executable, tool, "--backend", "nccl"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "weights identical after 3 steps" in r.stdout

@@ -1,5 +1,6 @@
-# The data-parallel training path (GradReducer + side stream + async all-reduce) with TWO ranks sharing the ONE GPU
-# of a gpurun box, gloo transporting the CUDA tensors: checks the reduced gradients against a single-process
+# The data-parallel training path (GradReducer + side stream + async all-reduce) with TWO ranks: by default both share
+# the ONE GPU of a gpurun box and gloo transports the CUDA tensors; with `--backend nccl` each rank takes its own GPU
+# and RCCL carries the all-reduce (needs two devices).  Checks the reduced gradients against a single-process
 # computation of both half-batches, and that both ranks hold identical weights after 3 optimizer steps.
 import os, sys
 import numpy as np
@@ -24,11 +25,15 @@ def data(rank, B=8):
     return x, y
 
 
-def worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from maest_amd.dist import GradReducer, broadcast_parameters
+def worker(rank, world, port, out, backend):
+    local = rank if backend == "nccl" else 0
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(local))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    from maest_amd.dist import GradReducer, broadcast_parameters, init_from_env
+    r, l, w = init_from_env(backend=backend)            # the bootstrap bench.py / examples use
+    assert (r, l, w) == (rank, local, world)
     net, mod = make(seed=5 + rank)                      # different init per rank: broadcast must fix it
     broadcast_parameters(net)
     opt = mod.configure_optimizers()
@@ -58,7 +63,8 @@ if __name__ == "__main__":
     with socket.socket() as sk:                      # a free rendezvous port on this box
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
+    backend = sys.argv[sys.argv.index("--backend") + 1] if "--backend" in sys.argv else "gloo"
+    mp.spawn(worker, args=(2, port, out, backend), nprocs=2, join=True)
     r0, r1 = torch.load(f"{out}/rank0.pt"), torch.load(f"{out}/rank1.pt")
     for n in r0["w"]:
         assert torch.equal(r0["w"][n], r1["w"][n]), f"weights diverged across ranks: {n}"
@@ -79,5 +85,5 @@ if __name__ == "__main__":
     for n, g in acc.items():
         e = ((r0["g"][n] - g).abs().max() / g.abs().max().clamp_min(1e-12)).item()
         worst = max(worst, e)
-    print(f"2 ranks on one GPU: weights identical after 3 steps; reduced gradients vs single-process mean: worst rel err {worst:.2e}")
+    print(f"2 ranks ({backend}): weights identical after 3 steps; reduced gradients vs single-process mean: worst rel err {worst:.2e}")
     assert worst < 5e-3
