@@ -181,6 +181,15 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2):
     close(dqkv[:, 1536:], g[:, 1536:], rt, at, "attention dV")
     close(dqkv[:, 768:1536], g[:, 768:1536], rt, at, "attention dK")
     close(dqkv[:, :768], g[:, :768], rt, at, "attention dQ")
+    if dtype == torch.bfloat16 and N <= 320:
+        # the call above took the fused one-pass kernel (bf16, <= 10 key blocks); the two-kernel dK/dV + dQ form must
+        # agree with the oracle too, and the two with each other to bf16 rounding of the same quantities
+        with ops.options(attn_bwd=1):
+            dq2 = ops.attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
+        close(dq2[:, 1536:], g[:, 1536:], rt, at, "attention dV (two-kernel)")
+        close(dq2[:, 768:1536], g[:, 768:1536], rt, at, "attention dK (two-kernel)")
+        close(dq2[:, :768], g[:, :768], rt, at, "attention dQ (two-kernel)")
+        close(dqkv, dq2.float(), 2e-2, 2e-2, "fused vs two-kernel attention backward")
 
 
 # ----------------------------------------------------------------------------- patch embed pieces

@@ -129,7 +129,8 @@ def test_training_step_batch256_bf16_is_the_path_the_bench_times():
     full-line 256x256 NT kernel (gemm_nt256w_kernel<bf16>), the 256-tile TN wgrad kernel (gemm_tn256_kernel<bf16>)
     and the bf16 attention / LayerNorm kernels at their benchmark shapes -- against the fp32 parity-mode step of the
     SAME batch and draws, which test_training_step_batch256_is_the_mean_of_its_quarters_fp32 anchors to the oracle.
-    Gates are ~3x the deviations observed on MI355X (printed below): bf16 operands, fp32 accumulation."""
+    Gates are ~3x the deviations observed on MI355X (loss 1.1e-4 relative; per-parameter relative L2 4e-3 .. 7e-3;
+    largest single element 0.11 x the gradient's RMS): bf16 operands, fp32 accumulation."""
     x = randn((B, 1, 96, T), 21).to(DEV)
     rng = np.random.Generator(np.random.PCG64(22))
     y = torch.from_numpy((rng.random((B, 400)) < 0.00625).astype(np.float32)).to(DEV)
@@ -162,8 +163,8 @@ def test_training_step_batch256_bf16_is_the_path_the_bench_times():
         e_norm = (g16[n] - g32[n]).norm().item() / max(g32[n].norm().item(), 1e-30)
         report.append(f"{n}: |d|max/rms {e_max:.2e}  ||d||/||g|| {e_norm:.2e}")
         worst = max(worst, e_norm)
-        assert e_norm < 3e-2, f"{n}: bf16 gradient deviates from fp32 by {e_norm:.2e} (relative L2)"
-        assert e_max < 0.5, f"{n}: bf16 gradient element off by {e_max:.2e} x RMS"
+        assert e_norm < 2e-2, f"{n}: bf16 gradient deviates from fp32 by {e_norm:.2e} (relative L2)"
+        assert e_max < 0.35, f"{n}: bf16 gradient element off by {e_max:.2e} x RMS"
     print(f"bench path bf16 vs fp32 at B=256: loss {l16:.6f} vs {l32:.6f} (rel {le:.2e}); worst relative-L2 gradient "
           f"deviation {worst:.2e}\n  " + "\n  ".join(report))
-    assert le < 5e-4
+    assert le < 3.5e-4

@@ -28,7 +28,7 @@ def randn(shape, seed):
 
 def rel_err(a, b):
     a = a.detach().float().cpu()
-    b = torch.as_tensor(b).float()
+    b = torch.as_tensor(b).detach().float().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
@@ -150,7 +150,8 @@ def _g5_batch(g):
     return x, y, mix, po
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 6e-2)])
+# bf16 gates: ~5x what MI355X shows against the reference fixture (loss 2.0e-5, worst gradient deviation 1.9e-3)
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 1e-2)])
 def test_g5_training_step_loss_and_gradients(precision, tol):
     g = np.load(os.path.join(GOLD, "g5_train_step.npz"))
     net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision=precision).train()
@@ -161,7 +162,7 @@ def test_g5_training_step_loss_and_gradients(precision, tol):
     loss.backward()
     le = abs(loss.item() - float(g["loss"])) / float(g["loss"])
     print(f"G5 {precision}: loss {loss.item():.6f} vs {float(g['loss']):.6f} (rel {le:.2e})")
-    assert le < tol
+    assert le < (tol if precision == "fp32" else 1e-4)
     names = [n for n, _ in O.state_dict_spec(625, 400)]
     params = dict(net.named_parameters())
     worst = 0.0
