@@ -24,6 +24,8 @@
 //
 // One template serves both numeric modes: T = bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate,
 // fp32 softmax) and T = float (v_mfma_f32_32x32x2_f32, exact fp32 -- parity mode).
+#include <type_traits>
+
 #include "common.h"
 
 namespace maest {
@@ -550,18 +552,23 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
 // =================================================================================== fused backward (bf16, N <= 320)
 // ONE workgroup per (batch, head) and ONE pass over the query tiles for dQ, dK and dV: 5 MFMA products per (query
 // block, key block) instead of the 7 of the two-kernel form above (S and dP are computed once), no delta kernel.
+// The waves are SPECIALISED, each role with its own loop (so that their register live ranges do not add up):
 //   * NKW = ceil(N / 32) KEY waves: wave w owns keys [32w, 32w + 32) for the whole launch -- its K and V rows are the
 //     B operands (registers) of  S = Q K^T  and  dP = dO V^T, and its dK^T / dV^T accumulators never leave registers.
-//   * 2 dQ waves (one per 32-wide half of the head dim).  dQ needs every key of a query row, i.e. every key wave's dS:
-//     the key waves drop dS (bf16, [key][q]) into an LDS exchange tile, and one barrier later the dQ waves compute
-//     dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]  with both operands gathered by the transpose read from row-major
-//     LDS (K resident for the whole launch).  While they do, the key waves already work on the next query tile, so
-//     with 10 + 2 waves every SIMD carries 3 waves and 48..52 MFMAs per tile.
-//   * the staging threads compute delta = rowsum(dO * O) on the fly from the chunks they carry to LDS.
-// Query tiles are 32 rows, double buffered; one barrier per tile.  Padded query rows carry lse = +BIG (P = 0);
-// padded keys have zero K rows in LDS (their dS multiplies zeros) and their dK / dV lanes are never stored.
-constexpr int FB_MAXW = 12;                       // 10 key waves + 2 dQ waves -> 3 waves per SIMD, <= 168 VGPRs
+//     Per 32-row query tile: 16 MFMAs, no global memory access at all.
+//   * 2 AUX waves.  (a) They feed the query tiles: wave A the Q tile, wave B the dO tile, computing
+//     delta = rowsum(dO * O) on the way, global -> registers -> LDS with the loads issued TWO tiles ahead (the
+//     exposed load latency of a one-tile-ahead version cost 27 % of the kernel).  (b) They compute dQ, one 32-wide
+//     half of the head dim each: dQ needs every key of a query row, i.e. every key wave's dS, which the key waves
+//     drop (bf16, [key][q]) into an LDS exchange tile; one barrier later
+//     dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]  with both operands gathered by the transpose read from
+//     row-major LDS (K resident for the whole launch), while the key waves already work on the next query tile.
+//     With 10 + 2 waves every SIMD carries 3 waves and 48..52 MFMAs per tile.
+// One barrier per tile.  Padded query rows carry lse = +BIG (P = 0); padded keys have zero K rows in LDS (their dS
+// multiplies zeros) and their dK / dV rows are never stored.  dK / dV leave through LDS as whole 128-byte rows.
+constexpr int FB_MAXW = 12;                       // 10 key waves + 2 aux waves -> 3 waves per SIMD, <= 168 VGPRs
 constexpr int FB_DS_PITCH = 72;                   // dS exchange tile [key][32 q] bf16: 64 B + 8 (conflict-free 8-byte stores)
+template <int ABL>   // ablation hooks (timing experiments only; 0 = the real kernel)
 __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv,
                                                                        const bf16_t* __restrict__ o,
                                                                        const bf16_t* __restrict__ dout,
@@ -575,13 +582,13 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthreads = blockDim.x;
-    // LDS map: K [nkw*32][64] | 2 x { Q tile [32][64], dO tile [32][64], lse[32], delta[32] } | 2 x dS [nkw*32][32 q]
+    // LDS map: K [nkw*32][64] | 2 x dS [nkw*32][32 q] | 2 x { Q tile [32][64], dO tile [32][64], lse[32], delta[32] }
     constexpr int QT = 32 * C::PITCH;              // one 32-row tile
     constexpr int QBUF = 2 * QT + 256;
-    char* k_lds = smem;
-    char* qbuf0 = smem + nkw * 32 * C::PITCH;
-    char* ds0 = qbuf0 + 2 * QBUF;
     const int DSBUF = nkw * 32 * FB_DS_PITCH;
+    char* k_lds = smem;
+    char* ds0 = smem + nkw * 32 * C::PITCH;
+    char* qbuf0 = ds0 + 2 * DSBUF;
 
     const int bh = xcd_remap(blockIdx.x, B * NHEADS);
     const int head = bh % NHEADS, b = bh / NHEADS;
@@ -591,163 +598,209 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
     const T* dobase = dout + (int64_t)b * N * OUT_LD + head * HD;
     const T* obase = o + (int64_t)b * N * OUT_LD + head * HD;
     const float* lse_b = lse + ((int64_t)b * NHEADS + head) * N;
+    T* dq_out = dqkv + (int64_t)b * N * QKV_LD + head * HD;
 
     const bool key_wave = wave < nkw;
-    const bool dq_wave = wave >= nkw && wave < nkw + 2;
-    const int key = wave * 32 + (lane & 31);
-    const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
+    const int aux = wave - nkw;                    // 0: Q feeder + dQ[:, 0:32], 1: dO feeder + dQ[:, 32:64]; >= 2: filler
 
-    // ---- staging: item i < 256 -> Q chunk (row i >> 3, chunk i & 7); 256 <= i < 512 -> dO chunk (+ O chunk for delta)
-    // (the launch always has >= 512 threads: one item per thread)
-    chunk16 st[1];
-    float st_delta[1] = {0.0f};
-    float st_lse = 0.0f;
-    auto stage_load = [&](int t) {
+    // ---- prologue, all threads: K of every key block -> LDS (rows >= N zero); up to 4 loads in flight per thread
+    {
+        const int total = (ABL & 8) ? 8 : nkw * 32 * 8;
+        for (int i0 = tid; i0 < total; i0 += 4 * nthreads) {
+            chunk16 v[4];
 #pragma unroll
-        for (int k = 0; k < 1; ++k) {
-            const int i = tid;
-            st[k][0] = 0; st[k][1] = 0; st[k][2] = 0; st[k][3] = 0;
-            st_delta[k] = 0.0f;
-            if (i < 512) {
-                const int r = (i & 255) >> 3, c = i & 7;
-                const int row = t * 32 + r;
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * nthreads;
+                const int r = i >> 3, c = i & 7;
+                v[k] = chunk16{0u, 0u, 0u, 0u};
+                if (i < total && r < N) v[k] = *reinterpret_cast<const chunk16*>(kbase + (uint32_t)(r * QKV_LD + c * 8));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * nthreads;
+                if (i < total) *reinterpret_cast<chunk16*>(k_lds + (i >> 3) * C::PITCH + (i & 7) * 16) = v[k];
+            }
+        }
+    }
+
+    if (key_wave) {
+        // =============================================================================== key waves
+        const int key = wave * 32 + (lane & 31);
+        const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
+        chunk16 kf[C::STEPS], vf[C::STEPS];
+        row_frags_load<T>(kf, kbase, QKV_LD, key, N, h);
+        row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
+        f32x16_t dk[2], dv[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[db][r] = 0.0f; dv[db][r] = 0.0f; }
+        __syncthreads();                                   // K in LDS, query tile 0 staged
+        for (int t = 0; t < nkw; ++t) {
+            const char* q_lds = qbuf0 + (t & 1) * QBUF;
+            const char* do_lds = q_lds + QT;
+            const float* lse_lds = reinterpret_cast<const float*>(q_lds + 2 * QT);
+            const float* dl_lds = lse_lds + 32;
+            if (!(ABL & 4)) {
+                f32x16_t s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+                mma_rows<T>(s, q_lds, 0, lane, kf);      // S[q][key]
+                mma_rows<T>(dp, do_lds, 0, lane, vf);    // dP[q][key]
+                char* ds_row = ds0 + (t & 1) * DSBUF + key * FB_DS_PITCH;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ql = 8 * g + 4 * h;        // local q of register 4g (4 consecutive rows)
+                    const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_lds + ql);
+                    const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dl_lds + ql);
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const int r = 4 * g + e;
+                        const f32x2_t sv = {s[r], s[r + 1]}, nl = {-l4[e], -l4[e + 1]};
+                        const f32x2_t dpv = {dp[r], dp[r + 1]}, dl = {d4[e], d4[e + 1]};
+                        const f32x2_t ev = __builtin_elementwise_fma(sv, c2v, nl);
+                        const f32x2_t pv = {fast_exp2<T>(ev[0]), fast_exp2<T>(ev[1])};
+                        const f32x2_t dsv = pv * (dpv - dl);
+                        s[r] = pv[0]; s[r + 1] = pv[1];       // P
+                        dp[r] = dsv[0]; dp[r + 1] = dsv[1];   // dS (unscaled)
+                    }
+                    chunk8 w;
+                    w[0] = pack_bf2(dp[4 * g], dp[4 * g + 1]);
+                    w[1] = pack_bf2(dp[4 * g + 2], dp[4 * g + 3]);
+                    *reinterpret_cast<chunk8*>(ds_row + ql * 2) = w;
+                }
+                mma_transposed<T>(dv, do_lds, 0, lane, s);    // dV^T[d][key] += dO^T[d][q] P[q][key]
+                mma_transposed<T>(dk, q_lds, 0, lane, dp);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            }
+            __syncthreads();
+        }
+        __syncthreads();                                   // the aux waves are done with K and the last dS tile
+        // dK / dV: registers -> this wave's private LDS patch (row = key, 128 B of d) -> whole rows, 16 B per lane
+        char* patch = smem + wave * (2 * 32 * C::PITCH);
+#pragma unroll
+        for (int tsel = 0; tsel < 2; ++tsel)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16_t& a = tsel == 0 ? dk[db] : dv[db];
+                    const float m = tsel == 0 ? scale : 1.0f;
+                    chunk8 w;
+                    w[0] = pack_bf2(a[4 * g] * m, a[4 * g + 1] * m);
+                    w[1] = pack_bf2(a[4 * g + 2] * m, a[4 * g + 3] * m);
+                    *reinterpret_cast<chunk8*>(patch + tsel * 32 * C::PITCH + (lane & 31) * C::PITCH +
+                                               (db * 32 + 8 * g + 4 * h) * 2) = w;
+                }
+        __syncthreads();
+#pragma unroll
+        for (int tsel = 0; tsel < 2; ++tsel)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = lane + 64 * j, r = i >> 3, c = i & 7;
+                const int krow = wave * 32 + r;
+                if (krow < N) {
+                    const chunk16 v = *reinterpret_cast<const chunk16*>(patch + tsel * 32 * C::PITCH + r * C::PITCH + c * 16);
+                    *reinterpret_cast<chunk16*>(dq_out + (uint32_t)(krow * QKV_LD + (1 + tsel) * NHEADS * HD + c * 8)) = v;
+                }
+            }
+    } else {
+        // =============================================================================== aux (and filler) waves
+        // feeder: lane handles chunks i = lane + 64 k (k = 0..3) of its 32 x 8-chunk tile: row i >> 3, chunk i & 7
+        struct Feed { chunk16 c[4]; float d[4]; float l; };
+        auto feed_load = [&](Feed& f, int t) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f.c[k] = chunk16{0u, 0u, 0u, 0u};
+                f.d[k] = 0.0f;
+            }
+            f.l = -NEG_BIG;                                // padded rows: P = 2^(-BIG) = 0
+            if (t >= nkw || aux > 1 || (ABL & 2)) return;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = lane + 64 * k, row = t * 32 + (i >> 3), c = i & 7;
                 if (row < N) {
-                    // 32-bit element offsets from wave-uniform bases (N <= 320 rows): no 64-bit per-lane pointers
-                    if (i < 256) {
-                        st[k] = *reinterpret_cast<const chunk16*>(qbase + (uint32_t)(row * QKV_LD + c * 8));
+                    if (aux == 0) {
+                        f.c[k] = *reinterpret_cast<const chunk16*>(qbase + (uint32_t)(row * QKV_LD + c * 8));
                     } else {
                         const uint32_t eo = (uint32_t)(row * OUT_LD + c * 8);
-                        st[k] = *reinterpret_cast<const chunk16*>(dobase + eo);
+                        f.c[k] = *reinterpret_cast<const chunk16*>(dobase + eo);
                         const chunk16 ov = *reinterpret_cast<const chunk16*>(obase + eo);
                         float acc = 0.0f;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            acc += u2f(st[k][e] << 16) * u2f(ov[e] << 16);
-                            acc += u2f(st[k][e] & 0xffff0000u) * u2f(ov[e] & 0xffff0000u);
+                            acc += u2f(f.c[k][e] << 16) * u2f(ov[e] << 16);
+                            acc += u2f(f.c[k][e] & 0xffff0000u) * u2f(ov[e] & 0xffff0000u);
                         }
-                        st_delta[k] = acc;
+                        f.d[k] = acc;
                     }
                 }
             }
-        }
-        if (tid < 32) {
-            const int row = t * 32 + tid;
-            st_lse = row < N ? lse_b[row] * LOG2E : -NEG_BIG;     // padded rows: P = 2^(-BIG) = 0
-        }
-    };
-    auto stage_store = [&](int buf) {
-        char* base = qbuf0 + buf * QBUF;
-#pragma unroll
-        for (int k = 0; k < 1; ++k) {
-            const int i = tid;
-            // the 8 chunks of a row sit in 8 consecutive lanes: butterfly over them
-            float d = st_delta[k];
-            d += __shfl_xor(d, 1, 64);
-            d += __shfl_xor(d, 2, 64);
-            d += __shfl_xor(d, 4, 64);
-            if (i < 512) {
-                const int r = (i & 255) >> 3, c = i & 7;
-                *reinterpret_cast<chunk16*>(base + (i < 256 ? 0 : QT) + r * C::PITCH + c * 16) = st[k];
-                if (i >= 256 && c == 0) reinterpret_cast<float*>(base + 2 * QT)[32 + r] = d;
+            if (aux == 0 && lane < 32) {
+                const int row = t * 32 + lane;
+                if (row < N) f.l = lse_b[row] * LOG2E;
             }
-        }
-        if (tid < 32) reinterpret_cast<float*>(base + 2 * QT)[tid] = st_lse;
-    };
-
-    // ---- prologue: K of every key block -> LDS (rows >= N zero), first query tile, this wave's K / V fragments
-    for (int i = tid; i < nkw * 32 * 8; i += nthreads) {
-        const int r = i >> 3, c = i & 7;
-        chunk16 v = {0u, 0u, 0u, 0u};
-        if (r < N) v = *reinterpret_cast<const chunk16*>(kbase + (uint32_t)(r * QKV_LD + c * 8));
-        *reinterpret_cast<chunk16*>(k_lds + r * C::PITCH + c * 16) = v;
-    }
-    stage_load(0);
-    chunk16 kf[C::STEPS], vf[C::STEPS];
-    if (key_wave) {
-        row_frags_load<T>(kf, kbase, QKV_LD, key, N, h);
-        row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
-    }
-    f32x16_t dk[2], dv[2];
+        };
+        auto feed_store = [&](const Feed& f, int t) {
+            if (t >= nkw || aux > 1) return;               // (wave-uniform)
+            char* base = qbuf0 + (t & 1) * QBUF;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.0f; dv[db][r] = 0.0f; }
-    stage_store(0);
-    __syncthreads();
-
-    auto dq_job = [&](int t) {      // dQ rows of query tile t from the dS tile the key waves left in ds0 + (t & 1) * DSBUF
-        const int db = wave - nkw;
-        const char* ds = ds0 + (t & 1) * DSBUF;
-        f32x16_t acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        for (int kb = 0; kb < nkw; ++kb) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const chunk16 a = frag_from_rows_bf16<C::PITCH>(k_lds, kb * 32, s, db, lane);        // K^T[d][key]
-                const chunk16 bq = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb * 32, s, 0, lane);       // dS^T[key][q]
-                mma_chunk<T>(acc, a, bq);
-            }
-        }
-        const int q = t * 32 + (lane & 31);
-        if (q < N) {
-            T* row = dqkv + ((int64_t)b * N + q) * QKV_LD + head * HD + db * 32;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                store4<T>(row + 8 * g + 4 * h, acc[4 * g] * scale, acc[4 * g + 1] * scale, acc[4 * g + 2] * scale,
-                          acc[4 * g + 3] * scale);
-        }
-    };
-
-    for (int t = 0; t < nkw; ++t) {
-        const char* qb = qbuf0 + (t & 1) * QBUF;
-        const char* q_lds = qb;
-        const char* do_lds = qb + QT;
-        const float* lse_lds = reinterpret_cast<const float*>(qb + 2 * QT);
-        const float* dl_lds = lse_lds + 32;
-        const bool more = t + 1 < nkw;
-        if (more) stage_load(t + 1);
-        if (key_wave) {
-            f32x16_t s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
-            mma_rows<T>(s, q_lds, 0, lane, kf);      // S[q][key]
-            mma_rows<T>(dp, do_lds, 0, lane, vf);    // dP[q][key]
-            char* ds_row = ds0 + (t & 1) * DSBUF + key * FB_DS_PITCH;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ql = 8 * g + 4 * h;        // local q of register 4g (4 consecutive rows)
-                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_lds + ql);
-                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dl_lds + ql);
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const int r = 4 * g + e;
-                    const f32x2_t sv = {s[r], s[r + 1]}, nl = {-l4[e], -l4[e + 1]};
-                    const f32x2_t dpv = {dp[r], dp[r + 1]}, dl = {d4[e], d4[e + 1]};
-                    const f32x2_t ev = __builtin_elementwise_fma(sv, c2v, nl);
-                    const f32x2_t pv = {fast_exp2<T>(ev[0]), fast_exp2<T>(ev[1])};
-                    const f32x2_t dsv = pv * (dpv - dl);
-                    s[r] = pv[0]; s[r + 1] = pv[1];       // P
-                    dp[r] = dsv[0]; dp[r + 1] = dsv[1];   // dS (unscaled)
+            for (int k = 0; k < 4; ++k) {
+                const int i = lane + 64 * k, r = i >> 3, c = i & 7;
+                *reinterpret_cast<chunk16*>(base + (aux == 0 ? 0 : QT) + r * C::PITCH + c * 16) = f.c[k];
+                if (aux == 1) {                            // the 8 chunks of a row sit in 8 consecutive lanes
+                    float d = f.d[k];
+                    d += __shfl_xor(d, 1, 64);
+                    d += __shfl_xor(d, 2, 64);
+                    d += __shfl_xor(d, 4, 64);
+                    if (c == 0) reinterpret_cast<float*>(base + 2 * QT)[32 + r] = d;
                 }
-                chunk8 w;
-                w[0] = pack_bf2(dp[4 * g], dp[4 * g + 1]);
-                w[1] = pack_bf2(dp[4 * g + 2], dp[4 * g + 3]);
-                *reinterpret_cast<chunk8*>(ds_row + ql * 2) = w;
             }
-            mma_transposed<T>(dv, do_lds, 0, lane, s);    // dV^T[d][key] += dO^T[d][q] P[q][key]
-            mma_transposed<T>(dk, q_lds, 0, lane, dp);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
-        } else if (dq_wave && t > 0) {
-            dq_job(t - 1);
+            if (aux == 0 && lane < 32) reinterpret_cast<float*>(base + 2 * QT)[lane] = f.l;
+        };
+        auto dq_job = [&](int t) {      // dQ[:, 32 aux ..] of query tile t from the dS tile in ds0 + (t & 1) * DSBUF
+            if (aux > 1 || (ABL & 1)) return;
+            const char* ds = ds0 + (t & 1) * DSBUF;
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int kb = 0; kb < nkw; ++kb) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const chunk16 a = frag_from_rows_bf16<C::PITCH>(k_lds, kb * 32, s, aux, lane);      // K^T[d][key]
+                    const chunk16 bq = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb * 32, s, 0, lane);       // dS^T[key][q]
+                    mma_chunk<T>(acc, a, bq);
+                }
+            }
+            const int q = t * 32 + (lane & 31);
+            if (q < N) {
+                T* row = dq_out + (uint32_t)(q * QKV_LD + aux * 32);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    store4<T>(row + 8 * g + 4 * h, acc[4 * g] * scale, acc[4 * g + 1] * scale, acc[4 * g + 2] * scale,
+                              acc[4 * g + 3] * scale);
+            }
+        };
+        Feed f0, f1;
+        feed_load(f0, 0);
+        feed_load(f1, 1);                                  // in flight across the first barrier
+        feed_store(f0, 0);
+        __syncthreads();                                   // K in LDS, query tile 0 staged
+        for (int t = 0; t < nkw; t += 2) {
+            // even step t: f1 carries tile t + 1; tile t + 2 goes into f0
+            feed_load(f0, t + 2);
+            if (t > 0) dq_job(t - 1);
+            feed_store(f1, t + 1);
+            __syncthreads();
+            if (t + 1 < nkw) {   // odd step t + 1: f0 carries tile t + 2; tile t + 3 goes into f1
+                feed_load(f1, t + 3);
+                dq_job(t);
+                feed_store(f0, t + 2);
+                __syncthreads();
+            }
         }
-        if (more) stage_store((t + 1) & 1);
+        dq_job(nkw - 1);
+        __syncthreads();                                   // LDS may be reused by the key waves' epilogue
         __syncthreads();
-    }
-    if (dq_wave) dq_job(nkw - 1);
-    if (key_wave && key < N) {
-        T* row = dqkv + ((int64_t)b * N + key) * QKV_LD + head * HD;
-        store_dT<T>(dk, row + NHEADS * HD, lane, scale);
-        store_dT<T>(dv, row + 2 * NHEADS * HD, lane, 1.0f);
     }
 }
 
@@ -776,12 +829,24 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
         const int nkw = (N + 31) / 32;
         if (nkw + 2 <= FB_MAXW && option(MAEST_OPT_ATTN_BWD) != 1) {
             const int smem_f = attn_bwd_fused_smem(N);
-            static DeviceOnce once_f;
-            ensure_dynamic_lds(once_f, &attn_bwd_fused_kernel, attn_bwd_fused_smem(32 * (FB_MAXW - 2)));
             const int waves = nkw + 2 < 8 ? 8 : nkw + 2;      // the staging step wants 512 threads (one chunk each)
-            hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * NHEADS), dim3(waves * 64), smem_f, st,
-                               (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N,
-                               scale);
+            auto go = [&](auto tag) {
+                constexpr int ABL = decltype(tag)::value;
+                static DeviceOnce once_f;
+                ensure_dynamic_lds(once_f, &attn_bwd_fused_kernel<ABL>, attn_bwd_fused_smem(32 * (FB_MAXW - 2)));
+                hipLaunchKernelGGL(attn_bwd_fused_kernel<ABL>, dim3(B * NHEADS), dim3(waves * 64), smem_f, st,
+                                   (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N,
+                                   scale);
+            };
+            switch (option(MAEST_OPT_ATTN_BWD)) {              // 2.. = ablation builds (scratch/attn_ablate.py)
+                case 2: go(std::integral_constant<int, 1>{}); break;
+                case 3: go(std::integral_constant<int, 2>{}); break;
+                case 4: go(std::integral_constant<int, 4>{}); break;
+                case 5: go(std::integral_constant<int, 8>{}); break;
+                case 6: go(std::integral_constant<int, 7>{}); break;
+                case 7: go(std::integral_constant<int, 15>{}); break;
+                default: go(std::integral_constant<int, 0>{}); break;
+            }
             return check_launch("maest_attn_bwd(fused)");
         }
     }

@@ -593,8 +593,8 @@ def test_config4_teacher_student_waveform_composite_matches_the_oracle_fp32():
 
 def test_hip_graph_captured_training_forward_equals_eager():
     """configs[4] "hipGraph-captured forward", training mode: eager call, capturing call and replays give the same
-    loss bit for bit (the forward has no atomics) and the same gradients up to the order of the split-K atomics; new
-    inputs and new draws on a replay follow the eager model."""
+    loss (up to the order of the BCE kernel's block-sum atomics: 1 ulp) and the same gradients up to the order of the
+    split-K atomics; new inputs and new draws on a replay follow the eager model."""
     g = np.load(os.path.join(GOLD, "g5_train_step.npz"))
     net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision="bf16").train()
     mod = Module(net=net, mixup_alpha=0.3)
@@ -614,7 +614,7 @@ def test_hip_graph_captured_training_forward_equals_eager():
     outs = [step(x, mix, po), step(x, mix, po), step(x2, mix2, po2), step(x, mix, po)]   # eager, capture, replay, replay
     assert any(st.get("graph") is not None for k, st in net._graphs.items() if k[0] == "train"), "nothing was captured"
     for (l, g1, g2), (le, ge1, ge2) in zip(outs, [e1, e1, e2, e1]):
-        assert l == le, (l, le)
+        assert abs(l - le) <= 3e-7 * abs(le), (l, le)
         assert rel_err(g1, ge1) < 1e-4 and rel_err(g2, ge2) < 1e-4
     # an optimizer step between replays: the recast inside the graph must pick the new weights up
     opt = mod.configure_optimizers()
@@ -624,7 +624,7 @@ def test_hip_graph_captured_training_forward_equals_eager():
         l1 = step(x, mix, po)[0]
     assert l1 < l0, "three AdamW steps on one batch must reduce the (graph-replayed) loss"
     net.enable_hip_graph(False)
-    assert step(x, mix, po)[0] == l1, "eager forward on the updated weights must equal the last replay"
+    assert abs(step(x, mix, po)[0] - l1) <= 3e-7 * l1, "eager forward on the updated weights must equal the last replay"
 
 
 def test_checkpoint_interop_on_the_device(tmp_path):
