@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmaest_hip.so")
 
 F32 = 0
 BF16 = 1
+F32X3 = 2   # fp32 tensors, split-bf16 matrix products (maest_gemm_nt in_dtype / maest_attn_fwd dtype only)
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_MUL, EPI_ATOMIC = 0, 1, 2, 3, 4
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float

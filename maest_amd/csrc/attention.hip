@@ -136,15 +136,16 @@ __device__ __forceinline__ void row_frags_load(chunk16 (&f)[AttnCfg<T>::STEPS], 
 }
 
 // acc[32 x 32] += sum_d  A_lds[row0 + (lane&31)][d] * frag[d]   (A from a row-major LDS tile)
-template <typename T>
+template <typename T, bool X3 = false>
 __device__ __forceinline__ void mma_rows(f32x16_t& acc, const char* lds, int row0, int lane,
                                          const chunk16 (&frag)[AttnCfg<T>::STEPS]) {
     using C = AttnCfg<T>;
     const char* rp = lds + (row0 + (lane & 31)) * C::PITCH + (lane >> 5) * 16;
 #pragma unroll
-    for (int s = 0; s < C::STEPS; ++s) {
-        const chunk16 a = *reinterpret_cast<const chunk16*>(rp + s * 32);
-        mma_chunk<T>(acc, a, frag[s]);
+    for (int s = 0; s < C::STEPS; s += 2) {      // chunk steps in pairs (STEPS is 4 / 8): see common.h mma_chunk2
+        const chunk16 a0 = *reinterpret_cast<const chunk16*>(rp + s * 32);
+        const chunk16 a1 = *reinterpret_cast<const chunk16*>(rp + (s + 1) * 32);
+        mma_chunk2<T, X3>(acc, a0, a1, frag[s], frag[s + 1]);
     }
 }
 // A-operand chunk At[d][rho] = Tile[rho][d] for step s of the 32-row group rho0, d = dblk*32 + (lane&31),
@@ -181,17 +182,18 @@ __device__ __forceinline__ chunk16 frag_from_rows<float>(const char* tile, int r
     return c;
 }
 // acc2[d-block db][32 d x 32 cols] += sum_{rho in 32-row group rho0} Tile[rho][d] * P[rho][col]
-template <typename T>
+template <typename T, bool X3 = false>
 __device__ __forceinline__ void mma_transposed(f32x16_t (&acc)[2], const char* tile, int rho0, int lane,
                                                const f32x16_t& p) {
     using C = AttnCfg<T>;
 #pragma unroll
-    for (int s = 0; s < C::ASTEPS; ++s) {
-        const chunk16 b = acc_to_chunk<T>(p, s);
+    for (int s = 0; s < C::ASTEPS; s += 2) {     // ASTEPS is 2 / 4
+        const chunk16 b0 = acc_to_chunk<T>(p, s), b1 = acc_to_chunk<T>(p, s + 1);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-            const chunk16 a = frag_from_rows<T>(tile, rho0, s, db, lane);
-            mma_chunk<T>(acc[db], a, b);
+            const chunk16 a0 = frag_from_rows<T>(tile, rho0, s, db, lane);
+            const chunk16 a1 = frag_from_rows<T>(tile, rho0, s + 1, db, lane);
+            mma_chunk2<T, X3>(acc[db], a0, a1, b0, b1);
         }
     }
 }
@@ -222,7 +224,7 @@ __device__ __forceinline__ void store_dT(const f32x16_t (&acc)[2], T* row_ptr, i
 }
 
 // =================================================================================== forward
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(const T* __restrict__ qkv,
                                                                                 T* __restrict__ out,
                                                                                 float* __restrict__ lse, int B, int N,
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(c
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
-            mma_rows<T>(s[kb], k_lds, kb * 32, lane, qf);
+            mma_rows<T, X3>(s[kb], k_lds, kb * 32, lane, qf);
         }
         // online softmax in the scaled log2 domain: p = 2^(s*c2 - m).  Only the ragged last tile pays for
         // key masking; the elementwise work is written on float pairs (v_pk_fma_f32 / v_pk_add_f32).
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(c
             for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         // O^T[d][q] += V^T[d][key] P^T[key][q]   (V^T gathered from the row-major V tile)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) mma_transposed<T>(o, v_lds, kb * 32, lane, s[kb]);
+        for (int kb = 0; kb < 2; ++kb) mma_transposed<T, X3>(o, v_lds, kb * 32, lane, s[kb]);
         }
         if (more) {
             char* nk = smem + ((kt + 1) & 1) * 2 * C::TILE;
@@ -706,56 +708,51 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
     } else {
         // =============================================================================== aux (and filler) waves
         // feeder: lane handles chunks i = lane + 64 k (k = 0..3) of its 32 x 8-chunk tile: row i >> 3, chunk i & 7
-        struct Feed { chunk16 c[4]; float d[4]; float l; };
+        // Every load is UNCONDITIONAL per lane (clamped row, wave-uniform base): a load under a lane condition merges
+        // with a default value at the join, which makes the compiler wait for it right there; and nothing consumes a
+        // loaded value before feed_store.  Rows >= N are zeroed when the tile is written to LDS.
+        struct Feed { chunk16 c[4]; chunk16 o[4]; float l; };
+        const T* fbase = aux == 0 ? qbase : dobase;        // wave-uniform
+        const int fld = aux == 0 ? QKV_LD : OUT_LD;
         auto feed_load = [&](Feed& f, int t) {
+            if (t >= nkw || aux > 1 || (ABL & 2)) return;  // (wave-uniform)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                f.c[k] = chunk16{0u, 0u, 0u, 0u};
-                f.d[k] = 0.0f;
+                const int i = lane + 64 * k, c = i & 7;
+                int row = t * 32 + (i >> 3);
+                row = row < N ? row : N - 1;
+                f.c[k] = *reinterpret_cast<const chunk16*>(fbase + (uint32_t)(row * fld + c * 8));
+                f.o[k] = *reinterpret_cast<const chunk16*>(obase + (uint32_t)(row * OUT_LD + c * 8));
             }
-            f.l = -NEG_BIG;                                // padded rows: P = 2^(-BIG) = 0
-            if (t >= nkw || aux > 1 || (ABL & 2)) return;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = lane + 64 * k, row = t * 32 + (i >> 3), c = i & 7;
-                if (row < N) {
-                    if (aux == 0) {
-                        f.c[k] = *reinterpret_cast<const chunk16*>(qbase + (uint32_t)(row * QKV_LD + c * 8));
-                    } else {
-                        const uint32_t eo = (uint32_t)(row * OUT_LD + c * 8);
-                        f.c[k] = *reinterpret_cast<const chunk16*>(dobase + eo);
-                        const chunk16 ov = *reinterpret_cast<const chunk16*>(obase + eo);
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            acc += u2f(f.c[k][e] << 16) * u2f(ov[e] << 16);
-                            acc += u2f(f.c[k][e] & 0xffff0000u) * u2f(ov[e] & 0xffff0000u);
-                        }
-                        f.d[k] = acc;
-                    }
-                }
-            }
-            if (aux == 0 && lane < 32) {
-                const int row = t * 32 + lane;
-                if (row < N) f.l = lse_b[row] * LOG2E;
-            }
+            int lrow = t * 32 + (lane & 31);
+            lrow = lrow < N ? lrow : N - 1;
+            f.l = lse_b[lrow];
         };
         auto feed_store = [&](const Feed& f, int t) {
-            if (t >= nkw || aux > 1) return;               // (wave-uniform)
+            if (t >= nkw || aux > 1 || (ABL & 2)) return;  // (wave-uniform)
             char* base = qbuf0 + (t & 1) * QBUF;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = lane + 64 * k, r = i >> 3, c = i & 7;
-                *reinterpret_cast<chunk16*>(base + (aux == 0 ? 0 : QT) + r * C::PITCH + c * 16) = f.c[k];
-                if (aux == 1) {                            // the 8 chunks of a row sit in 8 consecutive lanes
-                    float d = f.d[k];
+                const bool live = t * 32 + r < N;
+                chunk16 v = f.c[k];
+                if (!live) v = chunk16{0u, 0u, 0u, 0u};
+                *reinterpret_cast<chunk16*>(base + (aux == 0 ? 0 : QT) + r * C::PITCH + c * 16) = v;
+                if (aux == 1) {                            // delta = rowsum(dO * O); the 8 chunks of a row sit in 8 consecutive lanes
+                    float d = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        d += u2f(v[e] << 16) * u2f(f.o[k][e] << 16);
+                        d += u2f(v[e] & 0xffff0000u) * u2f(f.o[k][e] & 0xffff0000u);
+                    }
                     d += __shfl_xor(d, 1, 64);
                     d += __shfl_xor(d, 2, 64);
                     d += __shfl_xor(d, 4, 64);
                     if (c == 0) reinterpret_cast<float*>(base + 2 * QT)[32 + r] = d;
                 }
             }
-            if (aux == 0 && lane < 32) reinterpret_cast<float*>(base + 2 * QT)[lane] = f.l;
+            if (aux == 0 && lane < 32)                     // padded rows: lse = +BIG -> P = 2^(-BIG) = 0
+                reinterpret_cast<float*>(base + 2 * QT)[lane] = t * 32 + lane < N ? f.l * LOG2E : -NEG_BIG;
         };
         auto dq_job = [&](int t) {      // dQ[:, 32 aux ..] of query tile t from the dS tile in ds0 + (t & 1) * DSBUF
             if (aux > 1 || (ABL & 1)) return;
@@ -763,13 +760,21 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
             f32x16_t acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            for (int kb = 0; kb < nkw; ++kb) {
+            // two key blocks per trip, all 16 transpose reads issued before the 4 MFMAs that consume them (the chain on
+            // `acc` is serial anyway; what must overlap is the LDS latency)
+            for (int kb = 0; kb < nkw; kb += 2) {
+                const int kb1 = kb + 1 < nkw ? kb + 1 : kb;     // odd count: the last trip re-reads a block, weight 0
+                chunk16 a[4], bq[4];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const chunk16 a = frag_from_rows_bf16<C::PITCH>(k_lds, kb * 32, s, aux, lane);      // K^T[d][key]
-                    const chunk16 bq = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb * 32, s, 0, lane);       // dS^T[key][q]
-                    mma_chunk<T>(acc, a, bq);
+                    a[s] = frag_from_rows_bf16<C::PITCH>(k_lds, kb * 32, s, aux, lane);         // K^T[d][key]
+                    bq[s] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb * 32, s, 0, lane);          // dS^T[key][q]
+                    a[2 + s] = frag_from_rows_bf16<C::PITCH>(k_lds, kb1 * 32, s, aux, lane);
+                    bq[2 + s] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb1 * 32, s, 0, lane);
                 }
+                if (kb + 1 >= nkw) { bq[2] = chunk16{0u, 0u, 0u, 0u}; bq[3] = chunk16{0u, 0u, 0u, 0u}; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma_chunk<T>(acc, a[j], bq[j]);
             }
             const int q = t * 32 + (lane & 31);
             if (q < N) {
@@ -809,14 +814,14 @@ static int attn_bwd_fused_smem(int N) {
     return nkw * 32 * AttnCfg<bf16_t>::PITCH + 2 * (2 * 32 * AttnCfg<bf16_t>::PITCH + 256) + 2 * nkw * 32 * FB_DS_PITCH;
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, hipStream_t st) {
     using C = AttnCfg<T>;
     const int smem_bytes = 4 * C::TILE;
     static DeviceOnce once;
-    ensure_dynamic_lds(once, &attn_fwd_kernel<T>, smem_bytes);
+    ensure_dynamic_lds(once, &attn_fwd_kernel<T, X3>, smem_bytes);
     dim3 grid(((N + 127) / 128) * NHEADS * B);
-    hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, B, N, scale);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, X3>), grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, B, N, scale);
     return check_launch("maest_attn_fwd");
 }
 
@@ -874,8 +879,9 @@ extern "C" int maest_attn_fwd(const void* qkv, void* out, float* lse, int B, int
                               void* stream) {
     MAEST_REQUIRE(qkv && out, "maest_attn_fwd: null pointer");
     MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_fwd: bad shape B=%d N=%d", B, N);
-    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_attn_fwd: bad dtype %d", dtype);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3, "maest_attn_fwd: bad dtype %d", dtype);
     MAEST_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "maest_attn_fwd: 16-byte alignment");
+    if (dtype == MAEST_F32X3) return attn_fwd_launch<float, true>(qkv, out, lse, B, N, scale, (hipStream_t)stream);
     return dtype == MAEST_BF16 ? attn_fwd_launch<bf16_t>(qkv, out, lse, B, N, scale, (hipStream_t)stream)
                                : attn_fwd_launch<float>(qkv, out, lse, B, N, scale, (hipStream_t)stream);
 }

@@ -84,6 +84,47 @@ __device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const chunk16& a
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(a[q]), u2f(b[q]), acc, 0, 0, 0);
 }
 
+// Two chunk steps at once, optionally in "bf16 x 3" split precision (X3; fp32 operands only): every fp32 operand value
+// x is split as x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi), and a*b is accumulated (fp32) as
+// hi_a*hi_b + hi_a*lo_b + lo_a*hi_b on the full-rate bf16 matrix pipe: 3 MFMAs of K = 16 for 16 k-values against 8
+// exact-fp32 MFMAs at 1/16 of the rate (MI355X_MICROARCH.md: 32x32x16 bf16 = 32 cycles, 32x32x2 f32 = 64 cycles), i.e.
+// 96 instead of 512 matrix-pipe cycles, with a per-product error of ~2^-16 (the dropped lo*lo term and the
+// truncation of lo) instead of bf16's 2^-9.  SURVEY H1 "split-bf16"; the layouts are those of the fp32 mode.
+// Without X3 this is exactly two mma_chunk steps in the callers' original order (bit-identical results).
+__device__ __forceinline__ void split_bf16x8(const chunk16& c0, const chunk16& c1, bf16x8_t& hi, bf16x8_t& lo) {
+    chunk16 h, l;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const chunk16& c = j == 0 ? c0 : c1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float x0 = u2f(c[2 * e]), x1 = u2f(c[2 * e + 1]);
+            const uint32_t hb = pack_bf2(x0, x1);
+            const float r0 = x0 - u2f(hb << 16), r1 = x1 - u2f(hb & 0xffff0000u);   // exact in fp32
+            h[2 * j + e] = hb;
+            l[2 * j + e] = pack_bf2(r0, r1);
+        }
+    }
+    hi = __builtin_bit_cast(bf16x8_t, h);
+    lo = __builtin_bit_cast(bf16x8_t, l);
+}
+template <typename T, bool X3>
+__device__ __forceinline__ void mma_chunk2(f32x16_t& acc, const chunk16& a0, const chunk16& a1, const chunk16& b0,
+                                           const chunk16& b1) {
+    if constexpr (X3) {
+        static_assert(sizeof(T) == 4, "split precision applies to fp32 operands");
+        bf16x8_t ah, al, bh, bl;
+        split_bf16x8(a0, a1, ah, al);
+        split_bf16x8(b0, b1, bh, bl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);     // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    } else {
+        mma_chunk<T>(acc, a0, b0);
+        mma_chunk<T>(acc, a1, b1);
+    }
+}
+
 // C/D fragment map of every 32x32 MFMA on gfx950: register r of lane l holds
 //   row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),   col = l & 31.
 __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

@@ -550,7 +550,11 @@ extern "C" int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
                              int64_t ld_aux, int split_k, void* stream) {
     MAEST_REQUIRE(A && B && C, "maest_gemm_nt: null operand");
     MAEST_REQUIRE(M > 0 && N > 0 && K > 0, "maest_gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
-    MAEST_REQUIRE(in_dtype == MAEST_F32 || in_dtype == MAEST_BF16, "maest_gemm_nt: bad in_dtype %d", in_dtype);
+    MAEST_REQUIRE(in_dtype == MAEST_F32 || in_dtype == MAEST_BF16 || in_dtype == MAEST_F32X3,
+                  "maest_gemm_nt: bad in_dtype %d", in_dtype);
+    // split-bf16 products exist in the big-tile kernel; shapes it does not take run the exact fp32 kernel (a superset)
+    const bool x3 = in_dtype == MAEST_F32X3;
+    if (x3) in_dtype = MAEST_F32;
     MAEST_REQUIRE(out_dtype == MAEST_F32 || out_dtype == MAEST_BF16, "maest_gemm_nt: bad out_dtype %d", out_dtype);
     const int elt = in_dtype == MAEST_BF16 ? 2 : 4;
     const int ks = GEMM_ROWB / elt;
@@ -580,8 +584,8 @@ extern "C" int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     }
     p.vec_ok = vec ? 1 : 0;
     if (vec && split_k == 1) {   // large, aligned problems go to the 256x256 LDS-DMA kernel
-        const int rc = gemm_nt256_try(A, lda, B, ldb, in_dtype, C, ldc, out_dtype, M, N, K, bias, epi, aux_in, aux_out,
-                                      ld_aux, (hipStream_t)stream);
+        const int rc = gemm_nt256_try(A, lda, B, ldb, x3 ? MAEST_F32X3 : in_dtype, C, ldc, out_dtype, M, N, K, bias, epi,
+                                      aux_in, aux_out, ld_aux, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
     p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;

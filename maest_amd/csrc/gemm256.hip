@@ -588,7 +588,7 @@ __device__ __forceinline__ void epilogueW(char* smem, const f32x16_t (&acc)[2][4
 //     (applied on the DMA source address); a 16-lane ds_read_b128 group then covers all 16 slots of 256 B.
 // ================================================================================================
 
-template <typename T, int EPIV>
+template <typename T, int EPIV, bool X3 = false>
 __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -679,6 +679,22 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
         const int sc = stage < nstages ? stage : nstages - 1;   // past-the-end: re-load the last stage into a dead buffer
         char* dst = smem + buf * W2_UNIT + dma_off;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (X3) {
+            // split-bf16: the two k chunks of a fragment pair feed ONE K = 16 MFMA triple (common.h: mma_chunk2)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    mma_chunk2<T, true>(acc[nt][mt], fb[0][nt], fb[1][nt], fa[0][mt], fa[1][mt]);
+                    if (dma && (mt & 1)) {
+                        const int i = nt * 2 + (mt >> 1);
+                        const char* src = (is_b ? b_src[i] : a_src[i]) + (int64_t)sc * W2_ROWB;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -694,6 +710,7 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
                 }
 #endif
             }
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     auto next = [](int b, int by) { b += by; return b >= W2_NBUF ? b - W2_NBUF : b; };
@@ -762,11 +779,11 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     }
 }
 
-template <typename T, int EPIV>
+template <typename T, int EPIV, bool X3 = false>
 static int launch256w(Gemm256Params& p, hipStream_t stream) {
     static DeviceOnce once;
-    ensure_dynamic_lds(once, &gemm_nt256w_kernel<T, EPIV>, W2_SMEM);
-    hipLaunchKernelGGL((gemm_nt256w_kernel<T, EPIV>), dim3(p.tiles_m * p.tiles_n), dim3(512), W2_SMEM, stream, p);
+    ensure_dynamic_lds(once, &gemm_nt256w_kernel<T, EPIV, X3>, W2_SMEM);
+    hipLaunchKernelGGL((gemm_nt256w_kernel<T, EPIV, X3>), dim3(p.tiles_m * p.tiles_n), dim3(512), W2_SMEM, stream, p);
     return check_launch("maest_gemm_nt(256w)");
 }
 
@@ -912,6 +929,8 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
                    int out_dtype, int M, int N, int K, const float* bias, int epi, const void* aux_in, void* aux_out,
                    int64_t ld_aux, hipStream_t stream) {
     if (epi == MAEST_EPI_ATOMIC) return -1;
+    const bool x3 = in_dtype == MAEST_F32X3;     // fp32 tensors, split-bf16 products (full-line kernel only)
+    if (x3) in_dtype = MAEST_F32;
     // below ~8k rows the 256-row tiles leave most CUs idle (M = 560: 9-36 workgroups); the 128x128 kernel's finer
     // grid wins there (measured: one 10 s clip 2.13 -> 1.50 ms, batch 8 2.44 -> 2.23 ms, batch 16 equal).
     // MAEST_OPT_GEMM_MIN_M overrides the threshold (the emulator tests run the big kernels at M = 512).
@@ -937,6 +956,7 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
         // one-pass form never.  MAEST_OPT_GEMM_EPILOGUE = 0 / 1 / 2 forces one of them (-1 = this default).
         const int eopt = option(MAEST_OPT_GEMM_EPILOGUE);
         const int ev = eopt >= 0 ? eopt : (epi == MAEST_EPI_RESIDUAL ? 1 : 0);
+        if (x3) return ev == 1 ? launch256w<float, 1, true>(p, stream) : launch256w<float, 0, true>(p, stream);
         if (ev == 1) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 1>(p, stream) : launch256w<float, 1>(p, stream);
         if (ev == 2) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 2>(p, stream) : launch256w<float, 2>(p, stream);
         return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 0>(p, stream) : launch256w<float, 0>(p, stream);

@@ -20,7 +20,10 @@ Numeric modes (``model.precision``):
           fp32 CPU path to ~1e-5 (gate: 1e-3 relative, identical top-k labels);
   "bf16"  perf mode: bf16 MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm /
           softmax / GELU (the reference trains under fp16 autocast, ex_maest.py:51);
-  "auto"  (default) fp32 when ``model.training`` is False, bf16 when it is True.
+  "bf16x3" fast parity mode: fp32 tensors everywhere, the linear layers and the attention forward as three bf16
+          MFMAs on hi/lo splits of the fp32 operands (SURVEY H1 "split-bf16"): meets the same 1e-3 gate as "fp32"
+          at several times its speed (weight-gradient and attention-backward products stay exact fp32);
+  "auto"  (default) bf16 for a training forward that records a graph, fp32 otherwise.
 """
 from __future__ import annotations
 
@@ -215,6 +218,7 @@ class _Engine:
                 stop_block: int = -1, return_self_attention: bool = False, save: bool = False):
         """x3: fp32 [B, F, T] on the device; tok_ft: int32 [P, 2] kept patch tokens.  Returns (outputs, ctx)."""
         m, W = self.m, self.w
+        ops.set_f32_split(m.precision == "bf16x3")
         B, F, T = x3.shape
         P = int(tok_ft.shape[0])
         N = 2 + P
@@ -305,6 +309,7 @@ class _Engine:
         gradient is written straight into the sink's flat bucket view and reported as soon as it is
         complete, so the RCCL all-reduce of a bucket overlaps with the rest of the backward."""
         m, W = self.m, self.w
+        ops.set_f32_split(m.precision == "bf16x3")
         dt, B, N = ctx["dt"], ctx["B"], ctx["N"]
         Fp = m.freq_new_pos_embed.shape[2]
         M = B * N
@@ -597,11 +602,11 @@ class MAEST(nn.Module):
             # that records no graph -- eval(), no_grad, predict_labels on a fresh train-mode model -- is inference,
             # which the reference computes in fp32
             p = "bf16" if (self.training and recording) else "fp32"
-        if p in ("fp32", "float32"):
+        if p in ("fp32", "float32", "bf16x3"):
             return torch.float32
         if p in ("bf16", "bfloat16"):
             return torch.bfloat16
-        raise ValueError(f"precision must be 'auto', 'fp32' or 'bf16', got {self.precision!r}")
+        raise ValueError(f"precision must be 'auto', 'fp32', 'bf16x3' or 'bf16', got {self.precision!r}")
 
     # ---- input handling (maest.py:855-895) --------------------------------------------------
     def _prepare_input(self, x, melspectrogram_input):
@@ -780,7 +785,7 @@ class MAEST(nn.Module):
         if self._engine._weights_dirty:                  # a training step happened since the last eval forward
             self._engine.w.clear()
             self._engine._weights_dirty = False
-        key = (tuple(x3.shape), dt, kw["toffset"], int(kw["tok_ft"].shape[0]), str(x3.device),
+        key = (tuple(x3.shape), dt, self.precision, kw["toffset"], int(kw["tok_ft"].shape[0]), str(x3.device),
                sum(p._version for p in self.parameters()), self._engine.w.epoch)
         st = self._graphs.get(key)
         if st is None:                                   # first call: eager (fills the operand-copy caches)
@@ -811,7 +816,7 @@ class MAEST(nn.Module):
         stripes = kw.get("stripes")
         dyn = {"tok_ft": kw["tok_ft"], "perm": kw["perm"], "lam": kw["lam"],
                "t_stripes": None if stripes is None else stripes[0], "f_stripes": None if stripes is None else stripes[1]}
-        key = ("train", tuple(x3.shape), dt, kw["toffset"], str(x3.device),
+        key = ("train", tuple(x3.shape), dt, self.precision, kw["toffset"], str(x3.device),
                tuple((k, None if v is None else tuple(v.shape)) for k, v in dyn.items()))
         st = self._graphs.get(key)
         if st is None:

@@ -9,9 +9,25 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_ATOMIC, EPI_MUL, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F32, call
+from ._lib import BF16, EPI_ATOMIC, EPI_MUL, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F32, F32X3, call
 
 DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+# "bf16x3" precision mode: tensors stay fp32, but the big matrix products (maest_gemm_nt, maest_attn_fwd) run as three
+# bf16 MFMAs on hi/lo splits of their fp32 operands (csrc/common.h: mma_chunk2).  The engine switches it per forward /
+# backward pass (single host thread per process, like the reference's callers).
+_F32_SPLIT = False
+
+
+def set_f32_split(on: bool):
+    global _F32_SPLIT
+    _F32_SPLIT = bool(on)
+
+
+def _mm_code(dtype):
+    """dtype code of a matrix-product operand: fp32 becomes MAEST_F32X3 while the split mode is on."""
+    return F32X3 if (_F32_SPLIT and dtype == torch.float32) else DT[dtype]
+
 
 
 class KernelTimer:
@@ -111,7 +127,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
         if t is not None and not (t.is_cuda or _lib.host_emulation()):
             raise _lib.MaestHipError("maest_amd kernels need tensors on a HIP device; there is no CPU fallback")
     _chk(bias)
-    _timed_call("maest_gemm_nt", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), DT[a.dtype], _p(out),
+    _timed_call("maest_gemm_nt", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), _mm_code(a.dtype), _p(out),
                 out.stride(0), DT[out.dtype], M, N, K, _p(bias), epi, _p(aux_in), _p(aux_out), ld_aux, split_k, _s(a))
     return out
 
@@ -214,7 +230,7 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False):
     out = torch.empty((B * N, EMBED), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device) if save_lse else None
     _timed_call("maest_attn_fwd", 4.0 * B * HEADS * N * N * HEAD_DIM, _p(qkv), _p(out), _p(lse), B, N,
-                DT[qkv.dtype], scale, _s(qkv))
+                _mm_code(qkv.dtype), scale, _s(qkv))
     return (out, lse) if save_lse else out
 
 

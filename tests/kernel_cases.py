@@ -413,3 +413,37 @@ def case_swa(dev):
         want = [w + (c - w) * inv for w, c in zip(want, cur)]
     for g, w in zip(got, want):
         close(g, w, 1e-6, 1e-7, "swa running mean")
+
+
+# ------------------------------------------------------------------------------------- split-bf16 ("bf16x3") products
+def case_split_precision(dev, M=512, N=256, K=192, B=1, Ntok=75):
+    """fp32 tensors with the matrix products as three bf16 MFMAs on hi/lo operand splits (common.h: mma_chunk2):
+    the 256-tile NT GEMM (every epilogue path shares the main loop: checked on bias + residual) and the attention
+    forward, against fp64 references.  Gate: 1e-4 of the output scale -- 40x tighter than plain bf16 operands manage
+    (~4e-3) and an order of magnitude inside the 1e-3 parity gate; plain-bf16 results on the same data are asserted
+    to be well OUTSIDE it, so the test cannot pass on a silently taken bf16 path."""
+    a, b, bias, res = rnd((M, K), 50), rnd((N, K), 51), rnd((N,), 52), rnd((M, N), 53)
+    ref = (a.double() @ b.double().t() + bias.double() + res.double())
+    scale = ref.abs().max().item()
+    ops.set_f32_split(True)
+    try:
+        with ops.options(gemm_min_m=512):
+            c = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_dtype=torch.float32, epi=ops.EPI_RESIDUAL,
+                            aux_in=res.to(dev))
+        qkv = rnd((B * Ntok, 2304), 54)
+        out, lse = ops.attn_fwd(qkv.to(dev), B, Ntok, 0.125, save_lse=True)
+    finally:
+        ops.set_f32_split(False)
+    e = (c.double().cpu() - ref).abs().max().item() / scale
+    assert e < 1e-4, f"split-bf16 GEMM: {e:.2e} of the output scale"
+    with ops.options(gemm_min_m=512):
+        c16 = ops.gemm_nt(a.bfloat16().to(dev), b.bfloat16().to(dev), bias.to(dev), out_dtype=torch.float32,
+                          epi=ops.EPI_RESIDUAL, aux_in=res.to(dev))
+    e16 = (c16.double().cpu() - ref).abs().max().item() / scale
+    assert e16 > 10 * e, f"plain bf16 operands ({e16:.2e}) should be far coarser than the split ({e:.2e})"
+    x = qkv.double().requires_grad_(False)
+    oref, lref = _attn_ref(x, B, Ntok, 0.125)
+    eo = (out.double().cpu() - oref).abs().max().item() / oref.abs().max().item()
+    el = (lse.double().cpu() - lref).abs().max().item()
+    assert eo < 1e-4 and el < 1e-4, f"split-bf16 attention forward: out {eo:.2e}, lse {el:.2e}"
+    return e, eo

@@ -73,6 +73,11 @@ def test_emu_attention_multi_tile_spike(emu):
     KC.case_attention(emu, torch.float32, 1, 100, spike=True)
 
 
+def test_emu_split_bf16_products(emu):
+    """precision="bf16x3": fp32 tensors, three bf16 MFMAs per product on hi/lo operand splits (GEMM + attention fwd)."""
+    KC.case_split_precision(emu, M=512, N=256, K=192, B=1, Ntok=40)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_emu_patch_embed(emu, dtype):
     KC.case_patch_embed(emu, dtype, 2, 66, patchout=2, mix=True)

@@ -44,7 +44,7 @@ def _model(precision, **kw):
     return m.to(DEV), sd
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_inference_batch256_rows_are_independent_and_match_the_oracle(precision, gemm_options):
     # bit-exactness needs the SAME GEMM kernel for the 4-clip and the 256-clip batch (below 8192 rows the dispatcher
     # would otherwise pick the 128x128 kernel, whose accumulation order differs in the last bits)
@@ -64,11 +64,11 @@ def test_inference_batch256_rows_are_independent_and_match_the_oracle(precision,
         pl, _ = net(x[perm])
         assert torch.equal(pl, full[perm]), "permuting the batch must permute the outputs"
     want, wfeat = O.forward(x[sel[:2]].cpu(), sd, (96, 625))
-    tol = 1e-3 if precision == "fp32" else 3e-2
+    tol = 3e-2 if precision == "bf16" else 1e-3      # both parity modes meet the north_star gate
     e, ef = rel_err(small[:2], want), rel_err(sfeat[:2], wfeat)
     print(f"full-size inference {precision}: logits rel err {e:.2e}, features {ef:.2e}")
     assert e < tol and ef < tol
-    if precision == "fp32":
+    if precision != "bf16":
         assert torch.equal(small[:2].cpu().argsort(dim=1, descending=True)[:, :10],
                            want.argsort(dim=1, descending=True)[:, :10]), "top-10 label indices must be identical"
 

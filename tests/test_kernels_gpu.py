@@ -57,6 +57,13 @@ def test_attention(dtype, BN):
     KC.case_attention(DEV, dtype, *BN)
 
 
+def test_split_bf16_products():
+    """precision="bf16x3" kernels at model shapes: 1e-4 of the output scale against fp64."""
+    e, eo = KC.case_split_precision(DEV, M=8192, N=768, K=768, B=2, Ntok=290)
+    print(f"split-bf16: GEMM {e:.2e}, attention forward {eo:.2e} of the output scale")
+    KC.case_split_precision(DEV, M=1024, N=2304, K=3072, B=1, Ntok=560)
+
+
 def test_attention_rescale_branch():
     KC.case_attention(DEV, torch.float32, 1, 290, spike=True)
     KC.case_attention(DEV, torch.bfloat16, 1, 290, spike=True, bf16_tol=8e-2)

@@ -82,6 +82,33 @@ def test_g1_eval_bf16_reported():
     assert (np.argsort(-act)[:5] == g["top10"][:5]).all()
 
 
+def test_g1_eval_bf16x3_meets_the_parity_gate():
+    """precision="bf16x3" (split-bf16 products): the SAME gates as the exact-fp32 parity mode -- 1e-3
+    relative on logits / features against the reference fixture, identical top-10 and full 400-way ranking."""
+    g = np.load(os.path.join(GOLD, "g1_eval_10s.npz"))
+    m = build("discogs-maest-10s-pw-129e", 625, precision="bf16x3").eval()
+    x = randn((2, 96, 626), 7).to(DEV)
+    logits, feats = m(x.clone())
+    e1, e2 = rel_err(logits, g["logits"]), rel_err(feats, g["features"])
+    print(f"G1 bf16x3: logits rel err {e1:.2e}, features rel err {e2:.2e}")
+    assert e1 < 1e-3 and e2 < 1e-3
+    _, emb6 = m(x.clone(), transformer_block=6)
+    assert rel_err(emb6, g["emb6"]) < 1e-3
+    act, _ = m.predict_labels(x.clone())
+    assert np.abs(act - g["activations"]).max() < 1e-4
+    assert (np.argsort(-act)[:10] == g["top10"]).all(), "top-10 label indices must be bit-exact"
+    assert (np.argsort(-act) == np.argsort(-g["activations"])).all()
+    # and the training step through the same mode (dgrad GEMMs split, wgrad / attention backward exact fp32)
+    g5 = np.load(os.path.join(GOLD, "g5_train_step.npz"))
+    net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision="bf16x3").train()
+    mod = Module(net=net, mixup_alpha=0.3)
+    xb, y, mix, po = _g5_batch(g5)
+    loss = mod.training_step((xb, None, y), 0, _mixup=mix, _patchout=po)
+    loss.backward()
+    assert abs(loss.item() - float(g5["loss"])) / float(g5["loss"]) < 1e-5
+    assert rel_err(dict(net.named_parameters())["blocks.0.attn.qkv.weight"].grad[:16, :16], g5["grad_qkv0"]) < 1e-3
+
+
 def test_g1b_mel_like_input_fp32():
     g = np.load(os.path.join(GOLD, "g1b_eval_10s_mellike.npz"))
     m = build("discogs-maest-10s-pw-129e", 625).eval()
