@@ -37,8 +37,9 @@ extern "C" {
 #define MAEST_F32 0
 #define MAEST_BF16 1
 #define MAEST_F32X3 2 /* fp32 tensors, matrix products in split-bf16 ("bf16 x 3") precision: accepted as the INPUT dtype
-                         of maest_gemm_nt and as the dtype of maest_attn_fwd only (the other entry points take MAEST_F32
-                         for the same tensors); ~2^-16 per-product error on the full-rate bf16 matrix pipe */
+                         of maest_gemm_nt / maest_gemm_tn and as the dtype of maest_attn_fwd / maest_attn_bwd only (the
+                         other entry points take MAEST_F32 for the same tensors); ~2^-16 per-product error on the
+                         full-rate bf16 matrix pipe */
 
 /* GEMM epilogues */
 #define MAEST_EPI_NONE 0     /* C = acc + bias                                           */

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 }
 
 // =================================================================================== dK, dV
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, T* __restrict__ dqkv, int B, int N, float scale) {
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
             f32x16_t s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
-            mma_rows<T>(s, q_lds, qb * 32, lane, kf);     // S[q][key]
-            mma_rows<T>(dp, do_lds, qb * 32, lane, vf);   // dP[q][key]
+            mma_rows<T, X3>(s, q_lds, qb * 32, lane, kf);     // S[q][key]
+            mma_rows<T, X3>(dp, do_lds, qb * 32, lane, vf);   // dP[q][key]
             // P = 2^(S*c2 - lse), dS = P * (dP - delta) on float pairs.  No masks: padded query rows carry
             // lse = +BIG (P = 0 exactly), and a padded key column only feeds its own never-stored lane.
 #pragma unroll
@@ -452,8 +452,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
                     dp[r] = ds[0]; dp[r + 1] = ds[1];     // dS (unscaled)
                 }
             }
-            mma_transposed<T>(dv, do_lds, qb * 32, lane, s);   // dV^T[d][key] += dO^T[d][q] P[q][key]
-            mma_transposed<T>(dk, q_lds, qb * 32, lane, dp);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            mma_transposed<T, X3>(dv, do_lds, qb * 32, lane, s);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+            mma_transposed<T, X3>(dk, q_lds, qb * 32, lane, dp);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
         }
         }
         if (more) store_tile((qt + 1) & 1);
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
 }
 
 // =================================================================================== dQ
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, T* __restrict__ dqkv, int B, int N, float scale) {
@@ -521,8 +521,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
             f32x16_t s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
-            mma_rows<T>(s, k_lds, kb * 32, lane, qf);     // S^T[key][q]
-            mma_rows<T>(dp, v_lds, kb * 32, lane, dof);   // dP^T[key][q]
+            mma_rows<T, X3>(s, k_lds, kb * 32, lane, qf);     // S^T[key][q]
+            mma_rows<T, X3>(dp, v_lds, kb * 32, lane, dof);   // dP^T[key][q]
             // a padded key has a zero K row in LDS, so its dS column multiplies zeros below; the mask on the
             // ragged last tile only keeps 2^(-lse) from overflowing there
             if (kt == ntiles - 1 && (N & 63) != 0) {
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
                 const f32x2_t ds = pv * (dpv - dlv);
                 dp[r] = ds[0]; dp[r + 1] = ds[1];   // dS^T (unscaled)
             }
-            mma_transposed<T>(dq, k_lds, kb * 32, lane, dp);   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+            mma_transposed<T, X3>(dq, k_lds, kb * 32, lane, dp);   // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
         }
         }
         if (more) {
@@ -825,7 +825,7 @@ static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N,
     return check_launch("maest_attn_fwd");
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                            void* dqkv, int B, int N, float scale, hipStream_t st) {
     using C = AttnCfg<T>;
@@ -858,15 +858,15 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
     const int smem_a = 2 * (2 * C::TILE + 512);
     const int smem_b = 4 * C::TILE;
     static DeviceOnce once_a, once_b;
-    ensure_dynamic_lds(once_a, &attn_bwd_dkdv_kernel<T>, smem_a);
-    ensure_dynamic_lds(once_b, &attn_bwd_dq_kernel<T>, smem_b);
+    ensure_dynamic_lds(once_a, &attn_bwd_dkdv_kernel<T, X3>, smem_a);
+    ensure_dynamic_lds(once_b, &attn_bwd_dq_kernel<T, X3>, smem_b);
     const int64_t items = (int64_t)B * N * NHEADS * 4;
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
                        (const T*)out, (const T*)dout, delta, B, N);
     dim3 grid(((N + 127) / 128) * NHEADS * B);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, grid, dim3(256), smem_a, st, (const T*)qkv, (const T*)dout, lse,
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, X3>), grid, dim3(256), smem_a, st, (const T*)qkv, (const T*)dout, lse,
                        (const float*)delta, (T*)dqkv, B, N, scale);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), smem_b, st, (const T*)qkv, (const T*)dout, lse,
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, X3>), grid, dim3(256), smem_b, st, (const T*)qkv, (const T*)dout, lse,
                        (const float*)delta, (T*)dqkv, B, N, scale);
     return check_launch("maest_attn_bwd");
 }
@@ -890,7 +890,9 @@ extern "C" int maest_attn_bwd(const void* qkv, const void* out, const void* dout
                               float* delta, void* dqkv, int B, int N, int dtype, float scale, void* stream) {
     MAEST_REQUIRE(qkv && out && dout && lse && delta && dqkv, "maest_attn_bwd: null pointer");
     MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_bwd: bad shape B=%d N=%d", B, N);
-    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_attn_bwd: bad dtype %d", dtype);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3, "maest_attn_bwd: bad dtype %d", dtype);
+    if (dtype == MAEST_F32X3)
+        return attn_bwd_launch<float, true>(qkv, out, dout, lse, delta, dqkv, B, N, scale, (hipStream_t)stream);
     return dtype == MAEST_BF16
                ? attn_bwd_launch<bf16_t>(qkv, out, dout, lse, delta, dqkv, B, N, scale, (hipStream_t)stream)
                : attn_bwd_launch<float>(qkv, out, dout, lse, delta, dqkv, B, N, scale, (hipStream_t)stream);

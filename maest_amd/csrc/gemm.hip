@@ -602,14 +602,17 @@ extern "C" int maest_gemm_tn(const void* A, int64_t lda, const void* B, int64_t 
                              int64_t ldc, int M, int N, int K, float* colsum, int split_k, void* stream) {
     MAEST_REQUIRE(A && B && C, "maest_gemm_tn: null operand");
     MAEST_REQUIRE(M > 0 && N > 0 && K > 0, "maest_gemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
-    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_gemm_tn: bad dtype %d", dtype);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3, "maest_gemm_tn: bad dtype %d", dtype);
+    const bool x3 = dtype == MAEST_F32X3;        // split-bf16 products exist in the 256-tile kernel; other shapes: exact fp32
+    if (x3) dtype = MAEST_F32;
     const int elt = dtype == MAEST_BF16 ? 2 : 4;
     MAEST_REQUIRE(lda >= M && ldb >= N, "maest_gemm_tn: leading dims smaller than the matrix width");
     MAEST_REQUIRE((lda * elt) % 16 == 0 && (ldb * elt) % 16 == 0, "maest_gemm_tn: lda/ldb rows must be 16-byte multiples");
     MAEST_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "maest_gemm_tn: A/B must be 16-byte aligned");
     MAEST_REQUIRE(split_k >= 0, "maest_gemm_tn: split_k must be >= 0 (0 = automatic)");
     {   // large aligned problems go to the 256x256 LDS-DMA kernel
-        const int rc = gemm_tn256_try(A, lda, B, ldb, dtype, C, ldc, M, N, K, colsum, split_k, (hipStream_t)stream);
+        const int rc = gemm_tn256_try(A, lda, B, ldb, x3 ? MAEST_F32X3 : dtype, C, ldc, M, N, K, colsum, split_k,
+                                      (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
     if (split_k == 0) {

@@ -1050,7 +1050,7 @@ struct GemmTn256Params {
     int k_slices_per_split, split_k;
 };
 
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
     using C = Tn256<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1151,12 +1151,19 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
         tn_pin(fa, fb);
         __builtin_amdgcn_s_setprio(1);
 #ifndef MAEST_ABLATE_NO_MFMA
+        if constexpr (X3) {     // split-bf16: the two k chunks of a slice feed one K = 16 MFMA triple
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) mma_chunk2<T, true>(acc[a][b], fa[0][a], fa[1][a], fb[0][b], fb[1][b]);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) mma_chunk<T>(acc[a][b], fa[ks][a], fb[ks][b]);   // D rows = i, cols = j
+        }
         }
 #else
 #pragma unroll
@@ -1208,18 +1215,20 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
     }
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int launch_tn256(GemmTn256Params& p, int split_k, hipStream_t stream) {
     static DeviceOnce once;
-    ensure_dynamic_lds(once, &gemm_tn256_kernel<T>, G2_SMEM);
+    ensure_dynamic_lds(once, &gemm_tn256_kernel<T, X3>, G2_SMEM);
     p.split_k = split_k;
-    hipLaunchKernelGGL(gemm_tn256_kernel<T>, dim3(p.tiles_m * p.tiles_n * split_k), dim3(512), G2_SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_tn256_kernel<T, X3>), dim3(p.tiles_m * p.tiles_n * split_k), dim3(512), G2_SMEM, stream, p);
     return check_launch("maest_gemm_tn(256)");
 }
 
 // Called by maest_gemm_tn; returns -1 when the shape does not qualify.  split_k <= 0 = automatic.
 int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C, int64_t ldc, int M,
                    int N, int K, float* colsum, int split_k, hipStream_t stream) {
+    const bool x3 = dtype == MAEST_F32X3;        // fp32 tensors, split-bf16 products
+    if (x3) dtype = MAEST_F32;
     const int ks = dtype == MAEST_BF16 ? Tn256<bf16_t>::KS : Tn256<float>::KS;
     if ((M % 256) != 0 || (N % 256) != 0 || (K % ks) != 0 || K < 8 * ks) return -1;
     // variant 4: take any qualifying shape (emulator tests)
@@ -1239,6 +1248,7 @@ int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int d
     if (split_k > total / 4) split_k = total / 4 > 0 ? total / 4 : 1;
     p.k_slices_per_split = (total + split_k - 1) / split_k;
     split_k = (total + p.k_slices_per_split - 1) / p.k_slices_per_split;
+    if (x3) return launch_tn256<float, true>(p, split_k, stream);
     return dtype == MAEST_BF16 ? launch_tn256<bf16_t>(p, split_k, stream) : launch_tn256<float>(p, split_k, stream);
 }
 

@@ -22,7 +22,7 @@ Numeric modes (``model.precision``):
           softmax / GELU (the reference trains under fp16 autocast, ex_maest.py:51);
   "bf16x3" fast parity mode: fp32 tensors everywhere, the linear layers and the attention forward as three bf16
           MFMAs on hi/lo splits of the fp32 operands (SURVEY H1 "split-bf16"): meets the same 1e-3 gate as "fp32"
-          at several times its speed (weight-gradient and attention-backward products stay exact fp32);
+          at 2-2.5x its speed (forward and backward; small / ragged GEMMs stay exact fp32);
   "auto"  (default) bf16 for a training forward that records a graph, fp32 otherwise.
 """
 from __future__ import annotations

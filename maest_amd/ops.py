@@ -144,7 +144,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, colsum: Optiona
     for t in (a, b, out, colsum):
         if t is not None and not (t.is_cuda or _lib.host_emulation()):
             raise _lib.MaestHipError("maest_amd kernels need tensors on a HIP device; there is no CPU fallback")
-    _timed_call("maest_gemm_tn", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), DT[a.dtype], _p(out2),
+    _timed_call("maest_gemm_tn", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), _mm_code(a.dtype), _p(out2),
                 out2.stride(0), M, N, K, _p(colsum), split_k, _s(a))
     return out
 
@@ -240,7 +240,7 @@ def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float):
     delta = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device)
     dqkv = torch.empty_like(qkv)
     _timed_call("maest_attn_bwd", 10.0 * B * HEADS * N * N * HEAD_DIM, _p(qkv), _p(out), _p(dout), _p(lse),
-                _p(delta), _p(dqkv), B, N, DT[qkv.dtype], scale, _s(qkv))
+                _p(delta), _p(dqkv), B, N, _mm_code(qkv.dtype), scale, _s(qkv))
     return dqkv
 
 

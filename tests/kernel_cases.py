@@ -432,8 +432,26 @@ def case_split_precision(dev, M=512, N=256, K=192, B=1, Ntok=75):
                             aux_in=res.to(dev))
         qkv = rnd((B * Ntok, 2304), 54)
         out, lse = ops.attn_fwd(qkv.to(dev), B, Ntok, 0.125, save_lse=True)
+        # backward products: the wgrad form (256-tile TN kernel) and the attention backward
+        ta, tb = rnd((288, 256), 55), rnd((288, 512), 56)
+        tout = torch.zeros((256, 512), dtype=torch.float32, device=dev)
+        tcs = torch.zeros(256, dtype=torch.float32, device=dev)
+        with ops.options(gemm_variant=4):
+            ops.gemm_tn(ta.to(dev), tb.to(dev), tout, colsum=tcs, split_k=0)
+        xq = qkv.double().requires_grad_(True)
+        oref, lref = _attn_ref(xq, B, Ntok, 0.125)
+        dout = rnd((B * Ntok, 768), 57)
+        oref.backward(dout.double())
+        dqkv = ops.attn_bwd(qkv.to(dev), oref.detach().float().to(dev), dout.to(dev), lref.detach().float().contiguous().to(dev),
+                            B, Ntok, 0.125)
     finally:
         ops.set_f32_split(False)
+    tref = ta.double().t() @ tb.double()
+    et = (tout.double().cpu() - tref).abs().max().item() / tref.abs().max().item()
+    assert et < 1e-4, f"split-bf16 TN GEMM: {et:.2e} of the output scale"
+    assert (tcs.double().cpu() - ta.double().sum(0)).abs().max().item() < 1e-4
+    eb = (dqkv.double().cpu() - xq.grad).abs().max().item() / xq.grad.abs().max().item()
+    assert eb < 1e-4, f"split-bf16 attention backward: {eb:.2e} of the gradient scale"
     e = (c.double().cpu() - ref).abs().max().item() / scale
     assert e < 1e-4, f"split-bf16 GEMM: {e:.2e} of the output scale"
     with ops.options(gemm_min_m=512):
@@ -441,8 +459,7 @@ def case_split_precision(dev, M=512, N=256, K=192, B=1, Ntok=75):
                           epi=ops.EPI_RESIDUAL, aux_in=res.to(dev))
     e16 = (c16.double().cpu() - ref).abs().max().item() / scale
     assert e16 > 10 * e, f"plain bf16 operands ({e16:.2e}) should be far coarser than the split ({e:.2e})"
-    x = qkv.double().requires_grad_(False)
-    oref, lref = _attn_ref(x, B, Ntok, 0.125)
+    oref, lref = oref.detach(), lref.detach()
     eo = (out.double().cpu() - oref).abs().max().item() / oref.abs().max().item()
     el = (lse.double().cpu() - lref).abs().max().item()
     assert eo < 1e-4 and el < 1e-4, f"split-bf16 attention forward: out {eo:.2e}, lse {el:.2e}"
