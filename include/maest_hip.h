@@ -63,6 +63,7 @@ const char* maest_last_error(void);
 #define MAEST_OPT_GEMM_EPILOGUE 2
 #define MAEST_OPT_GEMM_ABLATE 4 /* env MAEST_GEMM_ABLATE, timing experiments only (WRONG results): 1 = the 256-tile NT
                                    GEMMs skip the C-tile drain, 2 = they drain into a 256-row window */
+#define MAEST_OPT_LN_BWD_BLOCKS 5 /* env MAEST_LN_BWD_BLOCKS, default 512: workgroup cap of the LayerNorm backward grid */
 #define MAEST_OPT_ATTN_BWD 3 /* env MAEST_ATTN_BWD, default 0: fused one-pass attention backward where it applies
                                 (bf16, N <= 320); 1 = always the two-kernel dK/dV + dQ form */
 int maest_set_option(int opt, int value, int restore_default);
@@ -110,6 +111,12 @@ int maest_cast_weights_multi(int n, const float* const* src, void* const* dst, v
 int maest_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y,
                         int64_t ldy, int y_dtype, float* mean, float* rstd, int rows, int cols,
                         float eps, void* stream);
+/* The residual add fused into the LayerNorm that follows it (models/maest.py:418-419 then :395/:405 of the next
+ * LayerNorm): x_out[r,:] = x[r,:] + delta[r,:] (fp32, contiguous [rows, 768]; may alias x) and y = LN(x_out).
+ * delta: the proj / fc2 Linear output including its bias, in delta_dtype. */
+int maest_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, float* x_out, const float* gamma,
+                            const float* beta, void* y, int y_dtype, float* mean, float* rstd, int rows, int cols,
+                            float eps, void* stream);
 /* dx_out[r,:] = dres[r,:] (may be NULL) + LN'(dy)[r,:]   (fp32), plus an optional copy of dx_out in
  * `dx_lp_dtype` (operand of the next dgrad GEMM).  dgamma/dbeta (fp32 [cols]) are ACCUMULATED
  * (atomics) -- zero them first. */

@@ -29,6 +29,7 @@ SIGNATURES = {
     "maest_cast_weights": [_P, _P, _P, _I, _I, _I, _P],
     "maest_cast_weights_multi": [_I, _P, _P, _P, _P, _P, _I, _P],
     "maest_layernorm_fwd": [_P, _L, _P, _P, _P, _L, _I, _P, _P, _I, _I, _F, _P],
+    "maest_add_layernorm_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
     "maest_layernorm_bwd": [_P, _L, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
     "maest_attn_fwd": [_P, _P, _P, _I, _I, _I, _F, _P],
     "maest_attn_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
@@ -55,7 +56,7 @@ SIGNATURES = {
 }
 
 ABI_VERSION = 2
-OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "gemm_ablate": 4}
+OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "gemm_ablate": 4, "ln_bwd_blocks": 5}
 
 _lib = None
 _host_emulation = False  # set only by tests/emu

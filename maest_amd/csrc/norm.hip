@@ -78,6 +78,48 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
+// Residual add fused into the LayerNorm that follows it (x += attn(...) ; LN2(x)  /  x += mlp(...) ; next block's LN1(x),
+// models/maest.py:418-419): x_out = x + delta is written once (the new residual stream, also the saved input of this
+// LayerNorm's backward) and normalised in the same pass.  The proj / fc2 GEMMs then emit `delta` (bias included) in
+// the operand dtype instead of reading and rewriting the fp32 stream in their epilogue: the same bytes move, but in
+// this streaming kernel (6 TB/s) rather than in a GEMM epilogue during which the matrix pipes idle.
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x, const void* __restrict__ delta,
+                                                                int delta_dtype, float* __restrict__ x_out,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, void* __restrict__ y,
+                                                                int y_dtype, float* __restrict__ mean,
+                                                                float* __restrict__ rstd, int rows, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;  // wave-uniform
+    float v[12];
+    ln_load_row(x + (int64_t)row * LN_COLS, lane, v);
+#pragma unroll
+    for (int i = 0; i < LN_VEC; ++i) {
+        const int64_t off = (int64_t)row * LN_COLS + i * 256 + lane * 4;
+        float d[4];
+        load_row4(delta, delta_dtype, off, d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * i + e] = d[e] + v[4 * i + e];     // (acc + bias) + x, the epilogue's order
+        *reinterpret_cast<float4*>(x_out + off) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+    float mu, rs;
+    ln_stats(v, eps, mu, rs);
+#pragma unroll
+    for (int i = 0; i < LN_VEC; ++i) {
+        const int c = i * 256 + lane * 4;
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+        store_row4(y, y_dtype, (int64_t)row * LN_COLS + c, (v[4 * i] - mu) * rs * g.x + bt.x,
+                   (v[4 * i + 1] - mu) * rs * g.y + bt.y, (v[4 * i + 2] - mu) * rs * g.z + bt.z,
+                   (v[4 * i + 3] - mu) * rs * g.w + bt.w);
+    }
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+}
+
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ;  dgamma += dy * xhat ; dbeta += dy
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_dtype,
                                                             const float* __restrict__ x, int64_t ldx,
@@ -269,6 +311,19 @@ extern "C" int maest_layernorm_fwd(const float* x, int64_t ldx, const float* gam
     return check_launch("maest_layernorm_fwd");
 }
 
+extern "C" int maest_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, float* x_out,
+                                       const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+                                       float* rstd, int rows, int cols, float eps, void* stream) {
+    MAEST_REQUIRE(x && delta && x_out && gamma && beta && y, "maest_add_layernorm_fwd: null pointer");
+    MAEST_REQUIRE(cols == LN_COLS, "maest_add_layernorm_fwd: cols must be 768, got %d", cols);
+    MAEST_REQUIRE(rows > 0, "maest_add_layernorm_fwd: rows=%d", rows);
+    MAEST_REQUIRE((y_dtype == MAEST_F32 || y_dtype == MAEST_BF16) && (delta_dtype == MAEST_F32 || delta_dtype == MAEST_BF16),
+                  "maest_add_layernorm_fwd: bad dtype");
+    hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, delta,
+                       delta_dtype, x_out, gamma, beta, y, y_dtype, mean, rstd, rows, eps);
+    return check_launch("maest_add_layernorm_fwd");
+}
+
 extern "C" int maest_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const float* x, int64_t ldx,
                                    const float* gamma, const float* mean, const float* rstd, const float* dres,
                                    float* dx_out, void* dx_lp, int dx_lp_dtype, float* dgamma, float* dbeta,
@@ -278,7 +333,8 @@ extern "C" int maest_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, c
     MAEST_REQUIRE(rows > 0, "maest_layernorm_bwd: rows=%d", rows);
     MAEST_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0, "maest_layernorm_bwd: leading dims must be multiples of 4");
     int blocks = (rows + 3) / 4;
-    if (blocks > 512) blocks = 512;
+    const int cap = option(MAEST_OPT_LN_BWD_BLOCKS);     // grid-stride cap: per-block dgamma/dbeta partials vs waves in flight
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 4 * 2 * LN_COLS * 4, (hipStream_t)stream, dy,
                        lddy, dy_dtype, x, ldx, gamma, mean, rstd, dres, dx_out, dx_lp, dx_lp_dtype, dgamma, dbeta,
                        rows);

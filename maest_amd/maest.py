@@ -251,10 +251,22 @@ class _Engine:
             ctx["blocks"] = []
         scale = m.blocks[0].attn.scale
         nblocks = len(m.blocks) if stop_block < 0 else stop_block + 1
+        # bf16 perf mode: the proj / fc2 GEMMs emit their output (bias included) in bf16 and the residual add rides in
+        # the LayerNorm that follows (ops.add_layernorm_fwd) -- the fp32 stream is read and rewritten by a streaming
+        # kernel instead of a GEMM epilogue (proj: 196 -> ~100 us).  The reference rounds these Linear outputs to 16 bits
+        # before the add as well (autocast, ex_maest.py:51).  fp32 modes keep the fused fp32 residual epilogue.
+        split_add = dt != torch.float32
+        pending = None            # delta of the previous block's fc2, to be added by this block's norm1
         for i in range(nblocks):
             blk = m.blocks[i]
-            r = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, dt, save_stats=save)
-            ln1, mean1, rstd1 = r if save else (r, None, None)
+            if pending is not None:
+                r = ops.add_layernorm_fwd(x, pending, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, dt, save_stats=save)
+                x, ln1 = r[0], r[1]
+                mean1, rstd1 = (r[2], r[3]) if save else (None, None)
+                pending = None
+            else:
+                r = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, dt, save_stats=save)
+                ln1, mean1, rstd1 = r if save else (r, None, None)
             qkv = ops.gemm_nt(ln1, W.get(blk.attn.qkv.weight, dt), blk.attn.qkv.bias, out_dtype=dt)
             r = ops.attn_fwd(qkv, B, N, scale, save_lse=save)
             ao, lse = r if save else (r, None)
@@ -262,19 +274,28 @@ class _Engine:
                 # Block.forward(..., return_self_attention=True) returns attn(norm1(x)) (maest.py:414-416)
                 a = ops.gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=torch.float32)
                 return ops.embed_pool(a.reshape(B, N, EMBED_DIM)), None
-            x1 = ops.gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=torch.float32,
-                             epi=ops.EPI_RESIDUAL, aux_in=x)
-            r = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save_stats=save)
-            ln2, mean2, rstd2 = r if save else (r, None, None)
+            if split_add:
+                d1 = ops.gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=dt)
+                r = ops.add_layernorm_fwd(x, d1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save_stats=save)
+                x1, ln2 = r[0], r[1]
+                mean2, rstd2 = (r[2], r[3]) if save else (None, None)
+            else:
+                x1 = ops.gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=torch.float32,
+                                 epi=ops.EPI_RESIDUAL, aux_in=x)
+                r = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save_stats=save)
+                ln2, mean2, rstd2 = r if save else (r, None, None)
             h = torch.empty((M, blk.mlp.fc1.out_features), dtype=dt, device=x.device) if save else None
             g = ops.gemm_nt(ln2, W.get(blk.mlp.fc1.weight, dt), blk.mlp.fc1.bias, out_dtype=dt, epi=ops.EPI_GELU,
                             aux_out=h)
-            x2 = ops.gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=torch.float32,
-                             epi=ops.EPI_RESIDUAL, aux_in=x1)
             if save:
                 ctx["blocks"].append(dict(x=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse, x1=x1,
                                           mean2=mean2, rstd2=rstd2, ln2=ln2, h=h, g=g))
-            x = x2
+            if split_add and i + 1 < nblocks:
+                pending = ops.gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=dt)
+                x = x1
+            else:             # last block of this pass: nothing follows that could carry the add
+                x = ops.gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=torch.float32,
+                                epi=ops.EPI_RESIDUAL, aux_in=x1)
         xb = x.reshape(B, N, EMBED_DIM)
         if stop_block >= 0:
             return ops.embed_pool(xb), None

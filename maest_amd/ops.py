@@ -62,14 +62,15 @@ class KernelTimer:
 _TIMER = None
 
 
-def _timed_call(name, work, *args):
+def _timed_call(name, work, *args, _entry=None):
+    """`name`: timing bucket (KernelTimer); `_entry`: C-ABI symbol when it differs from the bucket."""
     t = _TIMER
     if t is None or (t.kinds is not None and name not in t.kinds):
-        return call(name, *args)
+        return call(_entry or name, *args)
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    call(name, *args)
+    call(_entry or name, *args)
     e1.record()
     t.records.append((name, e0, e1, work))
 HEADS = 12
@@ -210,6 +211,20 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype, save_stat
     _timed_call("maest_layernorm_fwd", 0.0, _p(x), x.stride(0), _p(gamma), _p(beta), _p(y), cols, DT[out_dtype], _p(mean),
          _p(rstd), rows, cols, eps, _s(x))
     return (y, mean, rstd) if save_stats else y
+
+
+def add_layernorm_fwd(x: torch.Tensor, delta: torch.Tensor, gamma, beta, eps: float, out_dtype, save_stats=False):
+    """x fp32 [rows, 768] + delta (any operand dtype) -> (x_new fp32, y (out_dtype)[, mean, rstd])."""
+    _chk(x, delta, gamma, beta)
+    assert x.dtype == torch.float32 and x.dim() == 2 and delta.shape == x.shape
+    rows, cols = x.shape
+    x_new = torch.empty_like(x)
+    y = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    _timed_call("maest_layernorm_fwd", 0.0, _p(x), _p(delta), DT[delta.dtype], _p(x_new), _p(gamma), _p(beta), _p(y),
+                DT[out_dtype], _p(mean), _p(rstd), rows, cols, eps, _s(x), _entry="maest_add_layernorm_fwd")
+    return (x_new, y, mean, rstd) if save_stats else (x_new, y)
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, lp_dtype=None, want_fp32=True):
@@ -376,7 +391,7 @@ def logmel(wave: torch.Tensor, consts) -> torch.Tensor:
     B, S = wave.shape
     T = 1 + S // 256
     out = torch.empty((B, 96, T), dtype=torch.float32, device=wave.device)
-    call("maest_logmel", _p(wave), B, S, _p(consts.window), _p(consts.twiddle), _p(consts.fb_start),
+    _timed_call("maest_logmel", 0.0, _p(wave), B, S, _p(consts.window), _p(consts.twiddle), _p(consts.fb_start),
          _p(consts.fb_len), _p(consts.fb_w), consts.fb_stride, consts.log_scale, consts.norm_mean,
          consts.norm_2std, _p(out), _s(wave))
     return out

@@ -134,6 +134,13 @@ def case_layernorm(dev, dtype, rows):
     close(y, ref, rt, at, "layernorm fwd")
     close(mean, x.mean(1), 1e-5, 1e-6, "layernorm mean")
     close(rstd, 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-6), 1e-5, 1e-6, "layernorm rstd")
+    # residual add fused into the LayerNorm that follows it: x_new = x + delta exactly (one fp32 add per element),
+    # y / statistics = those of the plain kernel on x_new, bit for bit
+    delta = rnd((rows, 768), 12, 0.5).to(dtype)
+    xn, y2, mean2, rstd2 = ops.add_layernorm_fwd(x.to(dev), delta.to(dev), g.to(dev), b.to(dev), 1e-6, dtype, save_stats=True)
+    assert torch.equal(xn.cpu(), x + delta.float()), "fused residual add must be the exact fp32 sum"
+    y3, mean3, rstd3 = ops.layernorm_fwd(xn, g.to(dev), b.to(dev), 1e-6, dtype, save_stats=True)
+    assert torch.equal(y2, y3) and torch.equal(mean2, mean3) and torch.equal(rstd2, rstd3)
     # backward
     dy = rnd((rows, 768), 10).to(dtype)
     dres = rnd((rows, 768), 11)
