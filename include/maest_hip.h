@@ -63,7 +63,7 @@ const char* maest_last_error(void);
 #define MAEST_OPT_GEMM_EPILOGUE 2
 #define MAEST_OPT_GEMM_ABLATE 4 /* env MAEST_GEMM_ABLATE, timing experiments only (WRONG results): 1 = the 256-tile NT
                                    GEMMs skip the C-tile drain, 2 = they drain into a 256-row window */
-#define MAEST_OPT_LN_BWD_BLOCKS 5 /* env MAEST_LN_BWD_BLOCKS, default 512: workgroup cap of the LayerNorm backward grid */
+#define MAEST_OPT_LN_BWD_BLOCKS 5 /* env MAEST_LN_BWD_BLOCKS, default 1024: workgroup cap of the LayerNorm backward grid */
 #define MAEST_OPT_ATTN_BWD 3 /* env MAEST_ATTN_BWD, default 0: fused one-pass attention backward where it applies
                                 (bf16, N <= 320); 1 = always the two-kernel dK/dV + dQ form */
 int maest_set_option(int opt, int value, int restore_default);

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ;  dgamma += dy * xhat ; dbeta += dy
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_dtype,
+__global__ __launch_bounds__(256, 5) void layernorm_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_dtype,
                                                             const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
@@ -133,12 +133,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][768]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float g4[12], ag[12], ab[12];
-#pragma unroll
-    for (int i = 0; i < LN_VEC; ++i) {
-        const float4 g = *reinterpret_cast<const float4*>(gamma + i * 256 + lane * 4);
-        g4[4 * i] = g.x; g4[4 * i + 1] = g.y; g4[4 * i + 2] = g.z; g4[4 * i + 3] = g.w;
-    }
+    // (<= 96 VGPRs, launch bound 5 waves / SIMD: this HBM-bound kernel then fits beside a workgroup of the 256-tile
+    // wgrad GEMM -- 2 x 208 VGPRs per SIMD, 128 KiB of LDS -- that runs on the side stream at the same time; gamma is
+    // re-read per row from L1 instead of living in 12 registers)
+    float ag[12], ab[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { ag[i] = 0.0f; ab[i] = 0.0f; }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             const float xh = (xv[i] - mu) * rs;
-            const float g = dv[i] * g4[i];
+            const float g = dv[i] * gamma[(i >> 2) * 256 + lane * 4 + (i & 3)];
             s1 += g;
             s2 += g * xh;
             ag[i] += dv[i] * xh;
