@@ -61,15 +61,9 @@ const char* maest_last_error(void);
 #define MAEST_OPT_GEMM_MIN_M 0
 #define MAEST_OPT_GEMM_VARIANT 1
 #define MAEST_OPT_GEMM_EPILOGUE 2
-#define MAEST_OPT_GEMM_ABLATE 4 /* env MAEST_GEMM_ABLATE, timing experiments only (WRONG results): 1 = the 256-tile NT
-                                   GEMMs skip the C-tile drain, 2 = they drain into a 256-row window */
-#define MAEST_OPT_LN_BWD_BLOCKS 5 /* env MAEST_LN_BWD_BLOCKS, default 1024: workgroup cap of the LayerNorm backward grid */
-#define MAEST_OPT_ATTN_FWD 6 /* env MAEST_ATTN_FWD, default 0: K/V-resident attention forward where it applies (bf16,
-                                N <= 320); 1 = always the streaming kernel */
-#define MAEST_OPT_GEMM_STORE 7 /* env MAEST_GEMM_STORE: cache policy of the 256-tile GEMMs' C-tile stores: 0 = non-temporal,
-                                  1 = sc1 (write-through, line dropped from L2), 2 = plain */
 #define MAEST_OPT_ATTN_BWD 3 /* env MAEST_ATTN_BWD, default 0: fused one-pass attention backward where it applies
                                 (bf16, N <= 320); 1 = always the two-kernel dK/dV + dQ form */
+#define MAEST_OPT_LN_BWD_BLOCKS 4 /* env MAEST_LN_BWD_BLOCKS, default 1024: workgroup cap of the LayerNorm backward grid */
 int maest_set_option(int opt, int value, int restore_default);
 int maest_get_option(int opt, int* value);
 

@@ -56,7 +56,7 @@ SIGNATURES = {
 }
 
 ABI_VERSION = 2
-OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "gemm_ablate": 4, "ln_bwd_blocks": 5, "attn_fwd": 6, "gemm_store": 7}
+OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "ln_bwd_blocks": 4}
 
 _lib = None
 _host_emulation = False  # set only by tests/emu

@@ -37,8 +37,6 @@ constexpr int OUT_LD = NHEADS * HD;      // 768
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;
-// drain this wave's vector-memory queue (LDS-DMA included) without touching the LDS / scalar counters
-#define MAEST_ATTN_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 template <typename T>
 struct AttnCfg {
@@ -334,160 +332,6 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(c
     }
 }
 
-// =================================================================================== forward, K / V resident (bf16, N <= 320)
-// For the training shapes (N = 281 / 290) the whole K and V of one (batch, head) fit in LDS as UNPADDED 128-byte
-// rows (40 + 40 KiB), so they are fetched once by LDS-DMA (no register round trip, no ds_write pass) and the key
-// loop runs without a single barrier or staging step: every wave walks the five 64-key tiles on its own.  A
-// workgroup is 5 waves = 160 queries, two workgroups per (batch, head) and per CU (2 x 80 KiB): while one streams
-// its K / V in, the other computes.  Bank conflicts: chunk c of row r sits at chunk position c ^ swz(r) with
-// swz(r) = r[1] r[2] r[3] (bit-reversed), applied on the DMA SOURCE address (the LDS image of a DMA is lane-linear);
-// with it both the row-per-lane 16-byte reads (K as MFMA A operand) and the transpose reads (V^T) are conflict-free
-// (scratch/lds_banks.py; the padded pitch of the streaming kernel costs the transpose reads 2x).
-__device__ __forceinline__ int swz128(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
-// fill rows [0, nrows8 * 8) of an unpadded tile from `base` (row stride ld elements); rows >= nvalid re-read row
-// nvalid - 1 (finite data; their keys are masked / their probabilities are exactly 0).  Instruction j of a wave = 8 rows.
-__device__ __forceinline__ void dma_rows128(char* tile, const bf16_t* base, int ld, int nrows8, int nvalid, int wave,
-                                            int nwaves, int lane) {
-    for (int j = wave; j < nrows8; j += nwaves) {
-        int row = 8 * j + (lane >> 3);
-        const int p = lane & 7;
-        const int src_chunk = p ^ swz128(row);
-        row = row < nvalid ? row : nvalid - 1;
-        const bf16_t* src = base + (uint32_t)(row * ld + src_chunk * 8);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(tile + j * 1024), 16, 0, 0);
-    }
-}
-// acc[32 x 32] += sum_d A[row0 + (lane&31)][d] * frag[d]     (A = swizzled unpadded tile)
-__device__ __forceinline__ void mma_rows_swz(f32x16_t& acc, const char* tile, int row0, int lane,
-                                             const chunk16 (&frag)[4]) {
-    const int row = row0 + (lane & 31), f = swz128(row), h = lane >> 5;
-    const char* rp = tile + row * 128;
-#pragma unroll
-    for (int s = 0; s < 4; s += 2) {
-        const chunk16 a0 = *reinterpret_cast<const chunk16*>(rp + (((2 * s + h) ^ f) << 4));
-        const chunk16 a1 = *reinterpret_cast<const chunk16*>(rp + (((2 * s + 2 + h) ^ f) << 4));
-        mma_chunk2<bf16_t, false>(acc, a0, a1, frag[s], frag[s + 1]);
-    }
-}
-__device__ __forceinline__ chunk16 frag_from_rows_swz(const char* tile, int rho0, int s, int dblk, int lane) {
-    const int h = lane >> 5, g16 = (lane >> 4) & 1, q = lane & 15;
-    const int row = rho0 + 16 * s + 4 * h + (q >> 2);
-    const int cb = (dblk * 32 + 16 * g16 + 4 * (q & 3)) * 2;          // byte column
-    const char* p0 = tile + row * 128 + ((((cb >> 4) ^ swz128(row)) << 4) | (cb & 15));
-    const char* p1 = tile + (row + 8) * 128 + ((((cb >> 4) ^ swz128(row + 8)) << 4) | (cb & 15));
-    const v4i16a_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16a_t*)(p0));
-    const v4i16a_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16a_t*)(p1));
-    const chunk8 l2 = __builtin_bit_cast(chunk8, lo), h2 = __builtin_bit_cast(chunk8, hi);
-    chunk16 c;
-    c[0] = l2[0]; c[1] = l2[1]; c[2] = h2[0]; c[3] = h2[1];
-    return c;
-}
-__device__ __forceinline__ void mma_transposed_swz(f32x16_t (&acc)[2], const char* tile, int rho0, int lane,
-                                                   const f32x16_t& p) {
-    const chunk16 b0 = acc_to_chunk<bf16_t>(p, 0), b1 = acc_to_chunk<bf16_t>(p, 1);
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        const chunk16 a0 = frag_from_rows_swz(tile, rho0, 0, db, lane);
-        const chunk16 a1 = frag_from_rows_swz(tile, rho0, 1, db, lane);
-        mma_chunk2<bf16_t, false>(acc[db], a0, a1, b0, b1);
-    }
-}
-
-constexpr int FR_WAVES = 5;
-__global__ __launch_bounds__(FR_WAVES * 64, 2) void attn_fwd_resident_kernel(const bf16_t* __restrict__ qkv,
-                                                                              bf16_t* __restrict__ out,
-                                                                              float* __restrict__ lse, int B, int N,
-                                                                              float scale) {
-    using T = bf16_t;
-    using C = AttnCfg<T>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // K [nkb*32][128 B] | V [nkb*32][128 B]
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nkb = (N + 31) >> 5;
-    const int wg = xcd_remap(blockIdx.x, 2 * NHEADS * B);       // the two halves of a (batch, head) sit on one XCD
-    const int half = wg & 1, bh = wg >> 1;
-    const int head = bh % NHEADS, b = bh / NHEADS;
-    const int qb0 = half * ((nkb + 1) >> 1);                     // this workgroup's first 32-query block
-    const int q0 = (qb0 + wave) * 32;
-    const int q = q0 + (lane & 31);
-    const bool wave_active = q0 < N && (half == 1 || wave < ((nkb + 1) >> 1));   // wave-uniform
-    const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
-    const T* kbase = qbase + NHEADS * HD;
-    const T* vbase = qbase + 2 * NHEADS * HD;
-    char* k_lds = smem;
-    char* v_lds = smem + nkb * 32 * 128;
-
-    dma_rows128(k_lds, kbase, QKV_LD, nkb * 4, N, wave, FR_WAVES, lane);
-    dma_rows128(v_lds, vbase, QKV_LD, nkb * 4, N, wave, FR_WAVES, lane);
-    chunk16 qf[C::STEPS];
-    row_frags_load<T>(qf, qbase, QKV_LD, q, N, h);
-    f32x16_t o[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
-    float m_run = NEG_BIG, l_run = 0.0f;
-    const float c2 = scale * LOG2E;
-    MAEST_ATTN_WAIT_VM0();
-    __builtin_amdgcn_s_barrier();
-    if (!wave_active) return;
-
-    const int ntiles = (N + 63) >> 6;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const bool second = kt * 64 + 32 < nkb * 32;            // wave-uniform: the tile's second 32-key block exists
-        f32x16_t s[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = kb == 1 && !second ? NEG_BIG : 0.0f;
-            if (kb == 0 || second) mma_rows_swz(s[kb], k_lds, kt * 64 + kb * 32, lane, qf);   // S^T[key][q]
-        }
-        if (kt == ntiles - 1 && (N & 63) != 0) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kt * 64 + kb * 32 + frag_row(r, lane) >= N) s[kb][r] = NEG_BIG;
-        }
-        float mx = NEG_BIG;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * c2);
-        const float alpha = fast_exp2<T>(m_run - m_new);
-        m_run = m_new;
-        const f32x2_t c2v = {c2, c2}, nm = {-m_new, -m_new};
-        f32x2_t ps = {0.0f, 0.0f};
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2_t sv = {s[kb][r], s[kb][r + 1]};
-                const f32x2_t e = __builtin_elementwise_fma(sv, c2v, nm);
-                const f32x2_t pv = {fast_exp2<T>(e[0]), fast_exp2<T>(e[1])};
-                s[kb][r] = pv[0];
-                s[kb][r + 1] = pv[1];
-                ps += pv;
-            }
-        l_run = l_run * alpha + (ps[0] + ps[1]);
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        mma_transposed_swz(o, v_lds, kt * 64, lane, s[0]);        // O^T[d][q] += V^T[d][key] P^T[key][q]
-        if (second) mma_transposed_swz(o, v_lds, kt * 64 + 32, lane, s[1]);
-    }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (q < N) {
-        store_dT<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv);
-        if (lse != nullptr && h == 0) lse[((int64_t)b * NHEADS + head) * N + q] = m_run * LN2 + logf(l_tot);
-    }
-}
-
 // =================================================================================== delta
 // delta[b,head,q] = sum_d dO[b,q,head,d] * O[b,q,head,d]      (4 lanes per (row, head))
 template <typename T>
@@ -726,7 +570,6 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
 // multiplies zeros) and their dK / dV rows are never stored.  dK / dV leave through LDS as whole 128-byte rows.
 constexpr int FB_MAXW = 12;                       // 10 key waves + 2 aux waves -> 3 waves per SIMD, <= 168 VGPRs
 constexpr int FB_DS_PITCH = 72;                   // dS exchange tile [key][32 q] bf16: 64 B + 8 (conflict-free 8-byte stores)
-template <int ABL>   // ablation hooks (timing experiments only; 0 = the real kernel)
 __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv,
                                                                        const bf16_t* __restrict__ o,
                                                                        const bf16_t* __restrict__ dout,
@@ -763,7 +606,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
 
     // ---- prologue, all threads: K of every key block -> LDS (rows >= N zero); up to 4 loads in flight per thread
     {
-        const int total = (ABL & 8) ? 8 : nkw * 32 * 8;
+        const int total = nkw * 32 * 8;
         for (int i0 = tid; i0 < total; i0 += 4 * nthreads) {
             chunk16 v[4];
 #pragma unroll
@@ -799,7 +642,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
             const char* do_lds = q_lds + QT;
             const float* lse_lds = reinterpret_cast<const float*>(q_lds + 2 * QT);
             const float* dl_lds = lse_lds + 32;
-            if (!(ABL & 4)) {
+            {
                 f32x16_t s, dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
@@ -871,7 +714,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
         const T* fbase = aux == 0 ? qbase : dobase;        // wave-uniform
         const int fld = aux == 0 ? QKV_LD : OUT_LD;
         auto feed_load = [&](Feed& f, int t) {
-            if (t >= nkw || aux > 1 || (ABL & 2)) return;  // (wave-uniform)
+            if (t >= nkw || aux > 1) return;               // (wave-uniform)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = lane + 64 * k, c = i & 7;
@@ -885,7 +728,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
             f.l = lse_b[lrow];
         };
         auto feed_store = [&](const Feed& f, int t) {
-            if (t >= nkw || aux > 1 || (ABL & 2)) return;  // (wave-uniform)
+            if (t >= nkw || aux > 1) return;               // (wave-uniform)
             char* base = qbuf0 + (t & 1) * QBUF;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -911,7 +754,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
                 reinterpret_cast<float*>(base + 2 * QT)[lane] = t * 32 + lane < N ? f.l * LOG2E : -NEG_BIG;
         };
         auto dq_job = [&](int t) {      // dQ[:, 32 aux ..] of query tile t from the dS tile in ds0 + (t & 1) * DSBUF
-            if (aux > 1 || (ABL & 1)) return;
+            if (aux > 1) return;
             const char* ds = ds0 + (t & 1) * DSBUF;
             f32x16_t acc;
 #pragma unroll
@@ -973,17 +816,6 @@ static int attn_bwd_fused_smem(int N) {
 template <typename T, bool X3 = false>
 static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, hipStream_t st) {
     using C = AttnCfg<T>;
-    if constexpr (sizeof(T) == 2) {
-        const int nkb = (N + 31) / 32;
-        if (nkb <= 10 && option(MAEST_OPT_ATTN_FWD) != 1) {       // K and V of a (batch, head) resident in LDS
-            const int smem_r = 2 * nkb * 32 * 128;
-            static DeviceOnce once_r;
-            ensure_dynamic_lds(once_r, &attn_fwd_resident_kernel, 2 * 10 * 32 * 128);
-            hipLaunchKernelGGL(attn_fwd_resident_kernel, dim3(2 * NHEADS * B), dim3(FR_WAVES * 64), smem_r, st,
-                               (const bf16_t*)qkv, (bf16_t*)out, lse, B, N, scale);
-            return check_launch("maest_attn_fwd(resident)");
-        }
-    }
     const int smem_bytes = 4 * C::TILE;
     static DeviceOnce once;
     ensure_dynamic_lds(once, &attn_fwd_kernel<T, X3>, smem_bytes);
@@ -1002,23 +834,11 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
         if (nkw + 2 <= FB_MAXW && option(MAEST_OPT_ATTN_BWD) != 1) {
             const int smem_f = attn_bwd_fused_smem(N);
             const int waves = nkw + 2 < 8 ? 8 : nkw + 2;      // the staging step wants 512 threads (one chunk each)
-            auto go = [&](auto tag) {
-                constexpr int ABL = decltype(tag)::value;
-                static DeviceOnce once_f;
-                ensure_dynamic_lds(once_f, &attn_bwd_fused_kernel<ABL>, attn_bwd_fused_smem(32 * (FB_MAXW - 2)));
-                hipLaunchKernelGGL(attn_bwd_fused_kernel<ABL>, dim3(B * NHEADS), dim3(waves * 64), smem_f, st,
-                                   (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N,
-                                   scale);
-            };
-            switch (option(MAEST_OPT_ATTN_BWD)) {              // 2.. = ablation builds (scratch/attn_ablate.py)
-                case 2: go(std::integral_constant<int, 1>{}); break;
-                case 3: go(std::integral_constant<int, 2>{}); break;
-                case 4: go(std::integral_constant<int, 4>{}); break;
-                case 5: go(std::integral_constant<int, 8>{}); break;
-                case 6: go(std::integral_constant<int, 7>{}); break;
-                case 7: go(std::integral_constant<int, 15>{}); break;
-                default: go(std::integral_constant<int, 0>{}); break;
-            }
+            static DeviceOnce once_f;
+            ensure_dynamic_lds(once_f, &attn_bwd_fused_kernel, attn_bwd_fused_smem(32 * (FB_MAXW - 2)));
+            hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * NHEADS), dim3(waves * 64), smem_f, st,
+                               (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N,
+                               scale);
             return check_launch("maest_attn_bwd(fused)");
         }
     }

@@ -43,27 +43,7 @@ struct Gemm256Params {
     int M, N, K;
     int out_dtype, epi;
     int tiles_m, tiles_n;
-    int store_policy;  // C-tile store cache policy (store_c16)
-    int ablate;        // timing experiments only: 1 = no C-tile drain, 2 = drain into a 256-row (L2-resident) window
 };
-
-// C-tile store, 16 bytes per lane, with a selectable cache policy (p.store_policy; MAEST_OPT_GEMM_STORE):
-//   0: non-temporal (streaming hint; the line still allocates in the XCD's L2)
-//   1: sc1 = write-through, the line is DROPPED from L2 -- a C tile is never re-read by this kernel, and at 128..256
-//      KiB per tile and 32 tiles in flight per XCD it otherwise sweeps the 4 MiB L2 every round, evicting the weight
-//      panel that all workgroups re-read (measured on the qkv shape: 3.4x the algorithmic fetch, the excess = the
-//      weights once per round per XCD)
-//   2: plain
-__device__ __forceinline__ void store_c16(chunk16 v, void* dst, int policy) {
-#if defined(__AMDGCN__)
-    if (policy == 1) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
-        return;
-    }
-#endif
-    if (policy == 2) *reinterpret_cast<chunk16*>(dst) = v;
-    else __builtin_nontemporal_store(v, reinterpret_cast<chunk16*>(dst));
-}
 
 template <int OSZ>
 struct Epi256 {
@@ -162,7 +142,7 @@ __device__ __forceinline__ void stage256_pair(char* smem, int region, const f32x
 
 template <int OSZ, int MODE, int ROWS = Epi256<OSZ>::ROWS>
 __device__ __forceinline__ void drain256(const char* smem, void* dst, int64_t ld, const void* aux, int64_t ld_aux,
-                                         int mbase, int n0, int M, int N, int tid, int rowmask = -1, int policy = 0) {
+                                         int mbase, int n0, int M, int N, int tid) {
     using E = Epi256<OSZ>;
 #pragma unroll 4
     for (int c = tid; c < ROWS * E::CPR; c += 512) {
@@ -191,7 +171,8 @@ __device__ __forceinline__ void drain256(const char* smem, void* dst, int64_t ld
             }
         }
         // streaming output: written once, re-read by a later kernel after > L2-size of other traffic
-        store_c16(v, reinterpret_cast<char*>(dst) + ((int64_t)(gm & rowmask) * ld + gn) * OSZ, policy);
+        // streaming output: written once, re-read by a later kernel after > L2-size of other traffic
+        __builtin_nontemporal_store(v, reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ));
     }
 }
 
@@ -210,8 +191,8 @@ __device__ __forceinline__ void epilogue256(char* smem, const f32x16_t (&acc)[2]
             const int mbase = m0 + pwm * 128 + mt0 * 32;
             if (wm == pwm) stage256_pair<OSZ, EXACT, PMT>(smem, REGION, acc, p.bias, n0, p.N, mt0, wn, lane);
             __syncthreads();
-            drain256<OSZ, 0, PR>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
-            drain256<OSZ, 0, PR>(smem + REGION, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
+            drain256<OSZ, 0, PR>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
+            drain256<OSZ, 0, PR>(smem + REGION, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
             __syncthreads();
         }
         return;
@@ -226,21 +207,21 @@ __device__ __forceinline__ void epilogue256(char* smem, const f32x16_t (&acc)[2]
             if (p.aux_out != nullptr) {
                 if (mine) stage256<OSZ, 2, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
                 __syncthreads();
-                drain256<OSZ, 0>(smem, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
+                drain256<OSZ, 0>(smem, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
                 __syncthreads();
             }
             if (mine) stage256<OSZ, 1, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
             __syncthreads();
-            drain256<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
+            drain256<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
         } else {
             if (mine) stage256<OSZ, 0, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
             __syncthreads();
             if (p.epi == MAEST_EPI_RESIDUAL)
-                drain256<OSZ, 1>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
+                drain256<OSZ, 1>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
             else if (p.epi == MAEST_EPI_MUL)
-                drain256<OSZ, 2>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
+                drain256<OSZ, 2>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
             else
-                drain256<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
+                drain256<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
         }
         __syncthreads();
     }
@@ -460,8 +441,7 @@ __device__ __forceinline__ void stageT(char* smem, int region, const f32x16_t& a
 
 template <int OSZ, int MODE, int TNC, int NTH>
 __device__ __forceinline__ void drainT(const char* smem, int rows, void* dst, int64_t ld, const void* aux,
-                                       int64_t ld_aux, int mbase, int n0, int M, int N, int tid, int rowmask = -1,
-                                       int policy = 0) {
+                                       int64_t ld_aux, int mbase, int n0, int M, int N, int tid) {
     using E = EpiT<OSZ, TNC>;
 #pragma unroll 4
     for (int c = tid; c < rows * E::CPR; c += NTH) {
@@ -489,7 +469,8 @@ __device__ __forceinline__ void drainT(const char* smem, int rows, void* dst, in
                 }
             }
         }
-        store_c16(v, reinterpret_cast<char*>(dst) + ((int64_t)(gm & rowmask) * ld + gn) * OSZ, policy);
+        // streaming output: written once, re-read by a later kernel after > L2-size of other traffic
+        __builtin_nontemporal_store(v, reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ));
     }
 }
 
@@ -518,14 +499,14 @@ __device__ __forceinline__ void epilogueT(char* smem, const f32x16_t (&acc)[2][4
             __syncthreads();
             const int mbase = m0 + ps * RP;
             if (PAIR) {
-                drainT<OSZ, 0, TNC, NTH>(smem, RP, p.C, p.ldc, nullptr, 0, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
-                drainT<OSZ, 0, TNC, NTH>(smem + REGION, RP, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
+                drainT<OSZ, 0, TNC, NTH>(smem, RP, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
+                drainT<OSZ, 0, TNC, NTH>(smem + REGION, RP, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
             } else if (p.epi == MAEST_EPI_RESIDUAL) {
-                drainT<OSZ, 1, TNC, NTH>(smem, RP, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
+                drainT<OSZ, 1, TNC, NTH>(smem, RP, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
             } else if (p.epi == MAEST_EPI_MUL) {
-                drainT<OSZ, 2, TNC, NTH>(smem, RP, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
+                drainT<OSZ, 2, TNC, NTH>(smem, RP, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
             } else {
-                drainT<OSZ, 0, TNC, NTH>(smem, RP, p.C, p.ldc, nullptr, 0, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
+                drainT<OSZ, 0, TNC, NTH>(smem, RP, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
             }
             if (ps + 1 < 256 / RP) __syncthreads();
         }
@@ -566,8 +547,8 @@ __device__ __forceinline__ void epilogueW_run(char* smem, const f32x16_t (&acc)[
         for (int half = 0; half < 2; ++half) {                  // the two 32-row groups of the pass are 128 rows apart
             const int mbase = m0 + half * 128 + ps * 32;
             const char* src = buf + half * 32 * E::PITCH;
-            drainT<OSZ, MODE, 256, 512>(src, 32, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
-            if (PAIR) drainT<OSZ, 0, 256, 512>(src + REGION, 32, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, (p.ablate == 1 ? 0 : p.M), p.N, tid, (p.ablate == 2 ? 255 : -1), p.store_policy);
+            drainT<OSZ, MODE, 256, 512>(src, 32, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
+            if (PAIR) drainT<OSZ, 0, 256, 512>(src + REGION, 32, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
         }
     };
     stage(0, smem);
@@ -964,8 +945,6 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux;
     p.M = M; p.N = N; p.K = K; p.out_dtype = out_dtype; p.epi = epi;
     p.tiles_m = (M + 255) / 256;
-    p.ablate = option(MAEST_OPT_GEMM_ABLATE);
-    p.store_policy = option(MAEST_OPT_GEMM_STORE);
     // Measured (scratch/gemm_ab.py): the one-workgroup-per-CU 256x256 kernel wins on every ViT shape but the
     // value-only GELU epilogue; the 256x128 two-per-CU kernel serves N % 256 != 0 and MAEST_GEMM_VARIANT=2.
     // default: the full-cache-line kernel (fastest on every ViT shape, scratch/gemm_ab.py); MAEST_GEMM_VARIANT
