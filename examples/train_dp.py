@@ -1,12 +1,14 @@
 #!/usr/bin/env python
 """Data-parallel MAEST training loop on MI355X: on-disk float16 mel chunks -> device input (MelFileReader), fused
-mixup + patchout + ViT step (Module.training_step), bucketed RCCL gradient all-reduce (GradReducer), AdamW, SWA.
+SpecMasking + mixup + patchout + ViT step (Module.training_step), bucketed RCCL gradient all-reduce (GradReducer),
+AdamW, SWA.
 
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_dp.py --data DIR
     python examples/train_dp.py            # single GPU, synthetic mel files written to a temp dir
 
-What replaces what: discogs/dataset.py + datamodule.py loader workers -> MelFileReader; Lightning DDP ->
-GradReducer; helpers/swa_callback.py -> WeightAverager; models/module.py:Module -> maest_amd.module.Module.
+What replaces what: discogs/dataset.py + datamodule.py loader workers -> MelFileReader; helpers/spec_masking.py (applied
+per clip by those workers) -> SpecMasking stripes drawn per step and applied inside the patch-embedding operand load;
+Lightning DDP -> GradReducer; helpers/swa_callback.py -> WeightAverager; models/module.py:Module -> maest_amd.module.Module.
 """
 import argparse
 import os
@@ -20,6 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maest_amd.dist import GradReducer, broadcast_parameters, init_from_env  # noqa: E402
 from maest_amd.melfile import MelFileReader  # noqa: E402
 from maest_amd.module import Module  # noqa: E402
+from maest_amd.spec_masking import SpecMasking  # noqa: E402
 from maest_amd.swa import WeightAverager  # noqa: E402
 
 
@@ -39,6 +42,8 @@ def main():
     ap.add_argument("--data", default=None)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="per GPU")
+    ap.add_argument("--no-spec-masking", action="store_true")
+    ap.add_argument("--hip-graph", action="store_true", help="replay the training forward from a captured HIP graph")
     args = ap.parse_args()
     rank, local, world = init_from_env()
     torch.cuda.set_device(local)
@@ -53,8 +58,11 @@ def main():
     if y_all is None:
         y_all = np.zeros((len(names), 400), np.float32)       # plug the ground-truth pickle of the reference here
 
-    mod = Module(arch="passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30).to(dev)
+    mod = Module(arch="passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30,
+                 spec_masking=None if args.no_spec_masking else SpecMasking()).to(dev)
     mod.net.train()
+    if args.hip_graph:
+        mod.net.enable_hip_graph()
     broadcast_parameters(mod.net)
     opt = mod.configure_optimizers()
     reducer = None

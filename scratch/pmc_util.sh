@@ -18,20 +18,20 @@ O = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in glob.glob(O + "/pmc_util_*/**/p_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
-        k = k.replace("void maest::", "")[:70]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("maest::", "")[:70]
         a = agg[k][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
-out = {}
+out = {"_units": "per-launch averages over `launches` launches of scratch/kern_mix.py (B = 256, N = 290, bf16, random data). "
+                 "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the fraction of SIMD cycles, at "
+                 "the clock the kernel actually ran at, in which the matrix pipe was busy (SQ_VALU_MFMA_BUSY_CYCLES = 32 x "
+                 "SQ_INSTS_MFMA for 32x32x16 bf16; GRBM_GUI_ACTIVE is summed over the 8 XCDs).  *_frac_of_wave_cycles: SQ "
+                 "wave-state counters over SQ_WAVE_CYCLES (quad-cycles).  lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."}
 for k, cs in agg.items():
     if not any(s in k for s in ("gemm", "attn", "layernorm")): continue
     d = {c: v / n for c, (n, v) in cs.items()}
     d["launches"] = max(n for n, v in cs.values())
-    if d.get("SQ_BUSY_CYCLES"):
-        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles over all SIMDs; SQ_BUSY_CYCLES is per SE/XCC aggregate: report both the
-        # raw ratio and the per-wave one (MFMA busy cycles / (4 * wave quad-cycles)) -- see MI355X_MICROARCH.md units
-        d["mfma_busy_over_sq_busy"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / d["SQ_BUSY_CYCLES"]
+    if d.get("GRBM_GUI_ACTIVE"):
+        d["mfma_util"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * d["GRBM_GUI_ACTIVE"] / 8.0)
     if d.get("SQ_WAVE_CYCLES"):
-        d["mfma_busy_per_wave_cycle"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4.0 * d["SQ_WAVE_CYCLES"])
         for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS"):
             if c in d: d[c + "_frac_of_wave_cycles"] = d[c] / d["SQ_WAVE_CYCLES"]
     if d.get("SQ_LDS_IDX_ACTIVE"):
@@ -39,5 +39,5 @@ for k, cs in agg.items():
     out[k] = d
 json.dump(out, open(O + "/mfma_util.json", "w"), indent=1)
 for k, d in out.items():
-    print(k[:60], {c: (round(v, 4) if isinstance(v, float) and v < 10 else int(v)) for c, v in d.items() if "frac" in c or "mfma_busy" in c or c == "launches"})
+    if k[0] != "_": print(k[:60], {c: round(v, 4) for c, v in d.items() if "frac" in c or c == "mfma_util"}, d["launches"])
 PY
