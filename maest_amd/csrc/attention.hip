@@ -37,6 +37,8 @@ constexpr int OUT_LD = NHEADS * HD;      // 768
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;
+// drain this wave's vector-memory queue (LDS-DMA included) without touching the LDS / scalar counters
+#define MAEST_ATTN_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 template <typename T>
 struct AttnCfg {
@@ -808,6 +810,286 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
     }
 }
 
+// =================================================================================== fused backward, DMA-fed (bf16, N <= 320)
+// The same decomposition as attn_bwd_fused_kernel, with the aux waves relieved of the tile staging (their loop was the
+// critical path: 260 us of staging + dQ against 240 us of key-wave work): K (resident) and the Q / dO query tiles are
+// UNPADDED 128-byte-row tiles filled by LDS-DMA (no register round trip, no ds_write pass; two tiles ahead, three
+// buffers), with the bank swizzle  chunk ^= row[1] row[2] row[3]  applied on the DMA source address so that the
+// row-per-lane 16-byte reads AND the transpose reads are conflict-free (scratch/lds_banks.py; the padded pitch costs
+// the transpose reads 2x).  delta = rowsum(dO * O) comes from attn_delta_kernel again (the DMA cannot compute it).
+// DMA'd rows beyond N repeat row N - 1: padded queries carry lse = +BIG (P = 0 exactly), padded keys write dS = 0.
+constexpr int F2_QBUF = 2 * 32 * 128 + 256;       // Q tile | dO tile | lse[32] | delta[32]
+__device__ __forceinline__ int swz128(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+// One LDS-DMA instruction (global_load_lds_dwordx4: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS address `dst`),
+// issued as inline asm so that hipcc does not know about it: through the builtin the compiler treats the DMA as a
+// store to LDS that may alias every later LDS read and puts `s_waitcnt vmcnt(0)` in front of the next ds_read (here:
+// inside the dQ loop), i.e. it waits for the tile it has just requested.  The waits are placed by hand
+// (MAEST_ATTN_WAIT_VM0 one step later); a hidden DMA can only make the compiler's own counted waits longer, never
+// shorter.  M0 (the DMA's LDS base) is saved and restored inside the statement.  (The host emulator build takes
+// the builtin, which it executes synchronously.)
+__device__ __forceinline__ void dma16(const void* gsrc, char* dst) {
+#if defined(__AMDGCN__)
+    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#endif
+}
+// LDS-DMA of 8-row groups [j0, j1) of an unpadded 128-byte-row tile (instruction j = rows 8j .. 8j + 7 = 1 KiB)
+__device__ __forceinline__ void dma_rows128(char* tile, const bf16_t* base, int ld, int row0, int j0, int j1, int jstep,
+                                            int nvalid, int lane) {
+    for (int j = j0; j < j1; j += jstep) {
+        const int lrow = 8 * j + (lane >> 3);                  // row inside the tile (the swizzle is a function of it)
+        int grow = row0 + lrow;
+        grow = grow < nvalid ? grow : nvalid - 1;
+        const bf16_t* src = base + (uint32_t)(grow * ld + (((lane & 7) ^ swz128(lrow)) << 3));
+        dma16(src, tile + j * 1024);
+    }
+}
+__device__ __forceinline__ void mma_rows_swz(f32x16_t& acc, const char* tile, int row0, int lane, const chunk16 (&frag)[4]) {
+    const int row = row0 + (lane & 31), f = swz128(row), h = lane >> 5;
+    const char* rp = tile + row * 128;
+#pragma unroll
+    for (int s = 0; s < 4; s += 2) {
+        const chunk16 a0 = *reinterpret_cast<const chunk16*>(rp + (((2 * s + h) ^ f) << 4));
+        const chunk16 a1 = *reinterpret_cast<const chunk16*>(rp + (((2 * s + 2 + h) ^ f) << 4));
+        mma_chunk2<bf16_t, false>(acc, a0, a1, frag[s], frag[s + 1]);
+    }
+}
+__device__ __forceinline__ chunk16 frag_from_rows_swz(const char* tile, int rho0, int s, int dblk, int lane) {
+    const int h = lane >> 5, g16 = (lane >> 4) & 1, q = lane & 15;
+    const int row = rho0 + 16 * s + 4 * h + (q >> 2);
+    const int cb = (dblk * 32 + 16 * g16 + 4 * (q & 3)) * 2;          // byte column
+    const char* p0 = tile + row * 128 + ((((cb >> 4) ^ swz128(row)) << 4) | (cb & 15));
+    const char* p1 = tile + (row + 8) * 128 + ((((cb >> 4) ^ swz128(row + 8)) << 4) | (cb & 15));
+    const v4i16a_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16a_t*)(p0));
+    const v4i16a_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16a_t*)(p1));
+    const chunk8 l2 = __builtin_bit_cast(chunk8, lo), h2 = __builtin_bit_cast(chunk8, hi);
+    chunk16 c;
+    c[0] = l2[0]; c[1] = l2[1]; c[2] = h2[0]; c[3] = h2[1];
+    return c;
+}
+__device__ __forceinline__ void mma_transposed_swz(f32x16_t (&acc)[2], const char* tile, int rho0, int lane, const f32x16_t& p) {
+    const chunk16 b0 = acc_to_chunk<bf16_t>(p, 0), b1 = acc_to_chunk<bf16_t>(p, 1);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const chunk16 a0 = frag_from_rows_swz(tile, rho0, 0, db, lane);
+        const chunk16 a1 = frag_from_rows_swz(tile, rho0, 1, db, lane);
+        mma_chunk2<bf16_t, false>(acc[db], a0, a1, b0, b1);
+    }
+}
+
+__global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf16_t* __restrict__ qkv,
+                                                                        const bf16_t* __restrict__ dout,
+                                                                        const float* __restrict__ lse,
+                                                                        const float* __restrict__ delta,
+                                                                        bf16_t* __restrict__ dqkv, int B, int N,
+                                                                        float scale) {
+    using T = bf16_t;
+    using C = AttnCfg<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nkw = (N + 31) >> 5;                 // key waves = key blocks = query tiles
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    // LDS map: K [nkw*32][128 B] | 2 x dS [nkw*32][32 q] | 3 x { Q tile, dO tile, lse[32], delta[32] }
+    const int DSBUF = nkw * 32 * FB_DS_PITCH;
+    char* k_lds = smem;
+    char* ds0 = smem + nkw * 32 * 128;
+    char* qbuf0 = ds0 + 2 * DSBUF;
+
+    const int bh = xcd_remap(blockIdx.x, B * NHEADS);
+    const int head = bh % NHEADS, b = bh / NHEADS;
+    const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
+    const T* kbase = qbase + NHEADS * HD;
+    const T* vbase = qbase + 2 * NHEADS * HD;
+    const T* dobase = dout + (int64_t)b * N * OUT_LD + head * HD;
+    const float* lse_b = lse + ((int64_t)b * NHEADS + head) * N;
+    const float* dl_b = delta + ((int64_t)b * NHEADS + head) * N;
+    T* dq_out = dqkv + (int64_t)b * N * QKV_LD + head * HD;
+
+    const bool key_wave = wave < nkw;
+    const int aux = wave - nkw;                    // 0: Q feeder + dQ[:, 0:32], 1: dO feeder + dQ[:, 32:64]; >= 2: filler
+
+    // ---- prologue, all waves: K of every key block -> LDS by DMA
+    dma_rows128(k_lds, kbase, QKV_LD, 0, wave, nkw * 4, nwaves, N, lane);
+
+    if (key_wave) {
+        // =============================================================================== key waves
+        const int key = wave * 32 + (lane & 31);
+        const bool key_ok = key < N;
+        const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
+        chunk16 kf[C::STEPS], vf[C::STEPS];
+        row_frags_load<T>(kf, kbase, QKV_LD, key, N, h);
+        row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
+        f32x16_t dk[2], dv[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[db][r] = 0.0f; dv[db][r] = 0.0f; }
+        MAEST_ATTN_WAIT_VM0();                             // this wave's share of the K DMA (and its fragments) landed
+        __builtin_amdgcn_s_barrier();                      // K in LDS, query tile 0 staged
+        int buf = 0;
+        for (int t = 0; t < nkw; ++t) {
+            const char* q_lds = qbuf0 + buf * F2_QBUF;
+            const char* do_lds = q_lds + 32 * 128;
+            const float* lse_lds = reinterpret_cast<const float*>(q_lds + 2 * 32 * 128);
+            const float* dl_lds = lse_lds + 32;
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+            mma_rows_swz(s, q_lds, 0, lane, kf);         // S[q][key]
+            mma_rows_swz(dp, do_lds, 0, lane, vf);       // dP[q][key]
+            char* ds_row = ds0 + (t & 1) * DSBUF + key * FB_DS_PITCH;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ql = 8 * g + 4 * h;            // local q of register 4g (4 consecutive rows)
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_lds + ql);
+                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dl_lds + ql);
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const int r = 4 * g + e;
+                    const f32x2_t sv = {s[r], s[r + 1]}, nl = {-l4[e], -l4[e + 1]};
+                    const f32x2_t dpv = {dp[r], dp[r + 1]}, dl = {d4[e], d4[e + 1]};
+                    const f32x2_t ev = __builtin_elementwise_fma(sv, c2v, nl);
+                    const f32x2_t pv = {fast_exp2<T>(ev[0]), fast_exp2<T>(ev[1])};
+                    const f32x2_t dsv = pv * (dpv - dl);
+                    s[r] = pv[0]; s[r + 1] = pv[1];       // P
+                    dp[r] = dsv[0]; dp[r + 1] = dsv[1];   // dS (unscaled)
+                }
+                chunk8 w;                                 // a padded key contributes nothing to dQ (its K row is not zero here)
+                w[0] = key_ok ? pack_bf2(dp[4 * g], dp[4 * g + 1]) : 0u;
+                w[1] = key_ok ? pack_bf2(dp[4 * g + 2], dp[4 * g + 3]) : 0u;
+                *reinterpret_cast<chunk8*>(ds_row + ql * 2) = w;
+            }
+            mma_transposed_swz(dv, do_lds, 0, lane, s);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+            mma_transposed_swz(dk, q_lds, 0, lane, dp);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            buf = buf == 2 ? 0 : buf + 1;
+            __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): the dS tile is written
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();                      // the aux waves are done with K and the last dS tile
+        // dK / dV: registers -> this wave's private LDS patch (row = key, 128 B of d) -> whole rows, 16 B per lane
+        char* patch = smem + wave * (2 * 32 * C::PITCH);
+#pragma unroll
+        for (int tsel = 0; tsel < 2; ++tsel)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16_t& a = tsel == 0 ? dk[db] : dv[db];
+                    const float m = tsel == 0 ? scale : 1.0f;
+                    chunk8 w;
+                    w[0] = pack_bf2(a[4 * g] * m, a[4 * g + 1] * m);
+                    w[1] = pack_bf2(a[4 * g + 2] * m, a[4 * g + 3] * m);
+                    *reinterpret_cast<chunk8*>(patch + tsel * 32 * C::PITCH + (lane & 31) * C::PITCH +
+                                               (db * 32 + 8 * g + 4 * h) * 2) = w;
+                }
+        __syncthreads();
+#pragma unroll
+        for (int tsel = 0; tsel < 2; ++tsel)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = lane + 64 * j, r = i >> 3, c = i & 7;
+                const int krow = wave * 32 + r;
+                if (krow < N) {
+                    const chunk16 v = *reinterpret_cast<const chunk16*>(patch + tsel * 32 * C::PITCH + r * C::PITCH + c * 16);
+                    *reinterpret_cast<chunk16*>(dq_out + (uint32_t)(krow * QKV_LD + (1 + tsel) * NHEADS * HD + c * 8)) = v;
+                }
+            }
+    } else {
+        // =============================================================================== aux (and filler) waves
+        const T* fbase = aux == 0 ? qbase : dobase;        // wave-uniform
+        const int fld = aux == 0 ? QKV_LD : OUT_LD;
+        const float* sbase = aux == 0 ? lse_b : dl_b;      // per-row statistic this wave carries: lse (scaled) / delta
+        auto tile_dma = [&](int t) {                       // this wave's 32 x 128 B tile of query tile t -> ring buffer t % 3
+            if (t >= nkw || aux > 1) return;
+            char* dst = qbuf0 + (t % 3) * F2_QBUF + (aux == 0 ? 0 : 32 * 128);
+            dma_rows128(dst, fbase, fld, t * 32, 0, 4, 1, N, lane);
+        };
+        auto stat_load = [&](int t) -> float {             // (unconditional, clamped: see attn_bwd_fused_kernel)
+            int row = t * 32 + (lane & 31);
+            row = row < N ? row : N - 1;
+            return (t < nkw && aux <= 1) ? sbase[row] : 0.0f;
+        };
+        auto stat_store = [&](float v, int t) {
+            if (t >= nkw || aux > 1 || lane >= 32) return;
+            const bool live = t * 32 + lane < N;
+            float* dstp = reinterpret_cast<float*>(qbuf0 + (t % 3) * F2_QBUF + 2 * 32 * 128) + (aux == 0 ? 0 : 32) + lane;
+            if (aux == 0) *dstp = live ? v * LOG2E : -NEG_BIG;   // padded rows: lse = +BIG -> P = 2^(-BIG) = 0
+            else *dstp = live ? v : 0.0f;
+        };
+        auto dq_compute = [&](f32x16_t& acc, int t) {      // dQ^T[32 d of this wave][32 q of tile t]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            if (aux > 1) return;
+            const char* ds = ds0 + (t & 1) * DSBUF;
+            for (int kb = 0; kb < nkw; kb += 2) {
+                const int kb1 = kb + 1 < nkw ? kb + 1 : kb;     // odd count: the last trip re-reads a block, weight 0
+                chunk16 a[4], bq[4];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    a[s] = frag_from_rows_swz(k_lds, kb * 32, s, aux, lane);                      // K^T[d][key]
+                    bq[s] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb * 32, s, 0, lane);            // dS^T[key][q]
+                    a[2 + s] = frag_from_rows_swz(k_lds, kb1 * 32, s, aux, lane);
+                    bq[2 + s] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb1 * 32, s, 0, lane);
+                }
+                if (kb + 1 >= nkw) { bq[2] = chunk16{0u, 0u, 0u, 0u}; bq[3] = chunk16{0u, 0u, 0u, 0u}; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma_chunk<T>(acc, a[j], bq[j]);
+            }
+        };
+        auto dq_store = [&](const f32x16_t& acc, int t) {
+            if (t < 0 || aux > 1) return;
+            const int q = t * 32 + (lane & 31);
+            if (q < N) {
+                T* row = dq_out + (uint32_t)(q * QKV_LD + aux * 32);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    store4<T>(row + 8 * g + 4 * h, acc[4 * g] * scale, acc[4 * g + 1] * scale, acc[4 * g + 2] * scale,
+                              acc[4 * g + 3] * scale);
+            }
+        };
+        // prologue: tiles 0 and 1 by DMA; statistics of tile 0 stored, of tile 1 in flight
+        tile_dma(0);
+        tile_dma(1);
+        stat_store(stat_load(0), 0);
+        float st_next = stat_load(1);
+        f32x16_t dq_prev;                                  // dQ of the previous job, stored one step late (see below)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq_prev[r] = 0.0f;
+        MAEST_ATTN_WAIT_VM0();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();                      // K in LDS, query tile 0 staged (tile 1 landed too)
+        for (int t = 0; t < nkw; ++t) {
+            // Everything issued one step ago has landed by now: the DMA of tile t + 1, and the dQ stores of job
+            // t - 2, which were issued BEFORE the dQ product of that step -- a store issued right in front of this
+            // wait would put its latency on the critical path (vmcnt counts stores too on gfx950).
+            MAEST_ATTN_WAIT_VM0();
+            stat_store(st_next, t + 1);
+            tile_dma(t + 2);                               // lands during this step and the next one
+            st_next = stat_load(t + 2);
+            dq_store(dq_prev, t - 2);
+            if (t > 0) dq_compute(dq_prev, t - 1);
+            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): statistics of tile t + 1 are in LDS
+            __builtin_amdgcn_s_barrier();
+        }
+        dq_store(dq_prev, nkw - 2);
+        dq_compute(dq_prev, nkw - 1);
+        dq_store(dq_prev, nkw - 1);
+        __builtin_amdgcn_s_barrier();                      // LDS may be reused by the key waves' epilogue
+        __syncthreads();
+    }
+}
+
+static int attn_bwd_fused2_smem(int N) {
+    const int nkw = (N + 31) / 32;
+    return nkw * 32 * 128 + 2 * nkw * 32 * FB_DS_PITCH + 3 * F2_QBUF;
+}
+
 static int attn_bwd_fused_smem(int N) {
     const int nkw = (N + 31) / 32;
     return nkw * 32 * AttnCfg<bf16_t>::PITCH + 2 * (2 * 32 * AttnCfg<bf16_t>::PITCH + 256) + 2 * nkw * 32 * FB_DS_PITCH;
@@ -831,7 +1113,19 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
     if constexpr (sizeof(T) == 2) {
         // bf16 and at most 10 key blocks (the 10 s training shapes, N = 281 / 290): one fused pass per (batch, head)
         const int nkw = (N + 31) / 32;
-        if (nkw + 2 <= FB_MAXW && option(MAEST_OPT_ATTN_BWD) != 1) {
+        if (nkw + 2 <= FB_MAXW && option(MAEST_OPT_ATTN_BWD) == 0) {     // DMA-fed form (+ the delta kernel)
+            const int64_t items = (int64_t)B * N * NHEADS * 4;
+            hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
+                               (const T*)out, (const T*)dout, delta, B, N);
+            static DeviceOnce once_g;
+            ensure_dynamic_lds(once_g, &attn_bwd_fused2_kernel, attn_bwd_fused2_smem(32 * (FB_MAXW - 2)));
+            const int waves = nkw + 2 < 8 ? 8 : nkw + 2;
+            hipLaunchKernelGGL(attn_bwd_fused2_kernel, dim3(B * NHEADS), dim3(waves * 64), attn_bwd_fused2_smem(N), st,
+                               (const bf16_t*)qkv, (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, B, N,
+                               scale);
+            return check_launch("maest_attn_bwd(fused, dma)");
+        }
+        if (nkw + 2 <= FB_MAXW && option(MAEST_OPT_ATTN_BWD) == 2) {     // register-fed form (delta fused)
             const int smem_f = attn_bwd_fused_smem(N);
             const int waves = nkw + 2 < 8 ? 8 : nkw + 2;      // the staging step wants 512 threads (one chunk each)
             static DeviceOnce once_f;

@@ -197,6 +197,9 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2):
         close(dq2[:, 768:1536], g[:, 768:1536], rt, at, "attention dK (two-kernel)")
         close(dq2[:, :768], g[:, :768], rt, at, "attention dQ (two-kernel)")
         close(dqkv, dq2.float(), 2e-2, 2e-2, "fused vs two-kernel attention backward")
+        with ops.options(attn_bwd=2):     # the fused form with register-fed tiles (delta computed in flight)
+            dq3 = ops.attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
+        close(dq3, g, rt, at, "attention backward (fused, register-fed)")
 
 
 # ----------------------------------------------------------------------------- patch embed pieces
