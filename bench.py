@@ -39,7 +39,7 @@ def flops_per_clip_fwd(N, Tk, C=400):
     return 12 * per_block + 2 * (9 * Tk) * 256 * 768 + 2 * 768 * C
 
 
-PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r02b_pmc_traffic.json"
 
 
 def pmc_traffic():
