@@ -589,6 +589,13 @@ __device__ __forceinline__ void epilogueW(char* smem, const f32x16_t (&acc)[2][4
 //     (applied on the DMA source address); a 16-lane ds_read_b128 group then covers all 16 slots of 256 B.
 // ================================================================================================
 
+// MAEST_ABLATE_* : timing experiments only (scratch/probe/ablate_w.sh builds the kernel with parts of the main loop
+// removed; results are wrong on purpose).  Never defined in the product build.
+#ifdef MAEST_ABLATE_NO_BARRIER
+#define MAEST_LOOP_BARRIER() ((void)0)
+#else
+#define MAEST_LOOP_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 template <typename T, int EPIV, bool X3 = false>
 __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -659,7 +666,16 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     }
 
     chunk16 fa[2][4], fb[2][2];
+#ifdef MAEST_ABLATE_NO_DSREAD
+    for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 4; ++j) fa[i][j] = chunk16{0x3f803f80u + (uint32_t)lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        for (int j = 0; j < 2; ++j) fb[i][j] = chunk16{0x3f803f80u, 0x3f803f80u + (uint32_t)lane, 0x3f803f80u, 0x3f803f80u};
+    }
+#endif
     auto load_frags = [&](int abuf, int bbuf, int kh) {
+#ifdef MAEST_ABLATE_NO_DSREAD
+        return;
+#endif
         const char* la = smem + abuf * W2_UNIT;
         const char* lb = smem + bbuf * W2_UNIT;
 #pragma unroll
@@ -701,7 +717,11 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
+                for (int mt = 0; mt < 4; ++mt) {
+#ifndef MAEST_ABLATE_NO_MFMA
+                    mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
+#endif
+                }
 #ifndef MAEST_ABLATE_NO_DMA
                 if (dma) {
                     const int i = ks * 2 + nt;
@@ -739,28 +759,28 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
         const int abuf_prev = next(abuf, W2_NBUF - 2), bbuf_prev = next(bbuf, W2_NBUF - 2);
         load_frags(abuf, bbuf, 0);
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
-        __builtin_amdgcn_s_barrier();
+        MAEST_LOOP_BARRIER();
         if (wm == 0) compute(j > 0, j + 1, true, abuf_prev);
         else compute(j > 0, j + 2, false, bbuf_prev);
-        __builtin_amdgcn_s_barrier();
+        MAEST_LOOP_BARRIER();
         load_frags(abuf, bbuf, 1);
         if (wm == 0) {
             __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_s_barrier();           // b3
+            MAEST_LOOP_BARRIER();           // b3
             compute(j > 0, j + 2, false, bbuf_prev);
 #ifndef MAEST_ABLATE_NO_VMWAIT
             MAEST_WAIT_VMCNT(4);
 #endif
-            __builtin_amdgcn_s_barrier();           // b4
+            MAEST_LOOP_BARRIER();           // b4
         } else {
 #ifndef MAEST_ABLATE_NO_VMWAIT
             __builtin_amdgcn_s_waitcnt(0x0074);     // vmcnt(4) lgkmcnt(0)
 #else
             __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-            __builtin_amdgcn_s_barrier();           // b4
+            MAEST_LOOP_BARRIER();           // b4
             compute(true, j + 2, true, abuf);
-            __builtin_amdgcn_s_barrier();
+            MAEST_LOOP_BARRIER();
         }
         abuf = next(abuf, 2);
         bbuf = next(bbuf, 2);
