@@ -4,9 +4,11 @@
 //  Spectrogram(n_fft=512, hop=256, power=2, center=True/reflect) :29-34 and MelScale(96, slaney) :36-42;
 //  constants :16-24.)
 //
-// HBM-bound (0.88 MB / 10 s clip in+out vs ~7 MFLOP of FFT): a workgroup owns 64 consecutive frames
+// Algorithmically HBM-bound (0.88 MB / 10 s clip in+out vs ~7 MFLOP of FFT); as written it is instruction-issue bound
+// (~800 VALU / LDS instructions per frame and wave: 0.25 ms for 256 clips = 0.11 of the HBM roofline, 1.0 M clips/s --
+// 250x the rate the ViT consumes them at).  A workgroup owns 64 consecutive frames
 // of one clip so that the [96, T] output is written as 256-byte runs along T; each of its 4 waves
-// transforms 16 frames, one at a time, entirely in LDS: the 512 real samples are packed as 256
+// transforms 16 frames, one at a time (the next frame's samples in flight), entirely in LDS and without block barriers: the 512 real samples are packed as 256
 // complex points, transformed by 4 radix-4 DIF stages (one butterfly per lane per stage), unpacked
 // to the 257-bin one-sided spectrum, and projected onto the mel bands with the filterbank stored in
 // band-sparse form (each triangular band touches <= fb_stride consecutive bins).  All arithmetic is fp32.
@@ -20,6 +22,7 @@ constexpr int MEL_NBINS = 257;
 constexpr int MEL_BANDS = 96;
 constexpr int MEL_FRAMES_PER_BLOCK = 64;
 constexpr int MEL_OUT_LD = MEL_FRAMES_PER_BLOCK + 1;
+constexpr int MEL_WREG0 = 8, MEL_WREG1 = 16;   // filter weights kept in registers for bands 0..63 / 64..95
 
 struct cplx {
     float re, im;
@@ -30,6 +33,42 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.i
 __device__ __forceinline__ cplx mul_neg_i(cplx a) { return {a.im, -a.re}; }   // a * (-i)
 __device__ __forceinline__ int rev4_256(int k) {  // reverse the four base-4 digits of k
     return ((k & 3) << 6) | (((k >> 2) & 3) << 4) | (((k >> 4) & 3) << 2) | ((k >> 6) & 3);
+}
+
+// LDS hand-off between the lanes of ONE wave: a wave's DS instructions execute in order and all 64 lanes issue them
+// together, so a write by one lane is visible to a later read by another lane of the same wave without a barrier;
+// only the compiler has to keep the order (the host emulator, one thread per lane, maps this to a wave barrier).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// sample fetch of frame t: the 8 samples lane `lane` packs as complex points lane + 64 j.  INTERIOR (block-uniform: all 64
+// frames of the block lie inside the clip and the clip starts 8-byte aligned): four plain 8-byte loads; otherwise
+// clamped (frames >= T are computed on the last frame's data and not stored) and reflect-padded, sample by sample
+template <bool INTERIOR>
+__device__ __forceinline__ void mel_fetch(float (&x)[4][2], const float* __restrict__ wsrc, int t, int T, int S, int lane) {
+    if (INTERIOR) {
+        const float* p0 = wsrc + t * MEL_HOP - MEL_NFFT / 2 + 2 * lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 v = *reinterpret_cast<const float2*>(p0 + 128 * j);
+            x[j][0] = v.x; x[j][1] = v.y;
+        }
+        return;
+    }
+    const int tc = t < T ? t : T - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = 2 * (lane + 64 * j);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int i = tc * MEL_HOP + p + e - MEL_NFFT / 2;
+            if (i < 0) i = -i;
+            if (i >= S) i = 2 * (S - 1) - i;
+            x[j][e] = wsrc[i];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wave_in, int S, int T,
@@ -46,32 +85,50 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
     cplx* z = reinterpret_cast<cplx*>(otile + MEL_BANDS * MEL_OUT_LD) + wv * 256;   // per wave [256]
     float* pw = reinterpret_cast<float*>(reinterpret_cast<cplx*>(otile + MEL_BANDS * MEL_OUT_LD) + 4 * 256) + wv * 260;
 
-    for (int i = threadIdx.x; i < 1024; i += 256) tw[i] = twiddle[i];
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * MEL_FRAMES_PER_BLOCK;
     const float* wsrc = wave_in + (int64_t)b * S;
+    // the wave works alone on its 16 frames (its own z / pw regions): no block barrier inside the frame loop; the
+    // samples of frame fi + 1 are in flight while frame fi is transformed
+    float x[4][2], win[4][2];
+    const bool interior = t0 > 0 && (t0 + MEL_FRAMES_PER_BLOCK) * MEL_HOP + MEL_NFFT / 2 <= S && t0 + MEL_FRAMES_PER_BLOCK <= T &&
+                          (reinterpret_cast<uintptr_t>(wsrc) & 7) == 0;      // block-uniform
+    if (interior) mel_fetch<true>(x, wsrc, t0 + wv * 16, T, S, lane);
+    else mel_fetch<false>(x, wsrc, t0 + wv * 16, T, S, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float2 w2 = *reinterpret_cast<const float2*>(window + 2 * (lane + 64 * j));
+        win[j][0] = w2.x; win[j][1] = w2.y;
+    }
+    // this lane's two bands (lane, lane + 64): the first MEL_WREG0 / MEL_WREG1 filter weights live in registers (the
+    // slaney bank's bands are 1..6 and 5..15 bins long), zero beyond the band; longer bands finish in a global-read loop
+    int mb_start[2], mb_len[2];
+    float mw0[MEL_WREG0], mw1[MEL_WREG1];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = lane + 64 * j;
+        mb_start[j] = m < MEL_BANDS ? fb_start[m] : 0;
+        mb_len[j] = m < MEL_BANDS ? fb_len[m] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < MEL_WREG0; ++i) mw0[i] = i < mb_len[0] ? fb_w[lane * fb_stride + i] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < MEL_WREG1; ++i) mw1[i] = i < mb_len[1] ? fb_w[(lane + 64) * fb_stride + i] : 0.0f;
+    if (lane < 3) pw[MEL_NBINS + lane] = 0.0f;      // the padding the clamped reads below may touch
+    for (int i = threadIdx.x; i < 1024; i += 256) tw[i] = twiddle[i];
     __syncthreads();
 
     for (int fi = 0; fi < 16; ++fi) {
         const int tl = wv * 16 + fi;       // frame within the block
-        const int t = t0 + tl;             // frames >= T are computed on clamped data and not stored
         // ---- framing (center=True, reflect padding of 256 samples) + window + complex packing
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = lane + 64 * j;   // complex point index
-            float v[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int p = 2 * n + e;   // sample index within the frame
-                int i = (t < T ? t : T - 1) * MEL_HOP + p - MEL_NFFT / 2;
-                if (i < 0) i = -i;
-                if (i >= S) i = 2 * (S - 1) - i;
-                v[e] = wsrc[i] * window[p];
-            }
-            z[n] = {v[0], v[1]};
+        for (int j = 0; j < 4; ++j) z[lane + 64 * j] = {x[j][0] * win[j][0], x[j][1] * win[j][1]};
+        if (fi + 1 < 16) {
+            if (interior) mel_fetch<true>(x, wsrc, t0 + tl + 1, T, S, lane);
+            else mel_fetch<false>(x, wsrc, t0 + tl + 1, T, S, lane);
         }
-        __syncthreads();
-        // ---- 256-point complex FFT, radix-4 DIF, 4 stages, one butterfly per lane per stage
+        wave_lds_sync();
+        // ---- 256-point complex FFT, radix-4 DIF, 4 stages, one in-place butterfly per lane per stage
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             const int L = 256 >> (2 * st);
@@ -88,9 +145,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
             y1 = cmul(y1, w1);
             y2 = cmul(y2, w2);
             y3 = cmul(y3, w3);
-            __syncthreads();
-            z[base] = y0; z[base + q] = y1; z[base + 2 * q] = y2; z[base + 3 * q] = y3;
-            __syncthreads();
+            z[base] = y0; z[base + q] = y1; z[base + 2 * q] = y2; z[base + 3 * q] = y3;   // the points this lane read
+            wave_lds_sync();
         }
         // ---- unpack the real FFT: X[k] = E[k] + W^k O[k], power spectrum for k = 0..256
 #pragma unroll
@@ -104,25 +160,34 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
                 const cplx d = {0.5f * (zk.re - zc.re), 0.5f * (zk.im - zc.im)};
                 const cplx o = mul_neg_i(d);                                 // (Z[k] - conj Z[N-k]) / (2i)
                 const cplx w = {tw[2 * k], tw[2 * k + 1]};                    // exp(-2 pi i k / 512)
-                const cplx x = cadd(e, cmul(o, w));
-                pw[k] = x.re * x.re + x.im * x.im;
+                const cplx xk = cadd(e, cmul(o, w));
+                pw[k] = xk.re * xk.re + xk.im * xk.im;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         // ---- mel projection + logC + z-norm into the block's output tile
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = lane + 64 * j;
             if (m < MEL_BANDS) {
-                const int s0 = fb_start[m], n = fb_len[m];
+                const int s0 = mb_start[j], n = mb_len[j];
                 float acc = 0.0f;
-                for (int i = 0; i < n; ++i) acc += pw[s0 + i] * fb_w[m * fb_stride + i];
+                if (j == 0) {
+#pragma unroll
+                    for (int i = 0; i < MEL_WREG0; ++i) acc += pw[s0 + i < MEL_NBINS ? s0 + i : MEL_NBINS] * mw0[i];
+                    for (int i = MEL_WREG0; i < n; ++i) acc += pw[s0 + i] * fb_w[m * fb_stride + i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MEL_WREG1; ++i) acc += pw[s0 + i < MEL_NBINS ? s0 + i : MEL_NBINS] * mw1[i];
+                    for (int i = MEL_WREG1; i < n; ++i) acc += pw[s0 + i] * fb_w[m * fb_stride + i];
+                }
                 const float lm = log10f(1.0f + acc * log_scale);
                 otile[m * MEL_OUT_LD + tl] = (lm - norm_mean) / norm_2std;
             }
         }
-        __syncthreads();
+        wave_lds_sync();       // pw / z are rewritten by the next frame
     }
+    __syncthreads();
     // ---- coalesced store of the [96][64] tile
     for (int i = threadIdx.x; i < MEL_BANDS * MEL_FRAMES_PER_BLOCK; i += 256) {
         const int m = i >> 6, tl = i & 63;

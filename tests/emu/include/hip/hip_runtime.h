@@ -237,6 +237,9 @@ static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 static inline uint64_t __builtin_amdgcn_s_memtime() { static thread_local uint64_t t = 0; return t += 1000; }
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
+// wave-local LDS hand-off (csrc/mel.hip: wave_lds_sync): one host thread per lane, so it needs a real wave barrier
+static inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
