@@ -17,8 +17,9 @@ constexpr int ROWB = 128, UNIT = 256 * ROWB, NBUF = 5, SMEM = NBUF * UNIT;
 
 template <int VARIANT, int ABL = 0>
 __global__ __launch_bounds__(256) void nt4w_kernel(const char* __restrict__ A, const char* __restrict__ B, float* __restrict__ C,
-                                                   int M, int N, int K, int do_store) {
+                                                   int M, int N, int K, int do_store, unsigned long long* clk = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, h = lane >> 5;
     const int tiles_n = N / 256, nwg = (M / 256) * tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
@@ -166,6 +167,10 @@ __global__ __launch_bounds__(256) void nt4w_kernel(const char* __restrict__ A, c
         abuf = abuf_n; bbuf = bbuf_n;
     }
     WAIT_VMCNT(0);
+    if (clk != nullptr && threadIdx.x == 0) {      // shader cycles and 100 MHz wall ticks this workgroup lived
+        clk[2 * blockIdx.x] = clock64() - c0;
+        clk[2 * blockIdx.x + 1] = wall_clock64() - w0;
+    }
     if (do_store) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -202,7 +207,15 @@ static void run(const char* name, const void* A, const void* B, float* C, int M,
     for (int i = 0; i < 10; ++i) nt4w_kernel<VARIANT, ABL><<<grid, 256, SMEM>>>((const char*)A, (const char*)B, C, M, N, K, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
-    printf("%-10s M=%6d N=%5d K=%5d: %8.3f ms  %7.1f TF/s (main loop only, no C write)\n", name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9);
+    static unsigned long long* dclk = nullptr;
+    if (!dclk) hipMalloc(&dclk, (size_t)2 * 8192 * 8);
+    nt4w_kernel<VARIANT, ABL><<<grid, 256, SMEM>>>((const char*)A, (const char*)B, C, M, N, K, 0, dclk);
+    std::vector<unsigned long long> hc(2 * grid);
+    hipMemcpy(hc.data(), dclk, hc.size() * 8, hipMemcpyDeviceToHost);
+    double cyc = 0, wall = 0;
+    for (int i = 0; i < grid; ++i) { cyc += (double)hc[2 * i]; wall += (double)hc[2 * i + 1]; }
+    printf("%-10s M=%6d N=%5d K=%5d: %8.3f ms  %7.1f TF/s (main loop only, no C write)   shader clock %.0f MHz\n", name, M, N, K, ms,
+           2.0 * M * N * K / ms / 1e9, cyc / wall * 100.0);
 }
 
 #define CHECK(V) { const int M = 512, N = 512, K = 512; \
@@ -258,12 +271,12 @@ int main() {
         }
         printf("check 512^3 (asm reads): max |err| = %.3e %s\n", worst, worst < 1e-3 ? "OK" : "WRONG");
     }
-    CHECK(10); CHECK(11);
-    run<2>("4w-asmrd", A, B, C, 65536, 4096, 4096);
-    run<10>("4w-burst16", A, B, C, 65536, 4096, 4096);
-    run<11>("4w-burst8x2", A, B, C, 65536, 4096, 4096);
-    run<2>("4w-asmrd", A, B, C, 65280, 768, 3072);
-    run<10>("4w-burst16", A, B, C, 65280, 768, 3072);
-    run<11>("4w-burst8x2", A, B, C, 65280, 768, 3072);
+    run<2>("4w full", A, B, C, 65536, 4096, 4096);
+    run<2, 1>("  no DMA", A, B, C, 65536, 4096, 4096);
+    run<2, 2>("  no dsrd", A, B, C, 65536, 4096, 4096);
+    run<2, 3>("  mfma only", A, B, C, 65536, 4096, 4096);
+    hipMemset(A, 0, (size_t)65536 * 4096 * 2); hipMemset(B, 0, (size_t)4096 * 4096 * 2);
+    run<2>("4w zeros", A, B, C, 65536, 4096, 4096);
+    run<2, 3>("  mfma only zeros", A, B, C, 65536, 4096, 4096);
     return 0;
 }

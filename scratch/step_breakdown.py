@@ -7,13 +7,15 @@ dev = "cuda"
 net = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30, precision="bf16").to(dev).train()
 mod = Module(net=net)
 opt = mod.configure_optimizers()
+import os
+if os.environ.get("MAEST_SERIAL"): net._engine.overlap_wgrad = False     # each event pair then times one kernel alone
 B = 256
 x = torch.randn(B, 1, 96, 626, device=dev); y = (torch.rand(B, 400, device=dev) < 0.006).float()
 recs = []
 orig = ops._timed_call
-def hook(name, work, *args):
+def hook(name, work, *args, _entry=None):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record(); _lib.call(name, *args); e1.record()
+    e0.record(); _lib.call(_entry or name, *args); e1.record()
     tag = name
     if name == "maest_gemm_nt":
         tag = f"nt M={args[8]} N={args[9]} K={args[10]} epi={args[12]} out={args[7]} aux={'y' if args[14] is not None else 'n'}"
