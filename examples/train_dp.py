@@ -64,7 +64,8 @@ def main():
     if args.hip_graph:
         mod.net.enable_hip_graph()
     broadcast_parameters(mod.net)
-    opt = mod.configure_optimizers()
+    cfg = mod.configure_optimizers()
+    opt, sched = cfg["optimizer"], cfg["lr_scheduler"]        # exp warm-up / linear ramp-down, stepped per "epoch"
     reducer = None
     if world > 1:
         reducer = GradReducer(mod.net.named_parameters(), skip=("head_dist.weight", "head_dist.bias"))
@@ -84,7 +85,8 @@ def main():
             reducer.finish()
         opt.step()
         opt.zero_grad(set_to_none=reducer is None)
-        if (step + 1) % 10 == 0:
+        if (step + 1) % 10 == 0:          # this toy run calls 10 steps an epoch
+            sched.step()
             swa.update()
             if rank == 0:
                 print(f"step {step + 1}: loss {loss.item():.4f}  (SWA over {swa.n_averaged} snapshots)")

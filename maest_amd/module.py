@@ -64,7 +64,9 @@ def bce_with_logits(z, y, perm=None, lam=None, weight=1.0):
 class Module(nn.Module):
     """Mirror of ``models.module.Module`` (reference models/module.py:44-102, optimizer :237-254)."""
 
-    def __init__(self, net=None, mixup_alpha=0.3, lr=2e-5, weight_decay=1e-4, spec_masking=None, **maest_kwargs):
+    def __init__(self, net=None, mixup_alpha=0.3, lr=2e-5, weight_decay=1e-4, spec_masking=None, adamw=True,
+                 warm_up_len=5, ramp_down_start=50, ramp_down_len=50, last_lr_value=0.01, schedule_mode="exp_lin",
+                 **maest_kwargs):
         """``spec_masking``: a ``maest_amd.spec_masking.SpecMasking`` (or None).  The reference applies it per clip in
         the loader workers (discogs/datamodule.py:140-152), i.e. before mixup; here its stripes are drawn on the
         host each step and applied as a predicate of the patch-embedding operand load (no extra pass over the
@@ -74,6 +76,10 @@ class Module(nn.Module):
         self.mixup_alpha = mixup_alpha
         self.lr = lr
         self.weight_decay = weight_decay
+        # the reference's `optimizer` config block (models/module.py:31-41)
+        self.adamw = adamw
+        self.schedule = dict(schedule_mode=schedule_mode, warm_up_len=warm_up_len, ramp_down_start=ramp_down_start,
+                             ramp_down_len=ramp_down_len, last_lr_value=last_lr_value)
         self.net = net if net is not None else get_maest(**maest_kwargs)
         self.last_mixup = None
 
@@ -109,13 +115,31 @@ class Module(nn.Module):
         perm, lam = mix if mix is not None else (None, None)
         return bce_with_logits(y_hat, y, perm, lam)
 
-    def configure_optimizers(self):
-        # same hyper-parameters as the reference (models/module.py:239-243); on the GPU the single-kernel
-        # ("fused") implementation of the same update: 0.6 ms instead of 1.7 ms per step for 85.9 M parameters
-        params = list(self.parameters())
+    def get_optimizer(self, params=None):
+        """models/module.py:237-243.  Same hyper-parameters as the reference; on the GPU the single-kernel ("fused")
+        implementation of the same update: 0.6 ms instead of 1.7 ms per step for 85.9 M parameters."""
+        params = list(self.parameters() if params is None else params)
         fused = bool(params) and all(p.is_cuda for p in params)
-        return torch.optim.AdamW(params, lr=self.lr, betas=(0.9, 0.999), eps=1e-08,
-                                 weight_decay=self.weight_decay, amsgrad=False, fused=fused)
+        if self.adamw:
+            return torch.optim.AdamW(params, lr=self.lr, betas=(0.9, 0.999), eps=1e-08,
+                                     weight_decay=self.weight_decay, amsgrad=False, fused=fused)
+        return torch.optim.Adam(params, lr=self.lr, fused=fused)
+
+    def get_scheduler_lambda(self):
+        """models/module.py:213-226: epoch -> learning-rate factor."""
+        from .schedule import scheduler_lambda
+        return scheduler_lambda(**self.schedule)
+
+    def get_lr_scheduler(self, optimizer):
+        """models/module.py:228-235 (stepped once per epoch, Lightning's default interval)."""
+        if self.schedule["schedule_mode"] in {"exp_lin", "cos_cyc"}:
+            return torch.optim.lr_scheduler.LambdaLR(optimizer, self.get_scheduler_lambda())
+        raise RuntimeError(f"schedule_mode={self.schedule['schedule_mode']} Unknown.")
+
+    def configure_optimizers(self):
+        """models/module.py:245-254: the optimizer and its epoch-wise LambdaLR, in Lightning's dict form."""
+        optimizer = self.get_optimizer()
+        return {"optimizer": optimizer, "lr_scheduler": self.get_lr_scheduler(optimizer)}
 
 
 class TeacherStudentModule(Module):

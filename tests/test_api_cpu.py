@@ -184,3 +184,45 @@ def test_train_rng_draws_match_reference_order(model):
     want_off = torch.randint(1 + 62 - 61, (1,)).item()
     want_keep = torch.randperm(61)[:31].sort().values
     assert toff == want_off and torch.equal(tok[:31, 1].long(), want_keep) and int(tok[:31, 0].max()) == 0
+
+
+def test_lr_schedules_match_the_reference_fixture():
+    """maest_amd/schedule.py against tests/golden/g10_lr_schedule.npz, written by oracle/gen_golden_schedule.py from the
+    imported reference (helpers/ramp.py through Module.get_scheduler_lambda's argument order, models/module.py:213-226)."""
+    import os
+    import numpy as np
+    from maest_amd.schedule import scheduler_lambda
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g10_lr_schedule.npz"))
+    for tag in ("default", "b", "c"):
+        w, s, l, last = g[f"exp_lin_{tag}_args"]
+        kw = dict(warm_up_len=int(w), ramp_down_start=int(s), ramp_down_len=int(l), last_lr_value=float(last))
+        for mode in ("exp_lin", "cos_cyc"):
+            f = scheduler_lambda(schedule_mode=mode, **kw)
+            got = np.array([f(int(e)) for e in g["epochs"]])
+            np.testing.assert_allclose(got, g[f"{mode}_{tag}"], rtol=1e-14, atol=0, err_msg=f"{mode} {tag}")
+    import pytest
+    with pytest.raises(RuntimeError):
+        scheduler_lambda(schedule_mode="step")
+
+
+def test_configure_optimizers_returns_the_reference_layout():
+    """models/module.py:245-254: {"optimizer": AdamW(lr 2e-5, wd 1e-4), "lr_scheduler": LambdaLR(exp_lin)}; the schedule
+    drives the optimizer's learning rate epoch by epoch."""
+    import torch
+    from maest_amd.module import Module
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(3))
+    mod = Module(net=Tiny())
+    cfg = mod.configure_optimizers()
+    opt, sched = cfg["optimizer"], cfg["lr_scheduler"]
+    assert isinstance(opt, torch.optim.AdamW) and isinstance(sched, torch.optim.lr_scheduler.LambdaLR)
+    assert opt.defaults["lr"] == 2e-5 and opt.defaults["weight_decay"] == 1e-4
+    f = mod.get_scheduler_lambda()
+    for epoch in range(1, 8):
+        opt.step()
+        sched.step()
+        assert abs(opt.param_groups[0]["lr"] - 2e-5 * f(epoch)) < 1e-18
+    assert isinstance(Module(net=Tiny(), adamw=False).get_optimizer(), torch.optim.Adam)
