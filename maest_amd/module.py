@@ -1,5 +1,5 @@
-"""Training harness for the hot path: the tensor work of the reference's Lightning module
-(models/module.py:44-102 ``Module``, :279-316 ``TeacherStudentModule``) without Lightning/Sacred.
+"""Training / evaluation harness for the hot path: the tensor work of the reference's Lightning module
+(models/module.py:44-254 ``Module``, :279-352 ``TeacherStudentModule``) without Lightning/Sacred.
 
 ``training_step(batch, batch_idx) -> loss`` keeps the reference contract (a scalar tensor with a grad
 edge; the caller runs ``loss.backward()`` and ``optimizer.step()``), but executes as:
@@ -66,7 +66,7 @@ class Module(nn.Module):
 
     def __init__(self, net=None, mixup_alpha=0.3, lr=2e-5, weight_decay=1e-4, spec_masking=None, adamw=True,
                  warm_up_len=5, ramp_down_start=50, ramp_down_len=50, last_lr_value=0.01, schedule_mode="exp_lin",
-                 **maest_kwargs):
+                 do_swa=False, distributed_mode=False, **maest_kwargs):
         """``spec_masking``: a ``maest_amd.spec_masking.SpecMasking`` (or None).  The reference applies it per clip in
         the loader workers (discogs/datamodule.py:140-152), i.e. before mixup; here its stripes are drawn on the
         host each step and applied as a predicate of the patch-embedding operand load (no extra pass over the
@@ -82,6 +82,17 @@ class Module(nn.Module):
                              ramp_down_len=ramp_down_len, last_lr_value=last_lr_value)
         self.net = net if net is not None else get_maest(**maest_kwargs)
         self.last_mixup = None
+        # evaluation loop state (models/module.py:55-66, :104-116)
+        self.do_swa = do_swa
+        self.distributed_mode = distributed_mode
+        self.transformer_block = -1
+        self.validation_outputs = []
+        self.test_outputs = []
+        self.logged = {}                  # what Lightning's self.log / log_dict would have received, by name
+        if do_swa:                        # reference: created by the SWA callback at fit start (helpers/swa_callback.py:43-44)
+            from .swa import WeightAverager
+            self.averager = WeightAverager(self.net)
+            self.net_swa = self.averager.net_swa
 
     def forward(self, batch, transformer_block=-1, **kw):
         # the reference hard-codes transformer_block=-1 here (models/module.py:68-71)
@@ -115,6 +126,91 @@ class Module(nn.Module):
         perm, lam = mix if mix is not None else (None, None)
         return bce_with_logits(y_hat, y, perm, lam)
 
+    # ------------------------------------------------------------------ evaluation loop (models/module.py:104-212)
+    def log(self, name, value, **_):
+        self.logged[name] = float(value)
+
+    def log_dict(self, values, **_):
+        for k, v in values.items():
+            self.log(k, v)
+
+    @torch.no_grad()
+    def predict_step(self, batch, batch_idx=0, dataloader_idx=None):
+        """models/module.py:104-112 (like the reference, `forward` pins transformer_block to -1 whatever was set)."""
+        x, f, y = batch
+        logits, embed = self.forward(x, transformer_block=self.transformer_block)
+        return {"logits": logits.detach().cpu(), "embeddings": embed.detach().cpu(), "filename": f}
+
+    def set_prediction_tranformer_block(self, transformer_block):
+        self.transformer_block = transformer_block
+
+    @staticmethod
+    def _join(strings):
+        return "_".join(filter(lambda x: x, strings))
+
+    def _net_map(self):
+        net_map = [(None, self.net)]
+        if self.do_swa:
+            net_map.append(("swa", self.net_swa))
+        return net_map
+
+    @torch.no_grad()
+    def test_validation_step(self, batch, batch_idx, output_buffer, stage):
+        """models/module.py:121-146: per evaluated net the mean BCE (csrc/misc.hip:bce_logits_kernel) and the sigmoid
+        scores, kept on the device for the epoch-end metrics."""
+        x, f, y = batch
+        outputs = {"y": y.detach()}
+        batch_size = len(y)
+        for name, net in self._net_map():
+            logits, _ = net(x)
+            loss = bce_with_logits(logits, y).detach()
+            outputs[self._join((name, "loss"))] = loss
+            outputs[self._join((name, "y_hat"))] = torch.sigmoid(logits.detach().float())
+            output_buffer.append(outputs)        # (the reference appends once per evaluated net, :136; kept)
+            self.log(self._join((stage, "loss", name)), loss, batch_size=batch_size, sync_dist=True)
+        return outputs
+
+    def validation_step(self, batch, batch_idx=0):
+        return self.test_validation_step(batch, batch_idx, self.validation_outputs, "val")
+
+    def test_step(self, batch, batch_idx=0):
+        return self.test_validation_step(batch, batch_idx, self.test_outputs, "test")
+
+    def _all_gather(self, t):
+        """Lightning's self.all_gather: [world, ...] stacked over ranks (torch.distributed; eval glue)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return t.unsqueeze(0)
+        parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t.contiguous())
+        return torch.stack(parts)
+
+    @torch.no_grad()
+    def on_test_validation_epoch_end(self, outputs, stage):
+        """models/module.py:156-202: macro average precision and ROC-AUC over everything the epoch collected
+        (maest_amd/metrics.py: on the device, equal to scikit-learn's to 1e-9), mean loss, per evaluated net."""
+        from .metrics import macro_average_precision, macro_roc_auc
+        y = torch.cat([o["y"] for o in outputs], dim=0)
+        if self.distributed_mode:
+            y = self._all_gather(y).reshape(-1, y.shape[-1])
+        for name, net in self._net_map():
+            loss = torch.stack([o[self._join((name, "loss"))].reshape(()) for o in outputs]).mean()
+            y_hat = torch.cat([o[self._join((name, "y_hat"))] for o in outputs], dim=0)
+            if self.distributed_mode:
+                loss = self._all_gather(loss).mean()
+                y_hat = self._all_gather(y_hat).reshape(-1, y_hat.shape[-1])
+            self.log_dict({self._join((stage, "loss", name)): loss.item(),
+                           self._join((stage, "ap", name)): macro_average_precision(y, y_hat),
+                           self._join((stage, "roc", name)): macro_roc_auc(y, y_hat)}, sync_dist=True)
+        outputs.clear()
+
+    def on_validation_epoch_end(self):
+        self.on_test_validation_epoch_end(self.validation_outputs, "val")
+
+    def on_test_epoch_end(self):
+        self.on_test_validation_epoch_end(self.test_outputs, "test")
+
+    # ------------------------------------------------------------------ optimizer (models/module.py:213-254)
     def get_optimizer(self, params=None):
         """models/module.py:237-243.  Same hyper-parameters as the reference; on the GPU the single-kernel ("fused")
         implementation of the same update: 0.6 ms instead of 1.7 ms per step for 85.9 M parameters."""
@@ -157,3 +253,24 @@ class TeacherStudentModule(Module):
         loss_standard = bce_with_logits(y_hat, y, perm, lam, weight=0.5)
         loss_teacher = bce_with_logits(y_hat_teacher, y_teacher, perm, lam, weight=0.5)
         return loss_standard + loss_teacher
+
+    @torch.no_grad()
+    def test_validation_step(self, batch, batch_idx, output_buffer, stage):
+        """models/module.py:318-352: the logits against the labels and against the teacher.  (`logits, _ = net(x)` as in
+        the reference: a "separated" net returns three values and raises here, there as well.)"""
+        x, f, y, y_teacher = batch
+        outputs = {"y": y.detach(), "y_teacher": y_teacher.detach()}
+        for name, net in self._net_map():
+            logits, _ = net(x)
+            loss_standard = bce_with_logits(logits, y).detach()
+            loss_teacher = bce_with_logits(logits, y_teacher).detach()
+            loss = (loss_standard + loss_teacher) / 2
+            outputs[self._join((name, "loss_standard"))] = loss_standard
+            outputs[self._join((name, "loss_teacher"))] = loss_teacher
+            outputs[self._join((name, "loss"))] = loss
+            outputs[self._join((name, "y_hat"))] = torch.sigmoid(logits.detach().float())
+            output_buffer.append(outputs)
+            self.log_dict({self._join((stage, "loss_standard", name)): loss_standard,
+                           self._join((stage, "loss_teacher", name)): loss_teacher,
+                           self._join((stage, "loss", name)): loss}, sync_dist=True)
+        return outputs

@@ -732,3 +732,82 @@ def test_data_parallel_two_gpus_over_rccl():
     r = subprocess.run([sys.executable, tool, "--backend", "nccl"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "weights identical after 3 steps" in r.stdout
+
+
+def test_validation_loop_matches_the_oracle_and_scikit_learn():
+    """The evaluation side of the Lightning module (models/module.py:104-212): predict_step, validation_step for the
+    live and the SWA net, epoch-end macro AP / ROC-AUC -- losses and scores against the oracle forward (fp32, 1e-3 /
+    1e-4), the metrics against scikit-learn on the same scores (1e-9), buffers cleared like the reference's."""
+    import torch.nn.functional as F
+    from sklearn import metrics as skm
+    net = build("discogs-maest-10s-pw-129e", 625, n_classes=20, precision="fp32").eval()
+    mod = Module(net=net, do_swa=True)
+    with torch.no_grad():                      # make the averaged net differ from the live one
+        for p in net.parameters():
+            p.mul_(1.02)
+        mod.averager.update()
+        for p in net.parameters():
+            p.mul_(0.97)
+        mod.averager.update()
+    sds = {None: {k: v.detach().cpu() for k, v in net.state_dict().items()},
+           "swa": {k: v.detach().cpu() for k, v in mod.net_swa.state_dict().items()}}
+    rng = np.random.Generator(np.random.PCG64(77))
+    batches = []
+    for b in range(2):
+        x = randn((5, 96, 626), 500 + b)
+        y = torch.from_numpy((rng.random((5, 20)) < 0.4).astype(np.float32))
+        y[0], y[1] = 1.0, 0.0                  # every class has both labels within a batch
+        batches.append((x, [f"clip{b}_{i}" for i in range(5)], y))
+    want = {None: [], "swa": []}
+    for x, f, y in batches:
+        out = mod.validation_step((x.to(DEV), f, y.to(DEV)), 0)
+        for name in (None, "swa"):
+            logits, _ = O.forward(x, sds[name], (96, 625))
+            want[name].append((F.binary_cross_entropy_with_logits(logits, y).item(), torch.sigmoid(logits)))
+            key = "loss" if name is None else "swa_loss"
+            assert abs(out[key].item() - want[name][-1][0]) < 1e-4 * want[name][-1][0]
+            assert (out["y_hat" if name is None else "swa_y_hat"].cpu() - want[name][-1][1]).abs().max() < 1e-4
+    assert len(mod.validation_outputs) == 4    # the reference appends the batch's dict once per evaluated net
+    mod.on_validation_epoch_end()
+    assert mod.validation_outputs == []
+    y_all = torch.cat([b[2] for b in batches]).numpy()
+    for name, tag in ((None, ""), ("swa", "_swa")):
+        s_all = torch.cat([w[1] for w in want[name]]).numpy()
+        assert abs(mod.logged["val_loss" + tag] - np.mean([w[0] for w in want[name]])) < 1e-4
+        assert abs(mod.logged["val_ap" + tag] - skm.average_precision_score(y_all, s_all, average="macro")) < 1e-3
+        assert abs(mod.logged["val_roc" + tag] - skm.roc_auc_score(y_all, s_all, average="macro")) < 1e-3
+    assert abs(mod.logged["val_loss"] - mod.logged["val_loss_swa"]) > 1e-5
+    # same scores -> same metrics to rounding: recompute scikit-learn on the module's own y_hat
+    outs = [mod.test_step((x.to(DEV), f, y.to(DEV)), 0) for x, f, y in batches]
+    own = torch.cat([o["y_hat"] for o in outs[::1]]).cpu().numpy()
+    mod.on_test_epoch_end()
+    assert abs(mod.logged["test_ap"] - skm.average_precision_score(y_all, own, average="macro")) < 1e-9
+    assert abs(mod.logged["test_roc"] - skm.roc_auc_score(y_all, own, average="macro")) < 1e-9
+    # predict_step: CPU tensors + the file names, transformer_block pinned to -1 by forward like the reference
+    mod.set_prediction_tranformer_block(6)
+    pred = mod.predict_step((batches[0][0].to(DEV), batches[0][1], batches[0][2]), 0)
+    assert pred["filename"] == batches[0][1] and pred["logits"].device.type == "cpu"
+    assert pred["embeddings"].shape == (5, 768)
+    assert rel_err(pred["logits"], O.forward(batches[0][0], sds[None], (96, 625))[0]) < 1e-3
+
+
+def test_teacher_student_validation_step():
+    """models/module.py:318-352.  The reference unpacks `logits, _ = net(x)`, which only a two-output ("mean") net
+    satisfies -- a "separated" net returns three values and the reference raises there; both behaviours kept."""
+    import torch.nn.functional as F
+    net = build("discogs-maest-10s-pw-129e", 625, n_classes=20, precision="fp32").eval()
+    mod = TeacherStudentModule(net=net)
+    x = randn((3, 96, 626), 600)
+    rng = np.random.Generator(np.random.PCG64(78))
+    y = torch.from_numpy((rng.random((3, 20)) < 0.4).astype(np.float32))
+    yt = torch.from_numpy(rng.random((3, 20)).astype(np.float32))
+    out = mod.validation_step((x.to(DEV), None, y.to(DEV), yt.to(DEV)), 0)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    logits = O.forward(x, sd, (96, 625))[0]
+    ls, lt = F.binary_cross_entropy_with_logits(logits, y).item(), F.binary_cross_entropy_with_logits(logits, yt).item()
+    assert abs(out["loss_standard"].item() - ls) < 1e-4 * ls and abs(out["loss_teacher"].item() - lt) < 1e-4 * lt
+    assert abs(out["loss"].item() - (ls + lt) / 2) < 1e-4
+    assert abs(mod.logged["val_loss"] - (ls + lt) / 2) < 1e-4
+    sep = build("discogs-maest-10s-pw-129e", 625, n_classes=20, precision="fp32", distilled_type="separated").eval()
+    with pytest.raises(ValueError):
+        TeacherStudentModule(net=sep).validation_step((x.to(DEV), None, y.to(DEV), yt.to(DEV)), 0)
