@@ -89,3 +89,41 @@ class MelFileReader:
         offsets = offsets if offsets is not None else [None] * len(filenames)
         rows = [self.read_rows(self.base_dir / f, o) for f, o in zip(filenames, offsets)]
         return self.assemble(rows, device, normalize)
+
+    # ---- evaluation: every chunk of every track (DiscogsDatasetExhaustive.__init__, dataset.py:218-246) --------
+    def exhaustive_plan(self, filenames: Sequence, half_overlapped: bool = False) -> List[Tuple[str, int]]:
+        """(file, frame offset) pairs that tile each raw float16 track with patches of `melspectrogram_size` frames,
+        hop = the patch (or half of it), keeping the patches that start within 110 % of the track (the tail is
+        zero-padded by the reader); other file types get the single patch (file, 0)."""
+        size = self.melspectrogram_size
+        hop = size // 2 if half_overlapped else size
+        names = [str(f) for f in filenames]
+        if not names or pathlib.Path(names[0]).suffix != ".mmap":
+            return [(f, 0) for f in names]
+        plan = []
+        for f in names:
+            frames_num = (self.base_dir / f).stat().st_size // (2 * self.n_bands)
+            if half_overlapped:
+                frames_num -= hop
+            n_patches = int((frames_num * 1.1) // hop)
+            plan.extend((f, i * hop) for i in range(n_patches))
+        return plan
+
+
+def hard_teacher_target(logits: np.ndarray, threshold: float) -> np.ndarray:
+    """``DiscogsDatasetTS.__getitem__`` (dataset.py:177-191): teacher logits as stored (``<file>.logits.npy``) ->
+    float16 -> logistic -> {0,1} float16 at `threshold`; when no class passes, the arg-max class alone.  Host glue
+    (a few hundred values per clip); scipy's ``expit`` as in the reference so that borderline classes fall the same way."""
+    from scipy.special import expit
+    t = expit(np.asarray(logits).astype("float16").squeeze())
+    hard = (t > threshold).astype("float16")
+    if not np.sum(hard):
+        hard = np.zeros(hard.shape, dtype="float16")
+        hard[np.argmax(t)] = 1.0
+    return hard
+
+
+def load_teacher_targets(filenames: Sequence, teacher_target_base_dir, threshold: float) -> np.ndarray:
+    """float16 ``[B, C]`` hard teacher targets of a batch (one ``.logits.npy`` per clip, dataset.py:172-175)."""
+    base = pathlib.Path(teacher_target_base_dir)
+    return np.stack([hard_teacher_target(np.load(base / (str(f) + ".logits.npy")), threshold) for f in filenames])

@@ -67,3 +67,36 @@ def test_reader_refuses_cpu_tensors(tmp_path):
     _frames(60, 1, 96).tofile(tmp_path / "a.mel")
     with pytest.raises((MaestHipError, RuntimeError, AssertionError)):
         rd.load_batch(["a.mel"], "cpu", offsets=[0])
+
+
+def test_exhaustive_plan_and_teacher_targets_match_the_reference_fixture(tmp_path):
+    """tests/golden/g11_dataset_formats.npz (oracle/gen_golden_dataset.py: DiscogsDatasetExhaustive's chunk plan and
+    DiscogsDatasetTS's hard teacher targets, captured from the imported reference) -- host logic, exact."""
+    import os
+    import numpy as np
+    from maest_amd.melfile import MelFileReader, hard_teacher_target, load_teacher_targets
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_dataset_formats.npz"))
+    bands = int(g["bands"])
+    names = [f"a/track{i}.mmap" for i in range(len(g["frames"]))]
+    os.makedirs(tmp_path / "a")
+    for n, fr in zip(names, g["frames"]):
+        np.zeros((int(fr), bands), "float16").tofile(tmp_path / n)          # only the sizes matter for the plan
+    rd = MelFileReader(tmp_path, clip_length=int(g["clip_length"]), sample_rate=int(g["sample_rate"]),
+                       hop_size=int(g["hop_size"]), n_bands=bands)
+    for half in (0, 1):
+        plan = rd.exhaustive_plan(names, half_overlapped=bool(half))
+        assert [names.index(f) for f, _ in plan] == list(g[f"plan_half{half}_file"])
+        assert [o for _, o in plan] == list(g[f"plan_half{half}_offset"])
+        for f, o in plan:                                                    # every planned patch is readable
+            assert 0 < rd.plan(tmp_path / f, int(o))[1] <= rd.melspectrogram_size
+    assert rd.exhaustive_plan(["x.npy", "y.npy"]) == [("x.npy", 0), ("y.npy", 0)]
+    thr = float(g["teacher_threshold"])
+    want = g["teacher_hard"].view(np.float16)
+    os.makedirs(tmp_path / "t" / "a")
+    for n, lg in zip(names, g["teacher_logits"]):
+        np.save(tmp_path / "t" / (n + ".logits.npy"), lg)
+        got = hard_teacher_target(lg, thr)
+        assert got.dtype == np.float16
+    got = load_teacher_targets(names, tmp_path / "t", thr)
+    assert np.array_equal(got.view(np.uint16), g["teacher_hard"])
+    assert want[1].sum() == 1.0                                              # the arg-max fallback row
