@@ -226,7 +226,7 @@ def main():
         net.train()
         if args.hip_graph:
             net.enable_hip_graph()
-        opt = mod.configure_optimizers()["optimizer"]
+        opt = mod.get_optimizer()
         reducer = None
         if world > 1:
             skip = () if ts else ("head_dist.weight", "head_dist.bias")

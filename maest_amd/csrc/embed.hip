@@ -152,8 +152,12 @@ __global__ __launch_bounds__(192) void token_assemble_kernel(const float* __rest
     }
 }
 
-// grid (Ntok, 3): thread = channel; loops over the batch (coalesced over channels)
-__global__ __launch_bounds__(256) void token_assemble_bwd_kernel(const float* __restrict__ dx0, int B, int Fg, int P,
+// grid (Ntok, batch slices): thread = 4 channels (16-byte accesses); each workgroup walks ITS slice of the batch with the
+// loads of four clips in flight, and adds its partial sums to the (pre-zeroed) parameter gradients with atomics -- the
+// time / frequency tables are reduced over tokens that way in any case.  (One workgroup per token walking all 256 clips
+// with 4-byte loads was latency-bound: 222 us for 341 MB.)
+constexpr int TAB_SLICES = 8;
+__global__ __launch_bounds__(192) void token_assemble_bwd_kernel(const float* __restrict__ dx0, int B, int Fg, int P,
                                                                  int Tt, int toffset,
                                                                  const int32_t* __restrict__ tok_ft,
                                                                  void* __restrict__ dpatches, int dtype,
@@ -163,29 +167,52 @@ __global__ __launch_bounds__(256) void token_assemble_bwd_kernel(const float* __
                                                                  float* __restrict__ d_time_pos) {
     const int Ntok = 2 + P;
     const int n = blockIdx.x;
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    float s = 0.0f;
-    for (int b = 0; b < B; ++b) {
-        const float g = dx0[((int64_t)b * Ntok + n) * PE_D + c];
-        s += g;
-        if (n >= 2 && dpatches != nullptr) {
+    const int c = threadIdx.x * 4;
+    const int per = (B + TAB_SLICES - 1) / TAB_SLICES;
+    const int b0 = blockIdx.y * per;
+    const int b1 = b0 + per < B ? b0 + per : B;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool store = n >= 2 && dpatches != nullptr;
+    auto one = [&](int b, const float4& g) {
+        s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+        if (store) {
             const int64_t o = ((int64_t)b * P + (n - 2)) * PE_D + c;
-            if (dtype == MAEST_BF16) reinterpret_cast<bf16_t*>(dpatches)[o] = f2bf(g);
-            else reinterpret_cast<float*>(dpatches)[o] = g;
+            if (dtype == MAEST_BF16) {
+                chunk8 v;
+                v[0] = pack_bf2(g.x, g.y); v[1] = pack_bf2(g.z, g.w);
+                *reinterpret_cast<chunk8*>(reinterpret_cast<bf16_t*>(dpatches) + o) = v;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(dpatches) + o) = g;
+            }
         }
+    };
+    const int64_t bstride = (int64_t)Ntok * PE_D;
+    const float* src = dx0 + (int64_t)n * PE_D + c;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        float4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const float4*>(src + (b + u) * bstride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(b + u, g[u]);
     }
+    for (; b < b1; ++b) one(b, *reinterpret_cast<const float4*>(src + b * bstride));
+    if (b0 >= b1) return;
     if (n == 0) {
-        d_cls[c] += s;
-        d_new_pos[c] += s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsafeAtomicAdd(d_cls + c + e, s[e]); unsafeAtomicAdd(d_new_pos + c + e, s[e]); }
     } else if (n == 1) {
-        d_dist[c] += s;
-        d_new_pos[PE_D + c] += s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsafeAtomicAdd(d_dist + c + e, s[e]); unsafeAtomicAdd(d_new_pos + PE_D + c + e, s[e]); }
     } else {
         const int j = n - 2;
         const int f = tok_ft[2 * j];
         const int tcol = toffset + tok_ft[2 * j + 1];
-        unsafeAtomicAdd(d_freq_pos + (int64_t)c * Fg + f, s);
-        unsafeAtomicAdd(d_time_pos + (int64_t)c * Tt + tcol, s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsafeAtomicAdd(d_freq_pos + (int64_t)(c + e) * Fg + f, s[e]);
+            unsafeAtomicAdd(d_time_pos + (int64_t)(c + e) * Tt + tcol, s[e]);
+        }
     }
 }
 
@@ -295,7 +322,8 @@ extern "C" int maest_token_assemble_bwd(const float* dx0, int B, int P, int Fg, 
     MAEST_REQUIRE(dx0 && d_cls && d_dist && d_new_pos && d_freq_pos && d_time_pos && tok_ft,
                   "maest_token_assemble_bwd: null pointer");
     MAEST_REQUIRE(B > 0 && P > 0 && Fg > 0 && Tt > 0, "maest_token_assemble_bwd: bad shape");
-    hipLaunchKernelGGL(token_assemble_bwd_kernel, dim3(2 + P, PE_D / 256), dim3(256), 0, (hipStream_t)stream,
+    static_assert(PE_D == 192 * 4, "token_assemble_bwd_kernel: one thread per four channels");
+    hipLaunchKernelGGL(token_assemble_bwd_kernel, dim3(2 + P, TAB_SLICES), dim3(192), 0, (hipStream_t)stream,
                        dx0, B, Fg, P, Tt, toffset, tok_ft, dpatches, dtype, d_cls, d_dist, d_new_pos, d_freq_pos,
                        d_time_pos);
     return check_launch("maest_token_assemble_bwd");

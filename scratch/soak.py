@@ -7,7 +7,7 @@ from maest_amd.module import Module
 dev = "cuda"
 torch.manual_seed(0); np.random.seed(0)
 net = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30, precision="bf16").to(dev).train()
-mod = Module(net=net, lr=1e-4); opt = mod.configure_optimizers()["optimizer"]
+mod = Module(net=net, lr=1e-4); opt = mod.get_optimizer()
 B = 256
 x = torch.randn(B, 1, 96, 626, device=dev); y = (torch.rand(B, 400, device=dev) < 0.00625).float()
 losses = []

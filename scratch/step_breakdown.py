@@ -6,7 +6,7 @@ from maest_amd.module import Module
 dev = "cuda"
 net = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30, precision="bf16").to(dev).train()
 mod = Module(net=net)
-opt = mod.configure_optimizers()["optimizer"]
+opt = mod.get_optimizer()
 import os
 if os.environ.get("MAEST_SERIAL"): net._engine.overlap_wgrad = False     # each event pair then times one kernel alone
 B = 256

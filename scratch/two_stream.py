@@ -6,7 +6,7 @@ from maest_amd.module import Module
 dev = "cuda"
 def make(B):
     net = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30, precision="bf16").to(dev).train()
-    mod = Module(net=net); opt = mod.configure_optimizers()["optimizer"]
+    mod = Module(net=net); opt = mod.get_optimizer()
     x = torch.randn(B, 1, 96, 626, device=dev); y = (torch.rand(B, 400, device=dev) < 0.006).float()
     def step():
         loss = mod.training_step((x, None, y), 0); loss.backward(); opt.step(); opt.zero_grad()

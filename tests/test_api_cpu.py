@@ -221,6 +221,10 @@ def test_configure_optimizers_returns_the_reference_layout():
     assert isinstance(opt, torch.optim.AdamW) and isinstance(sched, torch.optim.lr_scheduler.LambdaLR)
     assert opt.defaults["lr"] == 2e-5 and opt.defaults["weight_decay"] == 1e-4
     f = mod.get_scheduler_lambda()
+    # LambdaLR applies the epoch-0 factor on construction (exp warm-up: 0.0174 x lr), exactly as under Lightning;
+    # callers that want the bare optimizer (bench.py, the parity tests) use get_optimizer()
+    assert abs(opt.param_groups[0]["lr"] - 2e-5 * f(0)) < 1e-18 and f(0) < 0.02
+    assert mod.get_optimizer().param_groups[0]["lr"] == 2e-5
     for epoch in range(1, 8):
         opt.step()
         sched.step()

@@ -403,7 +403,7 @@ def test_short_training_run_bf16_tracks_fp32():
         np.random.seed(11)
         net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision=precision).train()
         mod = Module(net=net, mixup_alpha=0.3, lr=1e-4)
-        opt = mod.configure_optimizers()["optimizer"]
+        opt = mod.get_optimizer()
         x = randn((16, 1, 96, 626), 500).to(DEV)
         rng = np.random.Generator(np.random.PCG64(501))
         y = torch.from_numpy((rng.random((16, 400)) < 0.02).astype(np.float32)).to(DEV)
@@ -430,7 +430,7 @@ def test_three_adamw_steps_match_the_oracle_fp32():
     net.load_state_dict(sd)
     net = net.to(DEV).train()
     mod = Module(net=net, mixup_alpha=0.3, lr=1e-3)
-    opt = mod.configure_optimizers()["optimizer"]
+    opt = mod.get_optimizer()
     sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     opt_o = torch.optim.AdamW([v for k, v in sdo.items() if not k.startswith("head_dist")], lr=1e-3, betas=(0.9, 0.999),
                               eps=1e-08, weight_decay=1e-4)
@@ -644,7 +644,7 @@ def test_hip_graph_captured_training_forward_equals_eager():
         assert abs(l - le) <= 3e-7 * abs(le), (l, le)
         assert rel_err(g1, ge1) < 1e-4 and rel_err(g2, ge2) < 1e-4
     # an optimizer step between replays: the recast inside the graph must pick the new weights up
-    opt = mod.configure_optimizers()["optimizer"]
+    opt = mod.get_optimizer()
     l0 = step(x, mix, po)[0]
     for _ in range(3):
         opt.step()
@@ -691,7 +691,7 @@ def test_weight_averager_built_mid_training_with_a_gradient_sink():
     g = np.load(os.path.join(GOLD, "g5_train_step.npz"))
     net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision="bf16").train()
     mod = Module(net=net, mixup_alpha=0.3, lr=1e-3)
-    opt = mod.configure_optimizers()["optimizer"]
+    opt = mod.get_optimizer()
     red = GradReducer(net.named_parameters(), skip=("head_dist.weight", "head_dist.bias"))
     net._grad_sink = red
     net.enable_hip_graph()

@@ -36,7 +36,7 @@ def worker(rank, world, port, out, backend):
     assert (r, l, w) == (rank, local, world)
     net, mod = make(seed=5 + rank)                      # different init per rank: broadcast must fix it
     broadcast_parameters(net)
-    opt = mod.configure_optimizers()["optimizer"]
+    opt = mod.get_optimizer()
     red = GradReducer(net.named_parameters(), skip=("head_dist.weight", "head_dist.bias"), bucket_mb=64)
     net._grad_sink = red
     x, y = data(rank)
