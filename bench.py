@@ -39,6 +39,13 @@ def flops_per_clip_fwd(N, Tk, C=400):
     return 12 * per_block + 2 * (9 * Tk) * 256 * 768 + 2 * 768 * C
 
 
+def flops_per_clip_fwd_not_executed(N, attn_rows):
+    """Forward FLOPs of the algorithmic count above that the engine does not execute: the last block runs its attention
+    queries, proj and MLP only for the two tokens the head reads (maest.py: _Engine.head_tail; outputs and gradients are
+    those of the full evaluation).  attn_rows = query rows the attention kernel still computes per clip."""
+    return 2 * (N - 2) * 768 * (768 + 3072 + 3072) + 4 * (N - attn_rows) * N * 768
+
+
 PMC_TRAFFIC_FILE = "profiles/r02b_pmc_traffic.json"
 
 
@@ -177,6 +184,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=None, help="clips per oracle step of the CPU baseline (SURVEY 8d: B = 8)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--complete-last-block", action="store_true",
+                    help="evaluate the last block on every token (A/B reference for the head-token restriction)")
     ap.add_argument("--serial-kernels", action="store_true",
                     help="disable the side-stream overlap of weight-gradient GEMMs (for kernel profiling)")
     args = ap.parse_args()
@@ -207,6 +216,8 @@ def main():
     net = get_maest(arch, pretrained=False, input_t=img_t, n_classes=C, s_patchout_t=patchout,
                     distilled_type="separated" if ts else "mean", precision=args.precision).to(dev)
     broadcast_parameters(net)
+    if args.complete_last_block:
+        net._engine.head_tail = False
     if args.serial_kernels:
         net._engine.overlap_wgrad = False
     mod = (TeacherStudentModule if ts else Module)(net=net, mixup_alpha=0.3)
@@ -292,6 +303,12 @@ def main():
         value = world * B * args.steps / elapsed
         fwd = flops_per_clip_fwd(N, Tk, C) + (2 * 768 * C if ts else 0)
         step_flops = (3 if train else 1) * fwd * B
+        tail_on = bool(getattr(net._engine, "head_tail", False))
+        # (training at shapes the fused attention backward does not serve keeps the last block's attention complete)
+        from maest_amd import ops as _ops
+        attn_rows = min(32, N) if (not train or _ops.attn_bwd_rows_supported(
+            torch.bfloat16 if args.precision == "bf16" else torch.float32, N)) else N
+        skipped = (3 if train else 1) * flops_per_clip_fwd_not_executed(N, attn_rows) * B if tail_on else 0
         secs = "10s" if T <= 640 else "30s"
         if ts:
             workload = ("discogs-maest-30s-pw-73e-ts teacher-student training step (BASELINE configs[4]): waveform -> "
@@ -315,9 +332,14 @@ def main():
                        "s_patchout_t": patchout, "tokens": N, "classes": C,
                        "hip_graph_forward": bool(args.hip_graph),
                        "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, overlapped)" if world > 1 else "")},
-            "model_tflops_per_s": round(step_flops * world / (elapsed / args.steps) / 1e12, 1),
-            "model_mfma_frac": round(step_flops / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            # FLOPs actually executed (the algorithmic count minus the last block's rows that feed nothing)
+            "model_tflops_per_s": round((step_flops - skipped) * world / (elapsed / args.steps) / 1e12, 1),
+            "model_mfma_frac": round((step_flops - skipped) / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "executed_flop_fraction": round(1.0 - skipped / step_flops, 4),
         }
+        out["config"]["last_block"] = ("attention queries, proj, norm2 and MLP evaluated for the two tokens the head reads "
+                                       "(cls, dist) only, forward and backward; logits, features and all gradients equal "
+                                       "the complete evaluation's" if tail_on else "complete")
         if timer is not None:
             summ = timer.summary()
             g = summ.get("maest_gemm_nt")

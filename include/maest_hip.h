@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MAEST_ABI_VERSION 2
+#define MAEST_ABI_VERSION 3
 
 #define MAEST_OK 0
 #define MAEST_ERR_INVALID 1 /* bad argument (shape / alignment / dtype) */
@@ -124,6 +124,14 @@ int maest_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const float*
                         const float* dres, float* dx_out, void* dx_lp, int dx_lp_dtype,
                         float* dgamma, float* dbeta, int rows, int cols, void* stream);
 
+/* The same with a COMPACT residual gradient: dres is [rows / n_tok][n_head][768] -- the first n_head tokens of every
+ * clip of n_tok tokens; the other tokens' residual gradient is zero.  (Last block of the network: only the tokens the
+ * head reads, cls and dist, carry a gradient above it -- models/maest.py:819-826.)  n_head = 0: dense dres / NULL. */
+int maest_layernorm_bwd_headres(const void* dy, int64_t lddy, int dy_dtype, const float* x, int64_t ldx,
+                                const float* gamma, const float* mean, const float* rstd,
+                                const float* dres, float* dx_out, void* dx_lp, int dx_lp_dtype,
+                                float* dgamma, float* dbeta, int rows, int cols, int n_tok, int n_head, void* stream);
+
 /* ---- K9 fused softmax attention (Attention.forward: models/maest.py:362-375) ---------------------
  * qkv: [B*N, 2304] with column = s*768 + h*64 + d  (s = 0,1,2 for q,k,v), exactly the layout the
  * reference's qkv Linear produces before its reshape/permute (:362-363).
@@ -134,6 +142,21 @@ int maest_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int dty
 /* delta: fp32 [B,12,N] workspace (rowsum(dO*O)); dqkv: [B*N, 2304] same layout as qkv. */
 int maest_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                    float* delta, void* dqkv, int B, int N, int dtype, float scale, void* stream);
+/* Attention of the LAST block, where only the first q_rows tokens of a clip (cls, dist) are read by what follows
+ * (final norm + head, models/maest.py:819-826): the same functions restricted to those queries; keys / values stay
+ * complete.  Forward: rows / lse of queries >= roundup(q_rows, 32) are NOT written.  Backward: dout rows
+ * [q_rows, roundup(q_rows, 32)) must be zero, later rows are not read (nor are out / lse there); dK, dV complete, dQ = 0
+ * for every query >= q_rows.  q_rows = N is maest_attn_fwd / maest_attn_bwd.  Backward with q_rows < N is served by
+ * the fused bf16 kernel only (N <= 320): MAEST_ERR_INVALID otherwise. */
+int maest_attn_fwd_rows(const void* qkv, void* out, float* lse, int B, int N, int dtype, float scale, int q_rows,
+                        void* stream);
+int maest_attn_bwd_rows(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                        int B, int N, int dtype, float scale, int q_rows, void* stream);
+/* Rows of the first n_head tokens of every clip, [clips][n_tok][768] -> compact [clips][n_head][768] (dtype fp32 / bf16),
+ * and back: dst rows [0, n_pad) of every clip = the compact rows followed by zeros, rows >= n_pad untouched. */
+int maest_gather_head_rows(const void* src, int clips, int n_tok, int n_head, int dtype, void* dst, void* stream);
+int maest_scatter_head_rows(const void* src, int clips, int n_tok, int n_head, int n_pad, int dtype, void* dst,
+                            void* stream);
 
 /* ---- K16 + K4 operand: mixup + im2col of the 16x16 / stride-10 patches ---------------------------
  * PatchEmbed.forward (models/maest.py:243-256) fused with Module.training_step's mixup

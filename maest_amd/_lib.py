@@ -33,6 +33,11 @@ SIGNATURES = {
     "maest_layernorm_bwd": [_P, _L, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
     "maest_attn_fwd": [_P, _P, _P, _I, _I, _I, _F, _P],
     "maest_attn_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "maest_attn_fwd_rows": [_P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "maest_attn_bwd_rows": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "maest_layernorm_bwd_headres": [_P, _L, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "maest_gather_head_rows": [_P, _I, _I, _I, _I, _P, _P],
+    "maest_scatter_head_rows": [_P, _I, _I, _I, _I, _I, _P, _P],
     "maest_patch_im2col": [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "maest_token_assemble": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P, _P],
     "maest_token_assemble_bwd": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P],
@@ -55,7 +60,7 @@ SIGNATURES = {
     "maest_get_option": [_I, _P],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "ln_bwd_blocks": 4}
 
 _lib = None

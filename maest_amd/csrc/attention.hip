@@ -230,16 +230,17 @@ template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(const T* __restrict__ qkv,
                                                                                 T* __restrict__ out,
                                                                                 float* __restrict__ lse, int B, int N,
-                                                                                float scale) {
+                                                                                float scale, int q_rows) {
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[key][d], V[key][d] }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const AttnBlock blk = attn_block((N + 127) / 128, B);
     const int head = blk.head, b = blk.b;
+    if (blk.rb * 128 >= q_rows) return;   // block-uniform: only the first q_rows queries are wanted (the head's tokens)
     const int q0 = blk.rb * 128 + wave * 32;
     const int q = q0 + (lane & 31);
-    const bool wave_active = q0 < N;   // wave-uniform
+    const bool wave_active = q0 < N && q0 < q_rows;   // wave-uniform
     const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
     const T* kbase = qbase + NHEADS * HD;
     const T* vbase = qbase + 2 * NHEADS * HD;
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(c
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q < N) {
+    if (q < N && wave_active) {
         store_dT<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv);
         if (lse != nullptr && h == 0) lse[((int64_t)b * NHEADS + head) * N + q] = m_run * LN2 + logf(l_tot);
     }
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(c
 // delta[b,head,q] = sum_d dO[b,q,head,d] * O[b,q,head,d]      (4 lanes per (row, head))
 template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
-                                                         float* __restrict__ delta, int B, int N) {
+                                                         float* __restrict__ delta, int B, int N, int q_rows) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)B * N * NHEADS;
     int64_t item = gid >> 2;
@@ -347,14 +348,17 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
     if (!valid) item = total - 1;
     const int64_t row = item / NHEADS;
     const int head = (int)(item - row * NHEADS);
-    const T* po = o + row * OUT_LD + head * HD + quarter * 16;
-    const T* pd = dout + row * OUT_LD + head * HD + quarter * 16;
+    // rows beyond the query tiles the backward visits are never read: they re-read row 0 (one hot line) and store nothing
+    const bool skip = q_rows < N && (int)(row % N) >= ((q_rows + 31) & ~31);
+    const int64_t srow = skip ? 0 : row;
+    const T* po = o + srow * OUT_LD + head * HD + quarter * 16;
+    const T* pd = dout + srow * OUT_LD + head * HD + quarter * 16;
     float acc = 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc += elem_traits<T>::to_f32(po[i]) * elem_traits<T>::to_f32(pd[i]);
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
-    if (valid && quarter == 0) {
+    if (valid && !skip && quarter == 0) {
         const int64_t bb = row / N;
         const int64_t qq = row - bb * N;
         delta[(bb * NHEADS + head) * N + qq] = acc;
@@ -887,11 +891,14 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
                                                                         const float* __restrict__ lse,
                                                                         const float* __restrict__ delta,
                                                                         bf16_t* __restrict__ dqkv, int B, int N,
-                                                                        float scale) {
+                                                                        float scale, int q_rows) {
     using T = bf16_t;
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nkw = (N + 31) >> 5;                 // key waves = key blocks = query tiles
+    const int nkw = (N + 31) >> 5;                 // key waves = key blocks
+    // query tiles that carry gradient: all of them, or only the first ones (the last block of the network, where only
+    // the head's tokens -- queries 0 .. q_rows-1 -- have a non-zero dO; rows of those tiles beyond q_rows hold dO = 0)
+    const int nqt = q_rows < N ? (q_rows + 31) >> 5 : nkw;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -933,7 +940,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
         MAEST_ATTN_WAIT_VM0();                             // this wave's share of the K DMA (and its fragments) landed
         __builtin_amdgcn_s_barrier();                      // K in LDS, query tile 0 staged
         int buf = 0;
-        for (int t = 0; t < nkw; ++t) {
+        for (int t = 0; t < nqt; ++t) {
             const char* q_lds = qbuf0 + buf * F2_QBUF;
             const char* do_lds = q_lds + 32 * 128;
             const float* lse_lds = reinterpret_cast<const float*>(q_lds + 2 * 32 * 128);
@@ -1006,17 +1013,17 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
         const int fld = aux == 0 ? QKV_LD : OUT_LD;
         const float* sbase = aux == 0 ? lse_b : dl_b;      // per-row statistic this wave carries: lse (scaled) / delta
         auto tile_dma = [&](int t) {                       // this wave's 32 x 128 B tile of query tile t -> ring buffer t % 3
-            if (t >= nkw || aux > 1) return;
+            if (t >= nqt || aux > 1) return;
             char* dst = qbuf0 + (t % 3) * F2_QBUF + (aux == 0 ? 0 : 32 * 128);
             dma_rows128(dst, fbase, fld, t * 32, 0, 4, 1, N, lane);
         };
         auto stat_load = [&](int t) -> float {             // (unconditional, clamped: see attn_bwd_fused_kernel)
             int row = t * 32 + (lane & 31);
             row = row < N ? row : N - 1;
-            return (t < nkw && aux <= 1) ? sbase[row] : 0.0f;
+            return (t < nqt && aux <= 1) ? sbase[row] : 0.0f;
         };
         auto stat_store = [&](float v, int t) {
-            if (t >= nkw || aux > 1 || lane >= 32) return;
+            if (t >= nqt || aux > 1 || lane >= 32) return;
             const bool live = t * 32 + lane < N;
             float* dstp = reinterpret_cast<float*>(qbuf0 + (t % 3) * F2_QBUF + 2 * 32 * 128) + (aux == 0 ? 0 : 32) + lane;
             if (aux == 0) *dstp = live ? v * LOG2E : -NEG_BIG;   // padded rows: lse = +BIG -> P = 2^(-BIG) = 0
@@ -1064,7 +1071,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
         MAEST_ATTN_WAIT_VM0();
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();                      // K in LDS, query tile 0 staged (tile 1 landed too)
-        for (int t = 0; t < nkw; ++t) {
+        for (int t = 0; t < nqt; ++t) {
             // Everything issued one step ago has landed by now: the DMA of tile t + 1, and the dQ stores of job
             // t - 2, which were issued BEFORE the dQ product of that step -- a store issued right in front of this
             // wait would put its latency on the critical path (vmcnt counts stores too on gfx950).
@@ -1077,9 +1084,16 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
             __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): statistics of tile t + 1 are in LDS
             __builtin_amdgcn_s_barrier();
         }
-        dq_store(dq_prev, nkw - 2);
-        dq_compute(dq_prev, nkw - 1);
-        dq_store(dq_prev, nkw - 1);
+        dq_store(dq_prev, nqt - 2);
+        dq_compute(dq_prev, nqt - 1);
+        dq_store(dq_prev, nqt - 1);
+        if (aux <= 1) {                                    // queries without gradient: dQ = 0
+            for (int q = nqt * 32 + (lane & 31); q < N; q += 32) {
+                T* row = dq_out + (uint32_t)(q * QKV_LD + aux * 32);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) store4<T>(row + 8 * g + 4 * h, 0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
         __builtin_amdgcn_s_barrier();                      // LDS may be reused by the key waves' epilogue
         __syncthreads();
     }
@@ -1096,19 +1110,20 @@ static int attn_bwd_fused_smem(int N) {
 }
 
 template <typename T, bool X3 = false>
-static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, hipStream_t st) {
+static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, int q_rows, hipStream_t st) {
     using C = AttnCfg<T>;
     const int smem_bytes = 4 * C::TILE;
     static DeviceOnce once;
     ensure_dynamic_lds(once, &attn_fwd_kernel<T, X3>, smem_bytes);
     dim3 grid(((N + 127) / 128) * NHEADS * B);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, X3>), grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, B, N, scale);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, X3>), grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, B, N, scale,
+                       q_rows);
     return check_launch("maest_attn_fwd");
 }
 
 template <typename T, bool X3 = false>
 static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
-                           void* dqkv, int B, int N, float scale, hipStream_t st) {
+                           void* dqkv, int B, int N, float scale, int q_rows, hipStream_t st) {
     using C = AttnCfg<T>;
     if constexpr (sizeof(T) == 2) {
         // bf16 and at most 10 key blocks (the 10 s training shapes, N = 281 / 290): one fused pass per (batch, head)
@@ -1116,15 +1131,23 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
         if (nkw + 2 <= FB_MAXW && option(MAEST_OPT_ATTN_BWD) == 0) {     // DMA-fed form (+ the delta kernel)
             const int64_t items = (int64_t)B * N * NHEADS * 4;
             hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
-                               (const T*)out, (const T*)dout, delta, B, N);
+                               (const T*)out, (const T*)dout, delta, B, N, q_rows);
             static DeviceOnce once_g;
             ensure_dynamic_lds(once_g, &attn_bwd_fused2_kernel, attn_bwd_fused2_smem(32 * (FB_MAXW - 2)));
             const int waves = nkw + 2 < 8 ? 8 : nkw + 2;
             hipLaunchKernelGGL(attn_bwd_fused2_kernel, dim3(B * NHEADS), dim3(waves * 64), attn_bwd_fused2_smem(N), st,
                                (const bf16_t*)qkv, (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, B, N,
-                               scale);
+                               scale, q_rows);
             return check_launch("maest_attn_bwd(fused, dma)");
         }
+    }
+    if (q_rows < N) {
+        set_error("maest_attn_bwd_rows: q_rows = %d < N = %d is served by the fused bf16 kernel only (N <= %d, "
+                  "MAEST_OPT_ATTN_BWD = 0)", q_rows, N, 32 * (FB_MAXW - 2));
+        return MAEST_ERR_INVALID;
+    }
+    if constexpr (sizeof(T) == 2) {
+        const int nkw = (N + 31) / 32;
         if (nkw + 2 <= FB_MAXW && option(MAEST_OPT_ATTN_BWD) == 2) {     // register-fed form (delta fused)
             const int smem_f = attn_bwd_fused_smem(N);
             const int waves = nkw + 2 < 8 ? 8 : nkw + 2;      // the staging step wants 512 threads (one chunk each)
@@ -1143,7 +1166,7 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
     ensure_dynamic_lds(once_b, &attn_bwd_dq_kernel<T, X3>, smem_b);
     const int64_t items = (int64_t)B * N * NHEADS * 4;
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
-                       (const T*)out, (const T*)dout, delta, B, N);
+                       (const T*)out, (const T*)dout, delta, B, N, N);
     dim3 grid(((N + 127) / 128) * NHEADS * B);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, X3>), grid, dim3(256), smem_a, st, (const T*)qkv, (const T*)dout, lse,
                        (const float*)delta, (T*)dqkv, B, N, scale);
@@ -1156,25 +1179,38 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
 
 using namespace maest;
 
-extern "C" int maest_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int dtype, float scale,
-                              void* stream) {
+extern "C" int maest_attn_fwd_rows(const void* qkv, void* out, float* lse, int B, int N, int dtype, float scale,
+                                   int q_rows, void* stream) {
     MAEST_REQUIRE(qkv && out, "maest_attn_fwd: null pointer");
     MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_fwd: bad shape B=%d N=%d", B, N);
+    MAEST_REQUIRE(q_rows > 0 && q_rows <= N, "maest_attn_fwd_rows: q_rows = %d outside 1..N", q_rows);
     MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3, "maest_attn_fwd: bad dtype %d", dtype);
     MAEST_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "maest_attn_fwd: 16-byte alignment");
-    if (dtype == MAEST_F32X3) return attn_fwd_launch<float, true>(qkv, out, lse, B, N, scale, (hipStream_t)stream);
-    return dtype == MAEST_BF16 ? attn_fwd_launch<bf16_t>(qkv, out, lse, B, N, scale, (hipStream_t)stream)
-                               : attn_fwd_launch<float>(qkv, out, lse, B, N, scale, (hipStream_t)stream);
+    if (dtype == MAEST_F32X3) return attn_fwd_launch<float, true>(qkv, out, lse, B, N, scale, q_rows, (hipStream_t)stream);
+    return dtype == MAEST_BF16 ? attn_fwd_launch<bf16_t>(qkv, out, lse, B, N, scale, q_rows, (hipStream_t)stream)
+                               : attn_fwd_launch<float>(qkv, out, lse, B, N, scale, q_rows, (hipStream_t)stream);
+}
+
+extern "C" int maest_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int dtype, float scale,
+                              void* stream) {
+    return maest_attn_fwd_rows(qkv, out, lse, B, N, dtype, scale, N, stream);
+}
+
+extern "C" int maest_attn_bwd_rows(const void* qkv, const void* out, const void* dout, const float* lse,
+                                   float* delta, void* dqkv, int B, int N, int dtype, float scale, int q_rows,
+                                   void* stream) {
+    MAEST_REQUIRE(qkv && out && dout && lse && delta && dqkv, "maest_attn_bwd: null pointer");
+    MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_bwd: bad shape B=%d N=%d", B, N);
+    MAEST_REQUIRE(q_rows > 0 && q_rows <= N, "maest_attn_bwd_rows: q_rows = %d outside 1..N", q_rows);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3, "maest_attn_bwd: bad dtype %d", dtype);
+    if (dtype == MAEST_F32X3)
+        return attn_bwd_launch<float, true>(qkv, out, dout, lse, delta, dqkv, B, N, scale, q_rows, (hipStream_t)stream);
+    return dtype == MAEST_BF16
+               ? attn_bwd_launch<bf16_t>(qkv, out, dout, lse, delta, dqkv, B, N, scale, q_rows, (hipStream_t)stream)
+               : attn_bwd_launch<float>(qkv, out, dout, lse, delta, dqkv, B, N, scale, q_rows, (hipStream_t)stream);
 }
 
 extern "C" int maest_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                               float* delta, void* dqkv, int B, int N, int dtype, float scale, void* stream) {
-    MAEST_REQUIRE(qkv && out && dout && lse && delta && dqkv, "maest_attn_bwd: null pointer");
-    MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_bwd: bad shape B=%d N=%d", B, N);
-    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3, "maest_attn_bwd: bad dtype %d", dtype);
-    if (dtype == MAEST_F32X3)
-        return attn_bwd_launch<float, true>(qkv, out, dout, lse, delta, dqkv, B, N, scale, (hipStream_t)stream);
-    return dtype == MAEST_BF16
-               ? attn_bwd_launch<bf16_t>(qkv, out, dout, lse, delta, dqkv, B, N, scale, (hipStream_t)stream)
-               : attn_bwd_launch<float>(qkv, out, dout, lse, delta, dqkv, B, N, scale, (hipStream_t)stream);
+    return maest_attn_bwd_rows(qkv, out, dout, lse, delta, dqkv, B, N, dtype, scale, N, stream);
 }

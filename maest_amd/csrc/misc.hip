@@ -103,6 +103,40 @@ __global__ __launch_bounds__(256) void cast_weights_multi_kernel(const CastTable
     }
 }
 
+// ---- head-token rows of a [clips][n_tok][768] tensor <-> the compact [clips][n_head][768] form (the last block of the
+// network runs its proj / MLP only on the tokens the head reads: maest.py, _Engine).  One wave-sized row segment per
+// thread group: 768 columns = 96 x 16-byte (fp32: 192 x) chunks; grid-stride over (clip, token).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_head_rows_kernel(const T* __restrict__ src, int n_tok, int n_head,
+                                                               T* __restrict__ dst, int64_t n_chunks) {
+    constexpr int CPR = 768 * (int)sizeof(T) / 16;      // 16-byte chunks per row
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * 256) {
+        const int64_t r = c / CPR;
+        const int k = (int)(c - r * CPR);
+        const int64_t clip = r / n_head;
+        const int tok = (int)(r - clip * n_head);
+        const chunk16 v = *reinterpret_cast<const chunk16*>(reinterpret_cast<const char*>(src) +
+                                                            ((clip * n_tok + tok) * CPR + k) * 16);
+        *reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + c * 16) = v;
+    }
+}
+// dst rows [0, n_pad) of every clip: the n_head compact rows, then zeros (dst rows >= n_pad are left alone)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_head_rows_kernel(const T* __restrict__ src, int n_tok, int n_head, int n_pad,
+                                                                T* __restrict__ dst, int64_t n_chunks) {
+    constexpr int CPR = 768 * (int)sizeof(T) / 16;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * 256) {
+        const int64_t r = c / CPR;
+        const int k = (int)(c - r * CPR);
+        const int64_t clip = r / n_pad;
+        const int tok = (int)(r - clip * n_pad);
+        chunk16 v = {0u, 0u, 0u, 0u};
+        if (tok < n_head)
+            v = *reinterpret_cast<const chunk16*>(reinterpret_cast<const char*>(src) + ((clip * n_head + tok) * CPR + k) * 16);
+        *reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((clip * n_tok + tok) * CPR + k) * 16) = v;
+    }
+}
+
 // ---- out[c] += sum_r src[r][c]; grid (ceil(cols/256), row chunks of 512)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ src, int64_t ld, int rows, int cols,
@@ -367,4 +401,37 @@ extern "C" int maest_swa_update_multi(int n, float* const* avg, const float* con
         hipLaunchKernelGGL(swa_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab, inv_count);
     }
     return check_launch("maest_swa_update_multi");
+}
+
+extern "C" int maest_gather_head_rows(const void* src, int clips, int n_tok, int n_head, int dtype, void* dst, void* stream) {
+    MAEST_REQUIRE(src && dst, "maest_gather_head_rows: null pointer");
+    MAEST_REQUIRE(clips > 0 && n_head > 0 && n_tok >= n_head, "maest_gather_head_rows: bad shape clips=%d n_tok=%d n_head=%d",
+                  clips, n_tok, n_head);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_gather_head_rows: bad dtype %d", dtype);
+    const int64_t n = (int64_t)clips * n_head * 768 * (dtype == MAEST_BF16 ? 2 : 4) / 16;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (dtype == MAEST_BF16)
+        hipLaunchKernelGGL(gather_head_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)src, n_tok, n_head, (bf16_t*)dst, n);
+    else
+        hipLaunchKernelGGL(gather_head_rows_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)src, n_tok, n_head, (float*)dst, n);
+    return check_launch("maest_gather_head_rows");
+}
+
+extern "C" int maest_scatter_head_rows(const void* src, int clips, int n_tok, int n_head, int n_pad, int dtype, void* dst,
+                                       void* stream) {
+    MAEST_REQUIRE(src && dst, "maest_scatter_head_rows: null pointer");
+    MAEST_REQUIRE(clips > 0 && n_head > 0 && n_pad >= n_head && n_tok >= n_pad,
+                  "maest_scatter_head_rows: bad shape clips=%d n_tok=%d n_head=%d n_pad=%d", clips, n_tok, n_head, n_pad);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_scatter_head_rows: bad dtype %d", dtype);
+    const int64_t n = (int64_t)clips * n_pad * 768 * (dtype == MAEST_BF16 ? 2 : 4) / 16;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (dtype == MAEST_BF16)
+        hipLaunchKernelGGL(scatter_head_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)src, n_tok, n_head, n_pad, (bf16_t*)dst, n);
+    else
+        hipLaunchKernelGGL(scatter_head_rows_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)src, n_tok, n_head, n_pad, (float*)dst, n);
+    return check_launch("maest_scatter_head_rows");
 }

@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256, 5) void layernorm_bwd_kernel(const void* __res
                                                             const float* __restrict__ dres, float* __restrict__ dx_out,
                                                             void* __restrict__ dx_lp, int dx_lp_dtype,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows) {
+                                                            int rows, int n_tok, int n_head) {
+    // n_head > 0: `dres` is COMPACT -- [clips][n_head][768], the residual gradient of the first n_head tokens of every
+    // clip of n_tok tokens, zero for the others (the last block of the network, whose patch tokens feed nothing)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][768]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -170,8 +172,17 @@ __global__ __launch_bounds__(256, 5) void layernorm_bwd_kernel(const void* __res
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rs * (dv[4 * i + e] - s1 - xv[4 * i + e] * s2);
             if (dres != nullptr) {
-                const float4 r = *reinterpret_cast<const float4*>(dres + off);
-                o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                int64_t roff = off;
+                bool has = true;
+                if (n_head > 0) {
+                    const int clip = row / n_tok, tok = row - clip * n_tok;     // wave-uniform
+                    has = tok < n_head;
+                    roff = ((int64_t)clip * n_head + tok) * LN_COLS + i * 256 + lane * 4;
+                }
+                if (has) {
+                    const float4 r = *reinterpret_cast<const float4*>(dres + roff);
+                    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                }
             }
             if (dx_out != nullptr) *reinterpret_cast<float4*>(dx_out + off) = make_float4(o[0], o[1], o[2], o[3]);
             if (dx_lp != nullptr) store_row4(dx_lp, dx_lp_dtype, off, o[0], o[1], o[2], o[3]);
@@ -322,11 +333,13 @@ extern "C" int maest_add_layernorm_fwd(const float* x, const void* delta, int de
     return check_launch("maest_add_layernorm_fwd");
 }
 
-extern "C" int maest_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const float* x, int64_t ldx,
-                                   const float* gamma, const float* mean, const float* rstd, const float* dres,
-                                   float* dx_out, void* dx_lp, int dx_lp_dtype, float* dgamma, float* dbeta,
-                                   int rows, int cols, void* stream) {
+extern "C" int maest_layernorm_bwd_headres(const void* dy, int64_t lddy, int dy_dtype, const float* x, int64_t ldx,
+                                           const float* gamma, const float* mean, const float* rstd, const float* dres,
+                                           float* dx_out, void* dx_lp, int dx_lp_dtype, float* dgamma, float* dbeta,
+                                           int rows, int cols, int n_tok, int n_head, void* stream) {
     MAEST_REQUIRE(dy && x && gamma && mean && rstd && dgamma && dbeta, "maest_layernorm_bwd: null pointer");
+    MAEST_REQUIRE(n_head >= 0 && (n_head == 0 || (dres && n_tok >= n_head && rows % n_tok == 0)),
+                  "maest_layernorm_bwd_headres: bad token counts n_tok=%d n_head=%d rows=%d", n_tok, n_head, rows);
     MAEST_REQUIRE(cols == LN_COLS, "maest_layernorm_bwd: cols must be 768, got %d", cols);
     MAEST_REQUIRE(rows > 0, "maest_layernorm_bwd: rows=%d", rows);
     MAEST_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0, "maest_layernorm_bwd: leading dims must be multiples of 4");
@@ -335,8 +348,16 @@ extern "C" int maest_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, c
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 4 * 2 * LN_COLS * 4, (hipStream_t)stream, dy,
                        lddy, dy_dtype, x, ldx, gamma, mean, rstd, dres, dx_out, dx_lp, dx_lp_dtype, dgamma, dbeta,
-                       rows);
+                       rows, n_tok > 0 ? n_tok : 1, n_head);
     return check_launch("maest_layernorm_bwd");
+}
+
+extern "C" int maest_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const float* x, int64_t ldx,
+                                   const float* gamma, const float* mean, const float* rstd, const float* dres,
+                                   float* dx_out, void* dx_lp, int dx_lp_dtype, float* dgamma, float* dbeta,
+                                   int rows, int cols, void* stream) {
+    return maest_layernorm_bwd_headres(dy, lddy, dy_dtype, x, ldx, gamma, mean, rstd, dres, dx_out, dx_lp, dx_lp_dtype,
+                                       dgamma, dbeta, rows, cols, 1, 0, stream);
 }
 
 extern "C" int maest_head_pool_fwd(const float* x, int B, int N, const float* gamma, const float* beta, float eps,

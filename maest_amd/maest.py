@@ -45,6 +45,7 @@ from .melspectrogram import MelSpectrogram
 _logger = logging.getLogger("MAEST")
 
 EMBED_DIM = 768
+HEAD_TOKENS = 2          # cls, dist: the tokens the final norm + head read (models/maest.py:819-826)
 DEPTH = 12
 NUM_HEADS = 12
 PATCH = 16
@@ -194,6 +195,11 @@ class _Engine:
         self.m = model
         self.w = _Weights()
         self.overlap_wgrad = True
+        # The head reads two tokens (cls, dist) of the last block's output (models/maest.py:819-826), and everything in a
+        # block after the attention's key / value side is per token: the last block therefore evaluates its attention
+        # queries, proj, norm2 and MLP -- forward and backward -- only on those two rows of every clip.  Outputs and
+        # gradients are the ones of the full evaluation (the skipped rows feed nothing and receive no gradient).
+        self.head_tail = True
         self._weights_dirty = False
         self._side = {}
 
@@ -268,8 +274,17 @@ class _Engine:
                 r = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, dt, save_stats=save)
                 ln1, mean1, rstd1 = r if save else (r, None, None)
             qkv = ops.gemm_nt(ln1, W.get(blk.attn.qkv.weight, dt), blk.attn.qkv.bias, out_dtype=dt)
-            r = ops.attn_fwd(qkv, B, N, scale, save_lse=save)
+            tail = self.head_tail and stop_block < 0 and i == nblocks - 1
+            # (training needs the backward kernel that honours the restriction; otherwise the attention stays complete
+            # and only the per-token part of the block is restricted)
+            q_rows = HEAD_TOKENS if tail and (not save or ops.attn_bwd_rows_supported(dt, N)) else None
+            r = ops.attn_fwd(qkv, B, N, scale, save_lse=save, q_rows=q_rows)
             ao, lse = r if save else (r, None)
+            ao_full, x_full, Mb = ao, x, M
+            if tail:      # from here on the block lives on [B * 2, 768]
+                ao = ops.gather_head_rows(ao, B, N, HEAD_TOKENS)
+                x = ops.gather_head_rows(x, B, N, HEAD_TOKENS)
+                Mb = B * HEAD_TOKENS
             if i == stop_block and return_self_attention:
                 # Block.forward(..., return_self_attention=True) returns attn(norm1(x)) (maest.py:414-416)
                 a = ops.gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=torch.float32)
@@ -284,19 +299,20 @@ class _Engine:
                                  epi=ops.EPI_RESIDUAL, aux_in=x)
                 r = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save_stats=save)
                 ln2, mean2, rstd2 = r if save else (r, None, None)
-            h = torch.empty((M, blk.mlp.fc1.out_features), dtype=dt, device=x.device) if save else None
+            h = torch.empty((Mb, blk.mlp.fc1.out_features), dtype=dt, device=x.device) if save else None
             g = ops.gemm_nt(ln2, W.get(blk.mlp.fc1.weight, dt), blk.mlp.fc1.bias, out_dtype=dt, epi=ops.EPI_GELU,
                             aux_out=h)
             if save:
-                ctx["blocks"].append(dict(x=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse, x1=x1,
-                                          mean2=mean2, rstd2=rstd2, ln2=ln2, h=h, g=g))
+                ctx["blocks"].append(dict(x=x_full, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse, x1=x1,
+                                          mean2=mean2, rstd2=rstd2, ln2=ln2, h=h, g=g, tail=tail, ao_full=ao_full,
+                                          q_rows=q_rows))
             if split_add and i + 1 < nblocks:
                 pending = ops.gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=dt)
                 x = x1
             else:             # last block of this pass: nothing follows that could carry the add
                 x = ops.gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=torch.float32,
                                 epi=ops.EPI_RESIDUAL, aux_in=x1)
-        xb = x.reshape(B, N, EMBED_DIM)
+        xb = x.reshape(B, -1, EMBED_DIM)          # [B, N, 768], or [B, 2, 768] behind a restricted last block
         if stop_block >= 0:
             return ops.embed_pool(xb), None
         r = ops.head_pool_fwd(xb, m.norm.weight, m.norm.bias, m.norm.eps, save_stats=save)
@@ -422,7 +438,7 @@ class _Engine:
         done("head.0.bias", g_h0b)
         g_nw, g_nb = buf("norm.weight", EMBED_DIM), buf("norm.bias", EMBED_DIM)
         dx = ops.head_pool_bwd(d_cls, d_dist, dfeat, ctx["x_final"], m.norm.weight, ctx["fmean"], ctx["frstd"],
-                               g_nw, g_nb).reshape(M, EMBED_DIM)
+                               g_nw, g_nb).reshape(-1, EMBED_DIM)
         done("norm.weight", g_nw)
         done("norm.bias", g_nb)
         dx_lp = dx if dt == torch.float32 else ops.cast_weights(dx, dt)[0]
@@ -448,12 +464,17 @@ class _Engine:
             # proj (+ residual)
             wgrad(p + "attn.proj.weight", p + "attn.proj.bias", dx1_lp, s["ao"], EMBED_DIM, EMBED_DIM)
             dao = ops.gemm_nt(dx1_lp, W.get(blk.attn.proj.weight, dt, transposed=True), None, out_dtype=dt)
-            dqkv = ops.attn_bwd(s["qkv"], s["ao"], dao, s["lse"], B, N, blk.attn.scale)
+            if s["tail"]:
+                # back to the token-major layout: the head tokens' rows, zeros for the queries the kernel still visits
+                # (its first 32-row tile when it honours q_rows, every row otherwise)
+                dao = ops.scatter_head_rows(dao, B, N, HEAD_TOKENS, min(32, N) if s["q_rows"] else N)
+            dqkv = ops.attn_bwd(s["qkv"], s["ao_full"], dao, s["lse"], B, N, blk.attn.scale, q_rows=s["q_rows"])
             wgrad(p + "attn.qkv.weight", p + "attn.qkv.bias", dqkv, s["ln1"], 3 * EMBED_DIM, EMBED_DIM)
             dln1 = ops.gemm_nt(dqkv, W.get(blk.attn.qkv.weight, dt, transposed=True), None, out_dtype=dt)
             gw, gb = buf(p + "norm1.weight", EMBED_DIM), buf(p + "norm1.bias", EMBED_DIM)
             dx, dx_lp = ops.layernorm_bwd(dln1, s["x"], blk.norm1.weight, s["mean1"], s["rstd1"], dx1, gw, gb,
-                                          lp_dtype=None if dt == torch.float32 else dt)
+                                          lp_dtype=None if dt == torch.float32 else dt,
+                                          head_tokens=(N, HEAD_TOKENS) if s["tail"] else None)
             done(p + "norm1.weight", gw)
             done(p + "norm1.bias", gb)
             if dt == torch.float32:

@@ -227,36 +227,73 @@ def add_layernorm_fwd(x: torch.Tensor, delta: torch.Tensor, gamma, beta, eps: fl
     return (x_new, y, mean, rstd) if save_stats else (x_new, y)
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, lp_dtype=None, want_fp32=True):
-    """-> (dx fp32 or None, dx in lp_dtype or None); dgamma/dbeta accumulated in place."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, lp_dtype=None, want_fp32=True, head_tokens=None):
+    """-> (dx fp32 or None, dx in lp_dtype or None); dgamma/dbeta accumulated in place.
+    head_tokens = (n_tok, n_head): `dres` is compact, [rows / n_tok * n_head, 768] -- the residual gradient of the
+    first n_head tokens of every clip; the other tokens have none."""
     _chk(dy, x, gamma, mean, rstd, dres, dgamma, dbeta)
     rows, cols = x.shape
     dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device) if want_fp32 else None
     dx_lp = torch.empty((rows, cols), dtype=lp_dtype, device=x.device) if lp_dtype is not None else None
+    n_tok, n_head = head_tokens if head_tokens is not None else (1, 0)
+    if n_head:
+        assert dres is not None and dres.shape == (rows // n_tok * n_head, cols) and dres.is_contiguous()
     _timed_call("maest_layernorm_bwd", 0.0, _p(dy), dy.stride(0), DT[dy.dtype], _p(x), x.stride(0), _p(gamma), _p(mean),
-         _p(rstd), _p(dres), _p(dx), _p(dx_lp), DT[lp_dtype] if lp_dtype is not None else 0, _p(dgamma), _p(dbeta),
-         rows, cols, _s(x))
+                _p(rstd), _p(dres), _p(dx), _p(dx_lp), DT[lp_dtype] if lp_dtype is not None else 0, _p(dgamma), _p(dbeta),
+                rows, cols, n_tok, n_head, _s(x), _entry="maest_layernorm_bwd_headres")
     return dx, dx_lp
 
 
-def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False):
+def _attn_flops(B, N, q_rows, per_pair):
+    nq = N if q_rows is None or q_rows >= N else min(N, -(-q_rows // 32) * 32)
+    return per_pair * B * HEADS * nq * N * HEAD_DIM
+
+
+def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False, q_rows=None):
+    """q_rows: only the first q_rows queries of every clip are wanted (rows beyond the 32-row tile that holds them are
+    left unwritten in `out` / `lse`)."""
     _chk(qkv)
     assert qkv.shape == (B * N, 3 * EMBED)
     out = torch.empty((B * N, EMBED), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device) if save_lse else None
-    _timed_call("maest_attn_fwd", 4.0 * B * HEADS * N * N * HEAD_DIM, _p(qkv), _p(out), _p(lse), B, N,
-                _mm_code(qkv.dtype), scale, _s(qkv))
+    _timed_call("maest_attn_fwd", _attn_flops(B, N, q_rows, 4.0), _p(qkv), _p(out), _p(lse), B, N,
+                _mm_code(qkv.dtype), scale, N if q_rows is None else q_rows, _s(qkv), _entry="maest_attn_fwd_rows")
     return (out, lse) if save_lse else out
 
 
-def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float):
+def attn_bwd_rows_supported(dtype, N: int) -> bool:
+    """Whether maest_attn_bwd_rows serves q_rows < N for this shape (the fused bf16 kernel: include/maest_hip.h)."""
+    return dtype == torch.bfloat16 and -(-N // 32) + 2 <= 12 and get_option("attn_bwd") == 0
+
+
+def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float, q_rows=None):
     _chk(qkv, out, dout, lse)
     assert dout.dtype == qkv.dtype and out.dtype == qkv.dtype
     delta = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device)
     dqkv = torch.empty_like(qkv)
-    _timed_call("maest_attn_bwd", 10.0 * B * HEADS * N * N * HEAD_DIM, _p(qkv), _p(out), _p(dout), _p(lse),
-                _p(delta), _p(dqkv), B, N, _mm_code(qkv.dtype), scale, _s(qkv))
+    _timed_call("maest_attn_bwd", _attn_flops(B, N, q_rows, 10.0), _p(qkv), _p(out), _p(dout), _p(lse),
+                _p(delta), _p(dqkv), B, N, _mm_code(qkv.dtype), scale, N if q_rows is None else q_rows, _s(qkv),
+                _entry="maest_attn_bwd_rows")
     return dqkv
+
+
+def gather_head_rows(x: torch.Tensor, clips: int, n_tok: int, n_head: int) -> torch.Tensor:
+    """[clips * n_tok, 768] -> the first n_head token rows of every clip, compact [clips * n_head, 768]."""
+    _chk(x)
+    assert x.shape == (clips * n_tok, EMBED) and x.is_contiguous() and x.dtype in DT
+    out = torch.empty((clips * n_head, EMBED), dtype=x.dtype, device=x.device)
+    call("maest_gather_head_rows", _p(x), clips, n_tok, n_head, DT[x.dtype], _p(out), _s(x))
+    return out
+
+
+def scatter_head_rows(xc: torch.Tensor, clips: int, n_tok: int, n_head: int, n_pad: int) -> torch.Tensor:
+    """compact [clips * n_head, 768] -> a [clips * n_tok, 768] buffer whose rows [0, n_pad) of every clip hold the compact
+    rows followed by zeros; the other rows are UNINITIALISED (never read by maest_attn_bwd_rows)."""
+    _chk(xc)
+    assert xc.shape == (clips * n_head, EMBED) and xc.is_contiguous()
+    out = torch.empty((clips * n_tok, EMBED), dtype=xc.dtype, device=xc.device)
+    call("maest_scatter_head_rows", _p(xc), clips, n_tok, n_head, n_pad, DT[xc.dtype], _p(out), _s(xc))
+    return out
 
 
 def patch_im2col(x: torch.Tensor, tok_ft: torch.Tensor, dtype, perm=None, lam=None, t_stripes=None, f_stripes=None):

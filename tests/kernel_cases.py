@@ -155,6 +155,23 @@ def case_layernorm(dev, dtype, rows):
     close(dx_lp, xr.grad + dres, *( (1e-4, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)), "layernorm dx_lp")
     close(dg, gr.grad, 1e-4, 1e-4 * math.sqrt(rows), "layernorm dgamma")
     close(db, br.grad, 1e-4, 1e-4 * math.sqrt(rows), "layernorm dbeta")
+    # compact residual gradient (the first 2 tokens of every clip of n_tok tokens; zero for the others): bit for bit
+    # the dense call on the scattered tensor
+    for n_tok in (1, 3, 11):
+        if rows % n_tok or n_tok < 2 and rows < 2:
+            continue
+        n_head = min(2, n_tok)
+        clips = rows // n_tok
+        dres_c = rnd((clips * n_head, 768), 13)
+        dense = torch.zeros(clips, n_tok, 768)
+        dense[:, :n_head] = dres_c.reshape(clips, n_head, 768)
+        dg1, db1 = torch.zeros(768, device=dev), torch.zeros(768, device=dev)
+        want, want_lp = ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), mean, rstd, dense.reshape(rows, 768).to(dev),
+                                          dg1, db1, lp_dtype=dtype)
+        dg2, db2 = torch.zeros(768, device=dev), torch.zeros(768, device=dev)
+        got, got_lp = ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), mean, rstd, dres_c.to(dev), dg2, db2,
+                                        lp_dtype=dtype, head_tokens=(n_tok, n_head))
+        assert torch.equal(got, want) and torch.equal(got_lp, want_lp), f"compact dres, n_tok={n_tok}"
 
 
 # --------------------------------------------------------------------------------------- attention
@@ -200,6 +217,48 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2):
         with ops.options(attn_bwd=2):     # the fused form with register-fed tiles (delta computed in flight)
             dq3 = ops.attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
         close(dq3, g, rt, at, "attention backward (fused, register-fed)")
+
+
+def case_attention_head_rows(dev, dtype, B, N, seed=25):
+    """The last block's attention: only the first two queries of every clip are wanted.  Forward: the rows the
+    restricted kernel writes (the 32-row tile holding them) equal the complete kernel's bit for bit.  Backward (fused bf16
+    kernel): equal -- to bf16 rounding of the same sums -- to the complete backward fed a dO that is zero beyond row 2, with
+    dQ = 0 for every other query; shapes the fused kernel does not serve are refused loudly."""
+    from maest_amd._lib import MaestHipError
+    qkv = rnd((B * N, 2304), seed, 1.0).to(dtype).to(dev)
+    scale = 0.125
+    full, lse_full = ops.attn_fwd(qkv, B, N, scale, save_lse=True)
+    part, lse_part = ops.attn_fwd(qkv, B, N, scale, save_lse=True, q_rows=2)
+    nv = min(32, N)
+    f3, p3 = full.reshape(B, N, 768), part.reshape(B, N, 768)
+    assert torch.equal(p3[:, :nv], f3[:, :nv]), "restricted forward differs on the rows it computes"
+    assert torch.equal(lse_part[:, :, :nv], lse_full[:, :, :nv])
+    # gather / scatter of the head tokens' rows
+    comp = ops.gather_head_rows(full, B, N, 2)
+    assert torch.equal(comp.reshape(B, 2, 768), f3[:, :2])
+    back = ops.scatter_head_rows(comp, B, N, 2, nv).reshape(B, N, 768)
+    assert torch.equal(back[:, :2], f3[:, :2]) and not back[:, 2:nv].any()
+    xf = rnd((B * N, 768), seed + 3).to(dev)
+    assert torch.equal(ops.gather_head_rows(xf, B, N, 2).reshape(B, 2, 768), xf.reshape(B, N, 768)[:, :2])
+    dout_c = rnd((B * 2, 768), seed + 1).to(dtype).to(dev)
+    dense = ops.scatter_head_rows(dout_c, B, N, 2, N)          # zero everywhere else
+    if ops.attn_bwd_rows_supported(dtype, N):
+        want = ops.attn_bwd(qkv, full, dense, lse_full, B, N, scale)
+        got = ops.attn_bwd(qkv, part, ops.scatter_head_rows(dout_c, B, N, 2, nv), lse_part, B, N, scale, q_rows=2)
+        close(got[:, 768:], want[:, 768:].float().cpu(), 2e-2, 2e-2, "restricted attention backward dK, dV")
+        g3, w3 = got.reshape(B, N, 2304), want.reshape(B, N, 2304)
+        close(g3[:, :2, :768], w3[:, :2, :768].float().cpu(), 2e-2, 2e-2, "restricted attention backward dQ")
+        assert not g3[:, 2:, :768].any(), "queries without gradient must get dQ = 0"
+        with ops.options(attn_bwd=1):
+            two = ops.attn_bwd(qkv, full, dense, lse_full, B, N, scale)
+        close(got[:, 768:], two[:, 768:].float().cpu(), 2e-2, 2e-2, "restricted fused vs complete two-kernel backward")
+    else:
+        try:
+            ops.attn_bwd(qkv, full, dense, lse_full, B, N, scale, q_rows=2)
+        except MaestHipError as e:
+            assert "q_rows" in str(e)
+        else:
+            raise AssertionError("restricted backward must be refused on shapes the fused kernel does not serve")
 
 
 # ----------------------------------------------------------------------------- patch embed pieces

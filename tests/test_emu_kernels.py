@@ -118,3 +118,8 @@ def test_emu_augment_mel(emu):
 
 def test_emu_swa(emu):
     KC.case_swa(emu)
+
+
+@pytest.mark.parametrize("dtype,B,N", [(torch.bfloat16, 2, 75), (torch.bfloat16, 1, 20), (torch.float32, 1, 40)])
+def test_attention_restricted_to_the_head_tokens(emu, dtype, B, N):
+    KC.case_attention_head_rows(emu, dtype, B, N)

@@ -47,8 +47,9 @@ def _model(precision, **kw):
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_inference_batch256_rows_are_independent_and_match_the_oracle(precision, gemm_options):
     # bit-exactness needs the SAME GEMM kernel for the 4-clip and the 256-clip batch (below 8192 rows the dispatcher
-    # would otherwise pick the 128x128 kernel, whose accumulation order differs in the last bits)
-    gemm_options(gemm_min_m=512)
+    # would otherwise pick the 128x128 kernel, whose accumulation order differs in the last bits): 256-tile kernels from
+    # 1024 rows (4 x 560 tokens) up, the 128x128 kernel for the head-token rows of the last block (8 and 512 rows)
+    gemm_options(gemm_min_m=1024)
     net, sd = _model(precision)
     net.eval()
     x = (0.2 * randn((B, 96, T), 11) + 0.4).to(DEV)          # z-normed log-mel scale

@@ -117,3 +117,8 @@ def test_augment_mel():
 
 def test_swa():
     KC.case_swa(DEV)
+
+
+@pytest.mark.parametrize("dtype,B,N", [(torch.bfloat16, 3, 290), (torch.bfloat16, 2, 281), (torch.bfloat16, 2, 560), (torch.float32, 2, 290), (torch.bfloat16, 1, 29)])
+def test_attention_restricted_to_the_head_tokens(dtype, B, N):
+    KC.case_attention_head_rows(DEV, dtype, B, N)

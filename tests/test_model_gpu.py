@@ -811,3 +811,48 @@ def test_teacher_student_validation_step():
     sep = build("discogs-maest-10s-pw-129e", 625, n_classes=20, precision="fp32", distilled_type="separated").eval()
     with pytest.raises(ValueError):
         TeacherStudentModule(net=sep).validation_step((x.to(DEV), None, y.to(DEV), yt.to(DEV)), 0)
+
+
+@pytest.mark.parametrize("precision,patchout", [("fp32", 30), ("bf16", 30), ("fp32", 0), ("bf16x3", 12)])
+def test_last_block_on_head_tokens_equals_the_complete_evaluation(precision, patchout):
+    """_Engine.head_tail: the last block evaluates its attention queries, proj, norm2 and MLP only for the two tokens the
+    head reads.  Against the same model with the restriction off, same draws: logits, features, loss and EVERY parameter
+    gradient agree to rounding (the restricted rows go through the 128x128 GEMM kernel instead of the 256-tile one; fp32:
+    1e-5 of the gradient's scale; bf16: the usual 2e-2), in training and in eval mode.  (Both are pinned to the reference
+    separately by the golden fixtures, which run with the restriction on.)  patchout 0 -> N = 560: the complete attention
+    backward with a zero-padded dO; patchout 30 -> the fused kernel's q_rows form in bf16."""
+    B, T = 6, 626
+    x = randn((B, 1, 96, T), 910).to(DEV)
+    rng = np.random.Generator(np.random.PCG64(911))
+    y = torch.from_numpy((rng.random((B, 400)) < 0.01).astype(np.float32)).to(DEV)
+    perm = torch.from_numpy(rng.permutation(B))
+    lam = torch.from_numpy(np.maximum(b := rng.beta(0.3, 0.3, B).astype(np.float32), 1 - b))
+    Tp = (T - 16) // 10 + 1
+    keep = torch.from_numpy(np.sort(rng.permutation(Tp)[: Tp - patchout]))
+    res = {}
+    for tail in (False, True):
+        net = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=patchout, precision=precision)
+        net.load_state_dict(O.make_state_dict(625, seed=77), strict=True)
+        net = net.to(DEV).train()
+        net._engine.head_tail = tail
+        mod = Module(net=net, mixup_alpha=0.3)
+        loss = mod.training_step((x, None, y), 0, _mixup=(perm, lam), _patchout=(0, keep))
+        loss.backward()
+        grads = {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None}
+        net.eval()
+        with torch.no_grad():
+            logits, feat = net(x)
+        res[tail] = (loss.item(), grads, logits.float().clone(), feat.float().clone())
+        del net, mod
+    (l0, g0, z0, f0), (l1, g1, z1, f1) = res[False], res[True]
+    tol = 1e-5 if precision != "bf16" else 2e-2
+    assert abs(l1 - l0) <= (1e-6 if precision != "bf16" else 3e-4) * abs(l0), (l0, l1)
+    assert rel_err(z1, z0) < tol and rel_err(f1, f0) < tol
+    assert set(g0) == set(g1)
+    worst = ("", 0.0)
+    for n in g0:
+        e = (g1[n] - g0[n]).norm().item() / max(g0[n].norm().item(), 1e-30)
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        assert e < tol, f"{n}: restricted last block changes the gradient by {e:.2e} (relative L2)"
+    print(f"head-token last block vs complete ({precision}, patchout {patchout}): loss {l1:.7f} vs {l0:.7f}, worst gradient "
+          f"deviation {worst[1]:.2e} at {worst[0]}")
