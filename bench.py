@@ -46,7 +46,7 @@ def flops_per_clip_fwd_not_executed(N, attn_rows):
     return 2 * (N - 2) * 768 * (768 + 3072 + 3072) + 4 * (N - attn_rows) * N * 768
 
 
-PMC_TRAFFIC_FILE = "profiles/r02b_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r02c_pmc_traffic.json"
 
 
 def pmc_traffic():
@@ -292,7 +292,7 @@ def main():
         # stream, an event pair around one launch would also count the time it shares the CUs with another
         net._engine.overlap_wgrad = False
         net.enable_hip_graph(False)
-        with ops.KernelTimer(kinds={"maest_gemm_nt", "maest_gemm_tn", "maest_attn_fwd", "maest_attn_bwd",
+        with ops.KernelTimer(kinds={"maest_gemm_nt", "maest_gemm_nt_small", "maest_gemm_tn", "maest_attn_fwd", "maest_attn_bwd",
                                     "maest_layernorm_fwd", "maest_layernorm_bwd", "maest_logmel"}) as timer:
             for _ in range(args.steps):
                 step()
@@ -348,7 +348,7 @@ def main():
                 # bf16x3 spends 3 bf16 MFMAs per product: its algorithmic rate is priced against a third of the bf16 peak
                 peak = {"bf16": PEAK_BF16_TFLOPS, "bf16x3": round(PEAK_BF16_TFLOPS / 3, 1)}.get(args.precision, 157.3)
                 traffic, traffic_source = pmc_traffic()
-                out["roofline"] = {"bound": "mfma", "kernel": ("maest_gemm_nt (gemm_nt256w_kernel<bf16>; gemm_nt_kernel<bf16> for the small head GEMMs)"
+                out["roofline"] = {"bound": "mfma", "kernel": ("maest_gemm_nt (gemm_nt256w_kernel<bf16>: every token-major GEMM of the blocks; the head and the last block's head-token rows, M <= 512, run gemm_nt_kernel and are listed as maest_gemm_nt_small)"
                                               if args.precision == "bf16" else
                                               ("maest_gemm_nt (gemm_nt256w_kernel<float, X3>: 3 bf16 MFMAs per fp32 product)"
                                                if args.precision == "bf16x3" else "maest_gemm_nt (fp32 MFMA)")),
@@ -370,11 +370,13 @@ def main():
             # QK^T + PV + output projection), its launches picked out of the timed records by their
             # algorithmic work (the MLP GEMMs have 3072-wide shapes)
             Mtok = B * N
-            set_work = {2.0 * Mtok * 2304 * 768, 2.0 * Mtok * 768 * 768}
+            set_work = {2.0 * Mtok * 2304 * 768, 2.0 * Mtok * 768 * 768, 2.0 * (2 * B) * 768 * 768}
             set_ms = sum(e0.elapsed_time(e1) for name, e0, e1, w in timer.records
                          if name in ("maest_attn_fwd", "maest_attn_bwd")
-                         or (name in ("maest_gemm_nt", "maest_gemm_tn") and w in set_work)) / args.steps
+                         or (name in ("maest_gemm_nt", "maest_gemm_nt_small", "maest_gemm_tn") and w in set_work)) / args.steps
             set_flops = (3 if train else 1) * B * 12 * (2.0 * N * 768 * 2304 + 4.0 * N * N * 768 + 2.0 * N * 768 * 768)
+            if tail_on:       # executed FLOPs: the last block's out-projection and attention queries cover the head tokens only
+                set_flops -= (3 if train else 1) * B * (2.0 * (N - 2) * 768 * 768 + 4.0 * (N - attn_rows) * N * 768)
             if set_ms > 0:
                 out["attention_set"] = {"what": "12 x (QKV proj + QK^T + PV + out proj)" + (", fwd+bwd" if train else ", fwd"),
                                         "ms_per_step": round(set_ms, 3), "tflops": round(set_flops / set_ms / 1e9, 1),

@@ -128,8 +128,11 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
         if t is not None and not (t.is_cuda or _lib.host_emulation()):
             raise _lib.MaestHipError("maest_amd kernels need tensors on a HIP device; there is no CPU fallback")
     _chk(bias)
-    _timed_call("maest_gemm_nt", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), _mm_code(a.dtype), _p(out),
-                out.stride(0), DT[out.dtype], M, N, K, _p(bias), epi, _p(aux_in), _p(aux_out), ld_aux, split_k, _s(a))
+    # timing bucket: the token-major GEMMs of the blocks apart from the few small ones (head, patch-embed remainder, the
+    # last block's head-token rows), which run the 128x128 kernel and would blur the dominant kernel's figures
+    _timed_call("maest_gemm_nt" if M >= 4096 else "maest_gemm_nt_small", 2.0 * M * N * K, _p(a), a.stride(0), _p(b),
+                b.stride(0), _mm_code(a.dtype), _p(out), out.stride(0), DT[out.dtype], M, N, K, _p(bias), epi, _p(aux_in),
+                _p(aux_out), ld_aux, split_k, _s(a), _entry="maest_gemm_nt")
     return out
 
 

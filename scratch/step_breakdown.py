@@ -17,7 +17,7 @@ def hook(name, work, *args, _entry=None):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); _lib.call(_entry or name, *args); e1.record()
     tag = name
-    if name == "maest_gemm_nt":
+    if name in ("maest_gemm_nt", "maest_gemm_nt_small"):
         tag = f"nt M={args[8]} N={args[9]} K={args[10]} epi={args[12]} out={args[7]} aux={'y' if args[14] is not None else 'n'}"
     elif name == "maest_gemm_tn":
         tag = f"tn M={args[7]} N={args[8]} K={args[9]} sk={args[11]}"
