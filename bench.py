@@ -283,6 +283,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the same K steps with the last block evaluated on every token (N = 1 only; reported next to `value` so that the
+    # effect of restricting it to the head's tokens is on the line itself)
+    complete = None
+    if world == 1 and getattr(net._engine, "head_tail", False) and not args.no_cpu_baseline and not args.hip_graph:
+        net._engine.head_tail = False
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        complete = time.perf_counter() - t1
+        net._engine.head_tail = True
+
     # ---- roofline pass (rank 0, N = 1): the same K steps again with HIP events around every launch of the
     # GEMM / attention kernels on the launch stream.  Kept out of the timed region above because ~400 event
     # records per step cost ~10 % of a step on the host; kernel durations themselves are unaffected.
@@ -337,6 +352,10 @@ def main():
             "model_mfma_frac": round((step_flops - skipped) / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "executed_flop_fraction": round(1.0 - skipped / step_flops, 4),
         }
+        if complete is not None:
+            out["complete_last_block"] = {"value": round(B * args.steps / complete, 2), "unit": "clips/s",
+                                          "ms_per_step": round(complete / args.steps * 1e3, 3),
+                                          "what": "the same K steps with the last block evaluated on every token"}
         out["config"]["last_block"] = ("attention queries, proj, norm2 and MLP evaluated for the two tokens the head reads "
                                        "(cls, dist) only, forward and backward; logits, features and all gradients equal "
                                        "the complete evaluation's" if tail_on else "complete")
