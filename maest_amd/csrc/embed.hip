@@ -155,8 +155,8 @@ __global__ __launch_bounds__(192) void token_assemble_kernel(const float* __rest
 // grid (Ntok, batch slices): thread = 4 channels (16-byte accesses); each workgroup walks ITS slice of the batch with the
 // loads of four clips in flight, and adds its partial sums to the (pre-zeroed) parameter gradients with atomics -- the
 // time / frequency tables are reduced over tokens that way in any case.  (One workgroup per token walking all 256 clips
-// with 4-byte loads was latency-bound: 222 us for 341 MB.)
-constexpr int TAB_SLICES = 8;
+// with 4-byte loads was latency-bound: 222 us for 341 MB; two slices with 16-byte accesses: 154 us.)
+constexpr int TAB_SLICES = 2;      // swept 1..32 at B = 256: 189 / 154 / 177 / 282 / 483 / 912 us -- the atomics of every extra slice cost 28 us
 __global__ __launch_bounds__(192) void token_assemble_bwd_kernel(const float* __restrict__ dx0, int B, int Fg, int P,
                                                                  int Tt, int toffset,
                                                                  const int32_t* __restrict__ tok_ft,
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(192) void token_assemble_bwd_kernel(const float* __
     const int Ntok = 2 + P;
     const int n = blockIdx.x;
     const int c = threadIdx.x * 4;
-    const int per = (B + TAB_SLICES - 1) / TAB_SLICES;
+    const int per = (B + (int)gridDim.y - 1) / (int)gridDim.y;
     const int b0 = blockIdx.y * per;
     const int b1 = b0 + per < B ? b0 + per : B;
     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
