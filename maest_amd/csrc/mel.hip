@@ -6,7 +6,7 @@
 //
 // Algorithmically HBM-bound (0.88 MB / 10 s clip in+out vs ~7 MFLOP of FFT); as written it is instruction-issue bound
 // (~800 VALU / LDS instructions per frame and wave: 0.25 ms for 256 clips = 0.11 of the HBM roofline, 1.0 M clips/s --
-// 250x the rate the ViT consumes them at).  A workgroup owns 64 consecutive frames
+// 200x the rate the training step consumes them at).  A workgroup owns 64 consecutive frames
 // of one clip so that the [96, T] output is written as 256-byte runs along T; each of its 4 waves
 // transforms 16 frames, one at a time (the next frame's samples in flight), entirely in LDS and without block barriers: the 512 real samples are packed as 256
 // complex points, transformed by 4 radix-4 DIF stages (one butterfly per lane per stage), unpacked
