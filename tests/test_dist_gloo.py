@@ -79,3 +79,55 @@ def test_grad_reducer_incomplete_bucket_is_an_error():
     red.on_grad("norm.weight")
     with pytest.raises(RuntimeError, match="never completed"):
         red.finish()
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import numpy as np
+    from sklearn import metrics as skm
+    from maest_amd.dist import init_from_env
+    from maest_amd.module import Module
+    init_from_env(backend="gloo")
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+    mod = Module(net=Tiny(), distributed_mode=True)
+    # what two validation_steps on each rank would have collected (scores and labels differ per rank)
+    all_y, all_s, all_l = [], [], []
+    for r in range(world):
+        rng = np.random.Generator(np.random.PCG64(50 + r))
+        ys = [(rng.random((6, 7)) < 0.4).astype(np.float32) for _ in range(2)]
+        for y in ys:
+            y[0], y[1] = 1.0, 0.0
+        ss = [rng.random((6, 7)).astype(np.float32) for _ in range(2)]
+        ls = [float(rng.random()) for _ in range(2)]
+        all_y.append(np.concatenate(ys)); all_s.append(np.concatenate(ss)); all_l.append(np.mean(ls))
+        if r == rank:
+            for y, s, l in zip(ys, ss, ls):
+                mod.validation_outputs.append({"y": torch.from_numpy(y), "y_hat": torch.from_numpy(s), "loss": torch.tensor(l)})
+    mod.on_validation_epoch_end()
+    y, s = np.concatenate(all_y), np.concatenate(all_s)
+    assert mod.validation_outputs == []
+    assert abs(mod.logged["val_ap"] - skm.average_precision_score(y, s, average="macro")) < 1e-6
+    assert abs(mod.logged["val_roc"] - skm.roc_auc_score(y, s, average="macro")) < 1e-6
+    assert abs(mod.logged["val_loss"] - np.mean(all_l)) < 1e-6
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_validation_epoch_end_gathers_over_ranks_gloo():
+    """models/module.py:156-202 in distributed mode: labels, scores and losses of every rank are gathered before the
+    macro AP / ROC-AUC (every rank logs the metrics of the whole validation set)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, "worker failed"
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
