@@ -253,40 +253,67 @@ __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    // grid-stride over the 2 B rows, a wave per row; dgamma / dbeta partials stay in registers across a wave's rows and
+    // leave as ONE atomic per column and workgroup (an atomic per element and row -- 512-way contention on each of the
+    // 1536 addresses at B = 256 -- took 99 us)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][768]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= B * 2) return;
-    const int b = item >> 1, tok = item & 1;
-    const float* dsrc = tok == 0 ? d_cls : d_dist;
-    float xv[12], dv[12];
-    ln_load_row(x + ((int64_t)b * N + tok) * LN_COLS, lane, xv);
-    const float mu = mean[item], rs = rstd[item];
-    float s1 = 0.0f, s2 = 0.0f;
+    float ag[12], ab[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { ag[i] = 0.0f; ab[i] = 0.0f; }
+    for (int item = blockIdx.x * 4 + wave; item < B * 2; item += gridDim.x * 4) {
+        const int b = item >> 1, tok = item & 1;
+        const float* dsrc = tok == 0 ? d_cls : d_dist;
+        float xv[12], dv[12];
+        ln_load_row(x + ((int64_t)b * N + tok) * LN_COLS, lane, xv);
+        const float mu = mean[item], rs = rstd[item];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < LN_VEC; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = i * 256 + lane * 4 + e;
+                float d = 0.0f;
+                if (dsrc != nullptr) d += dsrc[(int64_t)b * LN_COLS + c];
+                if (d_feat != nullptr) d += 0.5f * d_feat[(int64_t)b * LN_COLS + c];
+                const float xh = (xv[4 * i + e] - mu) * rs;
+                const float g = d * gamma[c];
+                s1 += g;
+                s2 += g * xh;
+                ag[4 * i + e] += d * xh;
+                ab[4 * i + e] += d;
+                xv[4 * i + e] = xh;
+                dv[4 * i + e] = g;
+            }
+        s1 = wave_sum(s1) * (1.0f / LN_COLS);
+        s2 = wave_sum(s2) * (1.0f / LN_COLS);
+#pragma unroll
+        for (int i = 0; i < LN_VEC; ++i) {
+            const int64_t off = ((int64_t)b * N + tok) * LN_COLS + i * 256 + lane * 4;
+            *reinterpret_cast<float4*>(dx + off) =
+                make_float4(rs * (dv[4 * i] - s1 - xv[4 * i] * s2), rs * (dv[4 * i + 1] - s1 - xv[4 * i + 1] * s2),
+                            rs * (dv[4 * i + 2] - s1 - xv[4 * i + 2] * s2), rs * (dv[4 * i + 3] - s1 - xv[4 * i + 3] * s2));
+        }
+    }
 #pragma unroll
     for (int i = 0; i < LN_VEC; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = i * 256 + lane * 4 + e;
-            float d = 0.0f;
-            if (dsrc != nullptr) d += dsrc[(int64_t)b * LN_COLS + c];
-            if (d_feat != nullptr) d += 0.5f * d_feat[(int64_t)b * LN_COLS + c];
-            const float xh = (xv[4 * i + e] - mu) * rs;
-            const float g = d * gamma[c];
-            s1 += g;
-            s2 += g * xh;
-            unsafeAtomicAdd(dgamma + c, d * xh);
-            unsafeAtomicAdd(dbeta + c, d);
-            xv[4 * i + e] = xh;
-            dv[4 * i + e] = g;
+            red[(wave * 2 + 0) * LN_COLS + c] = ag[4 * i + e];
+            red[(wave * 2 + 1) * LN_COLS + c] = ab[4 * i + e];
         }
-    s1 = wave_sum(s1) * (1.0f / LN_COLS);
-    s2 = wave_sum(s2) * (1.0f / LN_COLS);
+    __syncthreads();
+    for (int c = threadIdx.x; c < LN_COLS; c += 256) {
+        float sg = 0.0f, sb = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_VEC; ++i) {
-        const int64_t off = ((int64_t)b * N + tok) * LN_COLS + i * 256 + lane * 4;
-        *reinterpret_cast<float4*>(dx + off) =
-            make_float4(rs * (dv[4 * i] - s1 - xv[4 * i] * s2), rs * (dv[4 * i + 1] - s1 - xv[4 * i + 1] * s2),
-                        rs * (dv[4 * i + 2] - s1 - xv[4 * i + 2] * s2), rs * (dv[4 * i + 3] - s1 - xv[4 * i + 3] * s2));
+        for (int w = 0; w < 4; ++w) {
+            sg += red[(w * 2 + 0) * LN_COLS + c];
+            sb += red[(w * 2 + 1) * LN_COLS + c];
+        }
+        unsafeAtomicAdd(dgamma + c, sg);
+        unsafeAtomicAdd(dbeta + c, sb);
     }
 }
 
@@ -381,7 +408,8 @@ extern "C" int maest_head_pool_bwd(const float* d_cls, const float* d_dist, cons
         set_error("maest_head_pool_bwd: hipMemsetAsync failed");
         return MAEST_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(head_pool_bwd_kernel, dim3((2 * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_cls, d_dist,
+    const int blocks = (2 * B + 3) / 4 < 32 ? (2 * B + 3) / 4 : 32;
+    hipLaunchKernelGGL(head_pool_bwd_kernel, dim3(blocks), dim3(256), 4 * 2 * LN_COLS * 4, (hipStream_t)stream, d_cls, d_dist,
                        d_feat, x, B, N, gamma, mean, rstd, dx, dgamma, dbeta);
     return check_launch("maest_head_pool_bwd");
 }
