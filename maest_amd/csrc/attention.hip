@@ -227,7 +227,7 @@ __device__ __forceinline__ void store_dT(const f32x16_t (&acc)[2], T* row_ptr, i
 
 // =================================================================================== forward
 template <typename T, bool X3 = false>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(const T* __restrict__ qkv,
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(const T* __restrict__ qkv,
                                                                                 T* __restrict__ out,
                                                                                 float* __restrict__ lse, int B, int N,
                                                                                 float scale, int q_rows) {
