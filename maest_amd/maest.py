@@ -775,7 +775,9 @@ class MAEST(nn.Module):
             if tok_ft.shape[0] < 1:
                 raise Exception("patchout removed every patch token")
             if x3.is_cuda and not tok_ft.is_cuda:     # training: a fresh list every step; no stream-draining copy
-                tok_ft = tok_ft.contiguous().pin_memory().to(x3.device, non_blocking=True)
+                # the pinned staging tensor stays referenced until the next step's replaces it: the copy is asynchronous
+                self._tok_staging = tok_ft.contiguous().pin_memory()
+                tok_ft = self._tok_staging.to(x3.device, non_blocking=True)
             else:
                 tok_ft = tok_ft.to(x3.device)
             if not self.training and _patchout is None:

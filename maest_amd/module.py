@@ -35,6 +35,9 @@ class _BCEWithLogitsFn(torch.autograd.Function):
         return ops.scale_dev_(dz, g.to(torch.float32).reshape(1).contiguous()), None, None, None, None
 
 
+_STAGING = []      # the last few pinned staging tensors of the per-step host draws
+
+
 def _mix_to_device(mix, device):
     """(perm, lam) host draws -> int32 / fp32 device tensors through pinned memory, without a stream-draining
     synchronous copy; done ONCE per step (the forward and the loss both consume them)."""
@@ -48,7 +51,10 @@ def _mix_to_device(mix, device):
         if t.device == dev:
             return t.contiguous()
         if dev.type == "cuda" and t.device.type == "cpu":
-            return t.contiguous().pin_memory().to(dev, non_blocking=True)
+            staged = t.contiguous().pin_memory()
+            _STAGING.append(staged)            # kept referenced while the asynchronous copy may still read it
+            del _STAGING[:-8]
+            return staged.to(dev, non_blocking=True)
         return t.to(dev).contiguous()
     return put(perm, torch.int32), put(lam, torch.float32)
 
