@@ -709,8 +709,14 @@ class MAEST(nn.Module):
         toffset = 0
         if pinned is not None:
             toffset, t_keep = pinned
+            # the reference slices time_new_pos_embed[..., toffset:toffset + T'] (maest.py:648-657): an offset that does
+            # not leave T' columns makes its broadcast add fail; here it would read past the table in the kernel
+            if not 0 <= int(toffset) <= table - Tp:
+                raise ValueError(f"patchout offset {toffset} outside 0..{table - Tp} (time table {table}, {Tp} time patches)")
             if t_keep is not None:
                 t_list = torch.as_tensor(t_keep, dtype=torch.long).cpu()
+                if t_list.numel() and (int(t_list.min()) < 0 or int(t_list.max()) >= Tp):
+                    raise ValueError(f"kept time columns must lie in 0..{Tp - 1}")
         elif self.training:
             toffset = torch.randint(1 + table - Tp, (1,)).item()
             if self.s_patchout_t:

@@ -53,7 +53,7 @@ def test_first_forward_twice():
     for rep in range(3):
         for p in net.parameters():
             p.grad = None
-        loss = mod.training_step((x, None, y), 0, _mixup=(perm, lam), _patchout=(3, keep))
+        loss = mod.training_step((x, None, y), 0, _mixup=(perm, lam), _patchout=(0, keep))
         l_before = loss.item()
         loss.backward()
         torch.cuda.synchronize()

@@ -19,7 +19,7 @@ keep = torch.from_numpy(np.sort(rng.permutation(Tp)[: Tp - 30]))
 ref, bad = None, 0
 for it in range(n):
     for p in net.parameters(): p.grad = None
-    loss = mod.training_step((x, None, y), 0, _mixup=(perm, lam), _patchout=(3, keep))
+    loss = mod.training_step((x, None, y), 0, _mixup=(perm, lam), _patchout=(0, keep))
     if bwd: loss.backward()
     l = loss.item()
     ref = l if ref is None else ref

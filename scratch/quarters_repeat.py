@@ -16,7 +16,7 @@ perm = torch.cat([torch.from_numpy(rng.permutation(Q)) + q * Q for q in range(4)
 lam = torch.from_numpy(np.maximum(b := rng.beta(0.3, 0.3, B).astype(np.float32), 1 - b))
 Tp = (Tt - 16) // 10 + 1
 keep = torch.from_numpy(np.sort(rng.permutation(Tp)[: Tp - 30]))
-po = (3, keep)
+po = (0, keep)        # full-width input: the only offset that leaves 62 columns of the 62-column table
 def step(xs, ys, mix):
     for p in net.parameters(): p.grad = None
     loss = mod.training_step((xs, None, ys), 0, _mixup=mix, _patchout=po)

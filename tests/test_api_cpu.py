@@ -230,3 +230,20 @@ def test_configure_optimizers_returns_the_reference_layout():
         sched.step()
         assert abs(opt.param_groups[0]["lr"] - 2e-5 * f(epoch)) < 1e-18
     assert isinstance(Module(net=Tiny(), adamw=False).get_optimizer(), torch.optim.Adam)
+
+
+def test_explicit_patchout_draws_are_validated():
+    """An offset that does not leave T' columns of the time table fails in the reference (the sliced table no longer
+    broadcasts, models/maest.py:648-657); here it must raise instead of reaching the kernel, where it would read past
+    the table (found through a test that passed offset 3 for a full-width input)."""
+    import pytest
+    import torch
+    from maest_amd import get_maest
+    net = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30)
+    keep = torch.arange(32)
+    assert net._resolve_tokens(12, 62, pinned=(0, keep))[1].shape == (12 * 32, 2)
+    assert net._resolve_tokens(12, 40, pinned=(22, None))[0] == 22
+    with pytest.raises(ValueError, match="offset"):
+        net._resolve_tokens(12, 62, pinned=(3, keep))
+    with pytest.raises(ValueError, match="kept time columns"):
+        net._resolve_tokens(12, 40, pinned=(0, torch.tensor([0, 40])))

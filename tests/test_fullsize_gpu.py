@@ -86,7 +86,7 @@ def test_training_step_batch256_is_the_mean_of_its_quarters_fp32():
     lam = torch.from_numpy(np.maximum(b := rng.beta(0.3, 0.3, B).astype(np.float32), 1 - b))
     Tp = (T - 16) // 10 + 1
     keep = torch.from_numpy(np.sort(rng.permutation(Tp)[: Tp - 30]))
-    po = (3, keep)
+    po = (0, keep)        # full-width input: the only offset that leaves 62 columns of the 62-column table
     names = ["blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "blocks.5.norm1.weight", "patch_embed.proj.weight",
              "time_new_pos_embed", "head.1.bias", "blocks.7.attn.proj.bias"]
     params = dict(net.named_parameters())
