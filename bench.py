@@ -167,49 +167,13 @@ def cpu_baseline(batch, T, patchout, steps=3, teacher_student=False, waveform=Fa
                       f"{t:.2f} s/step"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 for the 10 s configs, 128 for ts)")
-    ap.add_argument("--frames", type=int, default=None, help="mel frames per clip (10 s @ 16 kHz -> 626; 30 s -> 1876)")
-    ap.add_argument("--patchout", type=int, default=None)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"],
-                    help="bf16: perf mode (the headline number); fp32: exact-fp32 MFMA parity mode; bf16x3: split-bf16 parity mode")
-    ap.add_argument("--mode", default="train", choices=["train", "infer", "ts"],
-                    help="train: BASELINE configs[2] (the headline metric); infer: configs[1]; ts: configs[4] "
-                         "(teacher-student, waveform -> HIP log-mel on the fly -> mixup -> 519-way separated heads, 30 s)")
-    ap.add_argument("--hip-graph", action="store_true", help="replay the forward from a captured HIP graph")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=None, help="clips per oracle step of the CPU baseline (SURVEY 8d: B = 8)")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--complete-last-block", action="store_true",
-                    help="evaluate the last block on every token (A/B reference for the head-token restriction)")
-    ap.add_argument("--serial-kernels", action="store_true",
-                    help="disable the side-stream overlap of weight-gradient GEMMs (for kernel profiling)")
-    args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args.gpus)
-
-    from maest_amd import get_maest, ops
-    from maest_amd.dist import GradReducer, broadcast_parameters, init_from_env
+def build_case(args, dev, rank, world, mode, T, B, patchout, reducer_kw=None):
+    """Model + resident synthetic batch + the step closure of one bench configuration."""
+    from maest_amd import get_maest
+    from maest_amd.dist import GradReducer, broadcast_parameters
     from maest_amd.module import Module, TeacherStudentModule
-
-    rank, local, world = init_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    import torch.distributed as dist
-
-    torch.manual_seed(1234 + rank)
-    np.random.seed(1234 + rank)
-    ts = args.mode == "ts"
-    train = args.mode in ("train", "ts")
-    T = args.frames if args.frames is not None else (1876 if ts else 626)
-    B = args.batch if args.batch is not None else (128 if T > 640 else 256)
-    patchout = args.patchout if args.patchout is not None else ((90 if T > 640 else 30) if train else 0)
+    ts = mode == "ts"
+    train = mode in ("train", "ts")
     C = 519 if ts else 400
     img_t = (T // 5) * 5 if T > 640 else 625      # time table: 62 columns for 10 s, 187 for the 30 s configs
     arch = "discogs-maest-30s-pw-73e-ts" if ts else ("passt_s_swa_p16_128_ap476" if train else "discogs-maest-10s-pw-129e")
@@ -221,10 +185,6 @@ def main():
     if args.serial_kernels:
         net._engine.overlap_wgrad = False
     mod = (TeacherStudentModule if ts else Module)(net=net, mixup_alpha=0.3)
-    Tp = (T - 16) // 10 + 1
-    Tk = Tp - patchout
-    N = 2 + 9 * Tk
-
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
     if ts:   # 30 s of synthetic 16 kHz audio per clip; the log-mel front end runs inside every step
         x = torch.rand((B, (T - 1) * 256), generator=gen, device=dev) * 2 - 1
@@ -232,16 +192,15 @@ def main():
         x = torch.randn((B, 1, 96, T), generator=gen, device=dev)               # synthetic z-normed log-mel
     y = (torch.rand((B, C), generator=gen, device=dev) < 2.5 / C).float()       # ~2.5 labels per clip
     y_teacher = (torch.rand((B, C), generator=gen, device=dev) < 2.5 / C).float() if ts else None
-
     if train:
         net.train()
         if args.hip_graph:
             net.enable_hip_graph()
-        opt = mod.get_optimizer()
+        opt = mod.get_optimizer(net.parameters())
         reducer = None
-        if world > 1:
+        if world > 1 or args.force_collective:
             skip = () if ts else ("head_dist.weight", "head_dist.bias")
-            reducer = GradReducer(net.named_parameters(), skip=skip)
+            reducer = GradReducer(net.named_parameters(), skip=skip, force_collective=args.force_collective)
             net._grad_sink = reducer
         batch = (x, None, y, y_teacher) if ts else (x, None, y)
 
@@ -263,15 +222,22 @@ def main():
         def step():
             with torch.no_grad():
                 return net(x)[0]
+    Tp = (T - 16) // 10 + 1
+    Tk = Tp - patchout
+    return dict(net=net, step=step, mode=mode, ts=ts, train=train, T=T, B=B, patchout=patchout, C=C, arch=arch,
+                Tk=Tk, N=2 + 9 * Tk)
 
-    for _ in range(args.warmup):
+
+def timed_steps(step, steps, warmup, world, dev):
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks."""
+    import torch.distributed as dist
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    # ---- timed region: EXACTLY K steps, nothing but the steps between the two barriers/syncs
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     if world > 1:
@@ -282,48 +248,179 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    return elapsed
+
+
+TIMED_KINDS = {"maest_gemm_nt", "maest_gemm_nt_small", "maest_gemm_tn", "maest_attn_fwd", "maest_attn_bwd",
+               "maest_layernorm_fwd", "maest_layernorm_bwd", "maest_logmel"}
+
+
+def kernel_pass(case, steps):
+    """The same K steps again with HIP events around every launch of the GEMM / attention / LayerNorm kernels on the
+    launch stream, kernels serialized (side-stream overlap off) so that each event pair times one kernel alone.  Kept
+    out of the timed region: ~400 event records per step cost ~10 % of a step on the host."""
+    from maest_amd import ops
+    net = case["net"]
+    prev = net._engine.overlap_wgrad
+    net._engine.overlap_wgrad = False
+    net.enable_hip_graph(False)
+    with ops.KernelTimer(kinds=TIMED_KINDS) as timer:
+        for _ in range(steps):
+            case["step"]()
+    torch.cuda.synchronize()
+    net._engine.overlap_wgrad = prev
+    return timer
+
+
+def flop_counts(case, precision):
+    """(algorithmic step FLOPs, FLOPs of it the engine does not execute, query rows the last block's attention computes)."""
+    from maest_amd import ops
+    net, N, Tk, C, B, train, ts = case["net"], case["N"], case["Tk"], case["C"], case["B"], case["train"], case["ts"]
+    fwd = flops_per_clip_fwd(N, Tk, C) + (2 * 768 * C if ts else 0)
+    step_flops = (3 if train else 1) * fwd * B
+    tail_on = bool(getattr(net._engine, "head_tail", False))
+    # (training at shapes the fused attention backward does not serve keeps the last block's attention complete)
+    attn_rows = min(32, N) if (not train or ops.attn_bwd_rows_supported(
+        torch.bfloat16 if precision == "bf16" else torch.float32, N)) else N
+    skipped = (3 if train else 1) * flops_per_clip_fwd_not_executed(N, attn_rows) * B if tail_on else 0
+    return step_flops, skipped, attn_rows, tail_on
+
+
+def kernel_report(case, timer, steps, precision, with_traffic):
+    """roofline / kernel_ms_per_step / attention_set objects from one kernel_pass."""
+    out = {}
+    B, N, train = case["B"], case["N"], case["train"]
+    _, _, attn_rows, tail_on = flop_counts(case, precision)
+    summ = timer.summary()
+    g = summ.get("maest_gemm_nt")
+    if g and g["ms"] > 0:
+        ach = g["work"] / (g["ms"] * 1e-3) / 1e12
+        # bf16x3 spends 3 bf16 MFMAs per product: its algorithmic rate is priced against a third of the bf16 peak
+        peak = {"bf16": PEAK_BF16_TFLOPS, "bf16x3": round(PEAK_BF16_TFLOPS / 3, 1)}.get(precision, 157.3)
+        out["roofline"] = {"bound": "mfma", "kernel": ("maest_gemm_nt (gemm_nt256w_kernel<bf16>: every token-major GEMM of the blocks; the head and the last block's head-token rows, M <= 512, run gemm_nt_kernel and are listed as maest_gemm_nt_small)"
+                                                      if precision == "bf16" else
+                                                      ("maest_gemm_nt (gemm_nt256w_kernel<float, X3>: 3 bf16 MFMAs per fp32 product)"
+                                                       if precision == "bf16x3" else "maest_gemm_nt (fp32 MFMA)")),
+                           "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+        if with_traffic:
+            traffic, traffic_source = pmc_traffic()
+            out["roofline"].update(traffic=traffic, traffic_source=traffic_source)
+        out["roofline"].update(launches_per_step=g["launches"] // steps, avg_launch_ms=round(g["ms"] / g["launches"], 4),
+                               ms_per_step=round(g["ms"] / steps, 3),
+                               note="second pass over the same K steps, kernels serialized (side-stream overlap off) "
+                                    "so that each event pair times one kernel alone")
+    out["kernel_ms_per_step"] = {k: round(v["ms"] / steps, 3) for k, v in summ.items()}
+    att = [summ.get("maest_attn_fwd"), summ.get("maest_attn_bwd")]
+    aw = sum(a["work"] for a in att if a)
+    am = sum(a["ms"] for a in att if a)
+    if am > 0:
+        out["attention_core_tflops"] = round(aw / (am * 1e-3) / 1e12, 1)
+    # north_star: "fraction of the attention-GEMM roofline" = the 12-block attention set (QKV projection + QK^T + PV +
+    # output projection; SURVEY.md 8d), its launches picked out of the timed records by their algorithmic work (the MLP
+    # GEMMs have 3072-wide shapes)
+    Mtok = B * N
+    set_work = {2.0 * Mtok * 2304 * 768, 2.0 * Mtok * 768 * 768, 2.0 * (2 * B) * 768 * 768}
+    set_ms = sum(e0.elapsed_time(e1) for name, e0, e1, w in timer.records
+                 if name in ("maest_attn_fwd", "maest_attn_bwd")
+                 or (name in ("maest_gemm_nt", "maest_gemm_nt_small", "maest_gemm_tn") and w in set_work)) / steps
+    set_flops = (3 if train else 1) * B * 12 * (2.0 * N * 768 * 2304 + 4.0 * N * N * 768 + 2.0 * N * 768 * 768)
+    if tail_on:       # executed FLOPs: the last block's out-projection and attention queries cover the head tokens only
+        set_flops -= (3 if train else 1) * B * (2.0 * (N - 2) * 768 * 768 + 4.0 * (N - attn_rows) * N * 768)
+    if set_ms > 0:
+        out["attention_set"] = {"what": "12 x (QKV proj + QK^T + PV + out proj)" + (", fwd+bwd" if train else ", fwd"),
+                                "ms_per_step": round(set_ms, 3), "tflops": round(set_flops / set_ms / 1e9, 1),
+                                "mfma_frac": round(set_flops / set_ms / 1e9 / PEAK_BF16_TFLOPS, 4)}
+    return out
+
+
+def side_case(args, dev, mode, T, B, patchout, steps, warmup, workload):
+    """A further BASELINE configuration measured on the same line (N = 1 only): its own K timed steps between two
+    synchronizes, then its own serialized kernel pass."""
+    case = build_case(args, dev, 0, 1, mode, T, B, patchout)
+    elapsed = timed_steps(case["step"], steps, warmup, 1, dev)
+    step_flops, skipped, _, _ = flop_counts(case, args.precision)
+    out = {"workload": workload, "value": round(B * steps / elapsed, 2), "unit": "clips/s", "steps": steps,
+           "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "per_gpu_batch": B, "mel": [96, T],
+           "s_patchout_t": patchout, "tokens": case["N"], "dtype": args.precision,
+           "model_tflops_per_s": round((step_flops - skipped) / (elapsed / steps) / 1e12, 1),
+           "model_mfma_frac": round((step_flops - skipped) / (elapsed / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+           "executed_flop_fraction": round(1.0 - skipped / step_flops, 4)}
+    if not args.no_kernel_timing:
+        out.update(kernel_report(case, kernel_pass(case, steps), steps, args.precision, with_traffic=False))
+    del case
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 for the 10 s configs, 128 for ts)")
+    ap.add_argument("--frames", type=int, default=None, help="mel frames per clip (10 s @ 16 kHz -> 626; 30 s -> 1876)")
+    ap.add_argument("--patchout", type=int, default=None)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"],
+                    help="bf16: perf mode (the headline number); fp32: exact-fp32 MFMA parity mode; bf16x3: split-bf16 parity mode")
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "ts"],
+                    help="train: BASELINE configs[2] (the headline metric); infer: configs[1]; ts: configs[4] "
+                         "(teacher-student, waveform -> HIP log-mel on the fly -> mixup -> 519-way separated heads, 30 s)")
+    ap.add_argument("--hip-graph", action="store_true", help="replay the forward from a captured HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=None, help="clips per oracle step of the CPU baseline (SURVEY 8d: B = 8)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-side-cases", action="store_true",
+                    help="skip the `infer` (configs[1]) and `train30s` (configs[3] per-GPU shape) sub-objects of the default line")
+    ap.add_argument("--complete-last-block", action="store_true",
+                    help="evaluate the last block on every token (A/B reference for the head-token restriction)")
+    ap.add_argument("--serial-kernels", action="store_true",
+                    help="disable the side-stream overlap of weight-gradient GEMMs (for kernel profiling)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1: create the one-rank RCCL communicator and push every gradient bucket through its "
+                         "all-reduce anyway (the data-parallel exchange path on a single GPU)")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
+
+    from maest_amd.dist import init_from_env
+
+    rank, local, world = init_from_env(force=args.force_collective)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+
+    torch.manual_seed(1234 + rank)
+    np.random.seed(1234 + rank)
+    ts = args.mode == "ts"
+    train = args.mode in ("train", "ts")
+    T = args.frames if args.frames is not None else (1876 if ts else 626)
+    B = args.batch if args.batch is not None else (128 if T > 640 else 256)
+    patchout = args.patchout if args.patchout is not None else ((90 if T > 640 else 30) if train else 0)
+    case = build_case(args, dev, rank, world, args.mode, T, B, patchout)
+    net, step, C, arch, N, Tk = case["net"], case["step"], case["C"], case["arch"], case["N"], case["Tk"]
+
+    # ---- timed region: EXACTLY K steps, nothing but the steps between the two barriers/syncs
+    elapsed = timed_steps(step, args.steps, args.warmup, world, dev)
 
     # ---- the same K steps with the last block evaluated on every token (N = 1 only; reported next to `value` so that the
     # effect of restricting it to the head's tokens is on the line itself)
     complete = None
     if world == 1 and getattr(net._engine, "head_tail", False) and not args.no_cpu_baseline and not args.hip_graph:
         net._engine.head_tail = False
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        complete = time.perf_counter() - t1
+        complete = timed_steps(step, args.steps, 2, 1, dev)
         net._engine.head_tail = True
 
-    # ---- roofline pass (rank 0, N = 1): the same K steps again with HIP events around every launch of the
-    # GEMM / attention kernels on the launch stream.  Kept out of the timed region above because ~400 event
-    # records per step cost ~10 % of a step on the host; kernel durations themselves are unaffected.
+    # ---- roofline pass (rank 0, N = 1)
     timer = None
     if not args.no_kernel_timing and world == 1:
-        # kernels are timed one at a time: with the wgrad GEMMs overlapping the dgrad chain on a second
-        # stream, an event pair around one launch would also count the time it shares the CUs with another
-        net._engine.overlap_wgrad = False
-        net.enable_hip_graph(False)
-        with ops.KernelTimer(kinds={"maest_gemm_nt", "maest_gemm_nt_small", "maest_gemm_tn", "maest_attn_fwd", "maest_attn_bwd",
-                                    "maest_layernorm_fwd", "maest_layernorm_bwd", "maest_logmel"}) as timer:
-            for _ in range(args.steps):
-                step()
-        torch.cuda.synchronize()
+        timer = kernel_pass(case, args.steps)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        fwd = flops_per_clip_fwd(N, Tk, C) + (2 * 768 * C if ts else 0)
-        step_flops = (3 if train else 1) * fwd * B
-        tail_on = bool(getattr(net._engine, "head_tail", False))
-        # (training at shapes the fused attention backward does not serve keeps the last block's attention complete)
-        from maest_amd import ops as _ops
-        attn_rows = min(32, N) if (not train or _ops.attn_bwd_rows_supported(
-            torch.bfloat16 if args.precision == "bf16" else torch.float32, N)) else N
-        skipped = (3 if train else 1) * flops_per_clip_fwd_not_executed(N, attn_rows) * B if tail_on else 0
+        step_flops, skipped, attn_rows, tail_on = flop_counts(case, args.precision)
         secs = "10s" if T <= 640 else "30s"
         if ts:
             workload = ("discogs-maest-30s-pw-73e-ts teacher-student training step (BASELINE configs[4]): waveform -> "
@@ -335,6 +432,7 @@ def main():
         else:
             workload = ("discogs-maest-10s-pw-129e inference (BASELINE configs[1])" if T <= 640
                         else f"30 s clips ({T} frames): discogs-maest-30s inference")
+        collective = world > 1 or args.force_collective
         out = {
             "metric": f"clips/sec ({secs}@16kHz, 96-mel) MAEST-{secs} " + ("fwd+bwd" if train else "fwd"),
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
@@ -346,7 +444,9 @@ def main():
                        "input": [B, (T - 1) * 256] if ts else [B, 96, T], "mel": [96, T],
                        "s_patchout_t": patchout, "tokens": N, "classes": C,
                        "hip_graph_forward": bool(args.hip_graph),
-                       "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, overlapped)" if world > 1 else "")},
+                       "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, overlapped" +
+                                                      ("; one-rank communicator, forced" if world == 1 else "") + ")"
+                                                      if collective else "")},
             # FLOPs actually executed (the algorithmic count minus the last block's rows that feed nothing)
             "model_tflops_per_s": round((step_flops - skipped) * world / (elapsed / args.steps) / 1e12, 1),
             "model_mfma_frac": round((step_flops - skipped) / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -360,52 +460,33 @@ def main():
                                        "(cls, dist) only, forward and backward; logits, features and all gradients equal "
                                        "the complete evaluation's" if tail_on else "complete")
         if timer is not None:
-            summ = timer.summary()
-            g = summ.get("maest_gemm_nt")
-            if g and g["ms"] > 0:
-                ach = g["work"] / (g["ms"] * 1e-3) / 1e12
-                # bf16x3 spends 3 bf16 MFMAs per product: its algorithmic rate is priced against a third of the bf16 peak
-                peak = {"bf16": PEAK_BF16_TFLOPS, "bf16x3": round(PEAK_BF16_TFLOPS / 3, 1)}.get(args.precision, 157.3)
-                traffic, traffic_source = pmc_traffic()
-                out["roofline"] = {"bound": "mfma", "kernel": ("maest_gemm_nt (gemm_nt256w_kernel<bf16>: every token-major GEMM of the blocks; the head and the last block's head-token rows, M <= 512, run gemm_nt_kernel and are listed as maest_gemm_nt_small)"
-                                              if args.precision == "bf16" else
-                                              ("maest_gemm_nt (gemm_nt256w_kernel<float, X3>: 3 bf16 MFMAs per fp32 product)"
-                                               if args.precision == "bf16x3" else "maest_gemm_nt (fp32 MFMA)")),
-                                   "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                                   "frac": round(ach / peak, 4),
-                                   "traffic": traffic, "traffic_source": traffic_source,
-                                   "launches_per_step": g["launches"] // args.steps,
-                                   "avg_launch_ms": round(g["ms"] / g["launches"], 4),
-                                   "ms_per_step": round(g["ms"] / args.steps, 3),
-                                   "note": "second pass over the same K steps, kernels serialized (side-stream "
-                                           "overlap off) so that each event pair times one kernel alone"}
-            out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in summ.items()}
-            att = [summ.get("maest_attn_fwd"), summ.get("maest_attn_bwd")]
-            aw = sum(a["work"] for a in att if a)
-            am = sum(a["ms"] for a in att if a)
-            if am > 0:
-                out["attention_core_tflops"] = round(aw / (am * 1e-3) / 1e12, 1)
-            # north_star: "fraction of the attention-GEMM roofline" = the 12-block attention set (QKV projection +
-            # QK^T + PV + output projection), its launches picked out of the timed records by their
-            # algorithmic work (the MLP GEMMs have 3072-wide shapes)
-            Mtok = B * N
-            set_work = {2.0 * Mtok * 2304 * 768, 2.0 * Mtok * 768 * 768, 2.0 * (2 * B) * 768 * 768}
-            set_ms = sum(e0.elapsed_time(e1) for name, e0, e1, w in timer.records
-                         if name in ("maest_attn_fwd", "maest_attn_bwd")
-                         or (name in ("maest_gemm_nt", "maest_gemm_nt_small", "maest_gemm_tn") and w in set_work)) / args.steps
-            set_flops = (3 if train else 1) * B * 12 * (2.0 * N * 768 * 2304 + 4.0 * N * N * 768 + 2.0 * N * 768 * 768)
-            if tail_on:       # executed FLOPs: the last block's out-projection and attention queries cover the head tokens only
-                set_flops -= (3 if train else 1) * B * (2.0 * (N - 2) * 768 * 768 + 4.0 * (N - attn_rows) * N * 768)
-            if set_ms > 0:
-                out["attention_set"] = {"what": "12 x (QKV proj + QK^T + PV + out proj)" + (", fwd+bwd" if train else ", fwd"),
-                                        "ms_per_step": round(set_ms, 3), "tflops": round(set_flops / set_ms / 1e9, 1),
-                                        "mfma_frac": round(set_flops / set_ms / 1e9 / PEAK_BF16_TFLOPS, 4)}
+            out.update(kernel_report(case, timer, args.steps, args.precision, with_traffic=True))
         if world == 1 and not args.no_kernel_timing:
             # the HBM-bound front end of the path: the log-mel kernel on a full batch of waveforms
             try:
                 out["mel"] = time_mel_kernel(dev, B, (T - 1) * 256)
             except Exception as e:  # pragma: no cover
                 out["mel"] = {"error": repr(e)}
+        # ---- the other single-GPU BASELINE configurations, driver-visible on the same line (default run only)
+        default_line = (world == 1 and args.mode == "train" and args.frames is None and args.batch is None
+                        and args.patchout is None and not args.hip_graph and not args.no_side_cases
+                        and not args.complete_last_block and not args.serial_kernels and not args.force_collective)
+        if default_line:
+            del case, net, step
+            torch.cuda.empty_cache()
+            try:
+                out["infer"] = side_case(args, dev, "infer", 626, 256, 0, max(args.steps, 20), 3,
+                                         "discogs-maest-10s-pw-129e inference (BASELINE configs[1]): batch 256 x (96 x 626) "
+                                         "pre-extracted mel, N = 560 tokens -- north_star's '12-block attention at batch 256'")
+            except Exception as e:  # pragma: no cover
+                out["infer"] = {"error": repr(e)}
+            try:
+                out["train30s"] = side_case(args, dev, "train", 1876, 128, 90, max(3, min(args.steps, 5)), 2,
+                                            "maest_30s_from_passt_pretrain-shaped training step (BASELINE configs[3], the "
+                                            "per-GPU shape of global batch 1024 over 8 GPUs): batch 128 x (96 x 1876), "
+                                            "s_patchout_t 90, N = 875 tokens")
+            except Exception as e:  # pragma: no cover
+                out["train30s"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 cb = args.cpu_batch if args.cpu_batch is not None else (8 if T <= 640 else 2)
@@ -414,7 +495,7 @@ def main():
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

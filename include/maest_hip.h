@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MAEST_ABI_VERSION 3
+#define MAEST_ABI_VERSION 4
 
 #define MAEST_OK 0
 #define MAEST_ERR_INVALID 1 /* bad argument (shape / alignment / dtype) */
@@ -42,6 +42,9 @@ extern "C" {
                          full-rate bf16 matrix pipe */
 
 /* GEMM epilogues */
+#define MAEST_F16 3 /* IEEE half: accepted as the INPUT dtype of maest_patch_im2col only (the loader's float16 mel batches,
+                       discogs/dataset.py:58-67) */
+
 #define MAEST_EPI_NONE 0     /* C = acc + bias                                           */
 #define MAEST_EPI_GELU 1     /* C = gelu_erf(acc+bias) ; aux_out (optional) = gelu_erf'(acc+bias), saved for backward */
 #define MAEST_EPI_RESIDUAL 2 /* C(fp32) = acc + bias + aux_in(fp32)                      */
@@ -163,14 +166,15 @@ int maest_scatter_head_rows(const void* src, int clips, int n_tok, int n_head, i
  * (models/module.py:77-83) and with EVERY patchout variant of models/maest.py:678-780 (structured time /
  * frequency, fixed index lists, interleaved, unstructured): the host resolves them into one list of kept
  * patch tokens and dropped patches are never computed -- mathematically identical to compute-then-drop.
- * x: fp32 [B, F, T]; perm: int32 [B] or NULL; lam: fp32 [B] or NULL (x' = lam*x + (1-lam)*x[perm]).
+ * x: [B, F, T] in x_dtype = MAEST_F32 or MAEST_F16 (the loader hands out float16 mel batches, discogs/dataset.py:58-67;
+ * a half sample is widened exactly as x.float() would, in the load); perm: int32 [B] or NULL; lam: fp32 [B] or NULL (x' = lam*x + (1-lam)*x[perm]).
  * tok_ft: int32 [P, 2] = (frequency patch index f, time patch index t) of each kept token, in sequence
  * order.  out: dtype [B*P, 256], row = b*P + j, col = ky*16 + kx, patch origin (10 f, 10 t).
  * Optional K17 SpecMasking fused into the same load (helpers/spec_masking.py:27-33; the loader masks each clip
  * before the batch is mixed up, discogs/datamodule.py:140-152): t_stripes int32 [B, n_t, 2] / f_stripes int32
  * [B, n_f, 2] = (start, width) per clip, as in maest_spec_mask; a masked sample reads as 0.0 (for the clip and,
  * with its own stripes, for its mixup partner).  n_t = n_f = 0 (pointers may be NULL) disables it. */
-int maest_patch_im2col(const float* x, int B, int F, int T, const int32_t* perm, const float* lam,
+int maest_patch_im2col(const void* x, int x_dtype, int B, int F, int T, const int32_t* perm, const float* lam,
                        const int32_t* tok_ft, int P, const int32_t* t_stripes, int n_t,
                        const int32_t* f_stripes, int n_f, void* out, int dtype, void* stream);
 

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmaest_hip.so")
 
 F32 = 0
 BF16 = 1
+F16 = 3     # IEEE half, input of maest_patch_im2col only
 F32X3 = 2   # fp32 tensors, split-bf16 matrix products (maest_gemm_nt in_dtype / maest_attn_fwd dtype only)
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_MUL, EPI_ATOMIC = 0, 1, 2, 3, 4
 
@@ -38,7 +39,7 @@ SIGNATURES = {
     "maest_layernorm_bwd_headres": [_P, _L, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "maest_gather_head_rows": [_P, _I, _I, _I, _I, _P, _P],
     "maest_scatter_head_rows": [_P, _I, _I, _I, _I, _I, _P, _P],
-    "maest_patch_im2col": [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P],
+    "maest_patch_im2col": [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "maest_token_assemble": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P, _P],
     "maest_token_assemble_bwd": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "maest_head_pool_fwd": [_P, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P],
@@ -60,7 +61,7 @@ SIGNATURES = {
     "maest_get_option": [_I, _P],
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "ln_bwd_blocks": 4}
 
 _lib = None

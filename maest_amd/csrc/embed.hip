@@ -44,7 +44,9 @@ __device__ __forceinline__ uint32_t stripe_bits(const int32_t* __restrict__ t_st
 }
 
 // one thread = one (patch row, ky): 16 contiguous input samples -> 16 contiguous operand elements
-__global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ x, int B, int F, int T,
+// XT: element type of x -- float, or _Float16 for the loader's half-precision mel batches (widened in the load)
+template <typename XT>
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const XT* __restrict__ x, int B, int F, int T,
                                                            const int32_t* __restrict__ perm,
                                                            const float* __restrict__ lam,
                                                            const int32_t* __restrict__ tok_ft, int P,
@@ -62,10 +64,10 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
     const int tcol = tok_ft[2 * j + 1] * PE_S;
     const int frow = f * PE_S + ky;
     const bool masked = n_t + n_f > 0;
-    const float* src = x + ((int64_t)b * F + frow) * T + tcol;
+    const XT* src = x + ((int64_t)b * F + frow) * T + tcol;
     float v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = src[i];
+    for (int i = 0; i < 16; ++i) v[i] = (float)src[i];
     if (masked) {
         const uint32_t bits = stripe_bits(t_stripes, n_t, f_stripes, n_f, b, frow, tcol);
 #pragma unroll
@@ -74,10 +76,10 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
     if (lam != nullptr) {
         const float l = lam[b];
         const int b2 = perm[b];
-        const float* src2 = x + ((int64_t)b2 * F + frow) * T + tcol;
+        const XT* src2 = x + ((int64_t)b2 * F + frow) * T + tcol;
         float u[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) u[i] = src2[i];
+        for (int i = 0; i < 16; ++i) u[i] = (float)src2[i];
         if (masked) {
             const uint32_t bits = stripe_bits(t_stripes, n_t, f_stripes, n_f, b2, frow, tcol);
 #pragma unroll
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void melfile_assemble_kernel(const uint16_t* _
 
 using namespace maest;
 
-extern "C" int maest_patch_im2col(const float* x, int B, int F, int T, const int32_t* perm, const float* lam,
+extern "C" int maest_patch_im2col(const void* x, int x_dtype, int B, int F, int T, const int32_t* perm, const float* lam,
                                   const int32_t* tok_ft, int P, const int32_t* t_stripes, int n_t,
                                   const int32_t* f_stripes, int n_f, void* out, int dtype, void* stream) {
     MAEST_REQUIRE(x && out && tok_ft, "maest_patch_im2col: null pointer");
@@ -296,11 +298,17 @@ extern "C" int maest_patch_im2col(const float* x, int B, int F, int T, const int
     MAEST_REQUIRE(F >= PE_K && T >= PE_K, "maest_patch_im2col: input %dx%d smaller than a patch", F, T);
     MAEST_REQUIRE((perm == nullptr) == (lam == nullptr), "maest_patch_im2col: perm and lam go together");
     MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_patch_im2col: bad dtype");
+    MAEST_REQUIRE(x_dtype == MAEST_F32 || x_dtype == MAEST_F16, "maest_patch_im2col: input must be fp32 or fp16");
     MAEST_REQUIRE(n_t >= 0 && n_f >= 0 && (n_t == 0 || t_stripes) && (n_f == 0 || f_stripes),
                   "maest_patch_im2col: bad stripe lists");
     const int64_t total = (int64_t)B * P * PE_K;
-    hipLaunchKernelGGL(patch_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       x, B, F, T, perm, lam, tok_ft, P, t_stripes, n_t, f_stripes, n_f, out, dtype);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (x_dtype == MAEST_F16)
+        hipLaunchKernelGGL(patch_im2col_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, B,
+                           F, T, perm, lam, tok_ft, P, t_stripes, n_t, f_stripes, n_f, out, dtype);
+    else
+        hipLaunchKernelGGL(patch_im2col_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, B, F,
+                           T, perm, lam, tok_ft, P, t_stripes, n_t, f_stripes, n_f, out, dtype);
     return check_launch("maest_patch_im2col");
 }
 

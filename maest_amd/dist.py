@@ -39,9 +39,14 @@ def backward_order(names: List[str]) -> List[str]:
 
 
 class GradReducer:
-    def __init__(self, named_params, bucket_mb: float = 96.0, process_group=None, skip=()):
+    def __init__(self, named_params, bucket_mb: float = 96.0, process_group=None, skip=(),
+                 force_collective: bool = False):
+        """force_collective: issue the bucket all-reduces even at world size 1 (needs an initialised process group).
+        A one-rank all-reduce changes nothing numerically, but it drives the whole exchange path -- communicator, the
+        asynchronous launch from the side stream, the wait in finish() -- through RCCL on a single-GPU box."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (bool(force_collective) and dist.is_initialized())
         params = {n: p for n, p in named_params if p.requires_grad and n not in skip}
         self.order = backward_order(list(params))
         self.params = params
@@ -86,7 +91,7 @@ class GradReducer:
         if b is None:
             return
         self._pending[b] -= 1
-        if self._pending[b] == 0 and self.world > 1:
+        if self._pending[b] == 0 and self.collective:
             bk = self.buckets[b]
             w = dist.all_reduce(self.flat[bk["start"]:bk["end"]], op=dist.ReduceOp.SUM, group=self.group,
                                 async_op=True)
@@ -108,14 +113,15 @@ class GradReducer:
             p.grad = self.views[n]
 
 
-def init_from_env(backend: Optional[str] = None):
+def init_from_env(backend: Optional[str] = None, force: bool = False):
     """torch.distributed bootstrap from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world)."""
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world).  `force`: create the process group at
+    world size 1 too (a one-rank RCCL communicator: GradReducer(force_collective=True), bench.py --force-collective)."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         be = backend or ("nccl" if torch.cuda.is_available() else "gloo")

@@ -178,13 +178,13 @@ def _split_k(n_out: int, k_out: int, tokens: int) -> int:
     return max(1, min(1024 // tiles, math.ceil(tokens / 64)))
 
 
-def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int, out=None, bias_out=None) -> torch.Tensor:
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int, out=None, bias_out=None, x3=False) -> torch.Tensor:
     """dW[n_out, k_out] = dy[M, n_out]^T @ x[M, k_out] (fp32) and, fused in the same kernel,
     db[n_out] = dy.sum(0): token-major operands are consumed in place (csrc/gemm.hip: gemm_tn_kernel).
     `out` / `bias_out` (pre-zeroed fp32) receive the results if given."""
     dw = (torch.zeros((n_out, k_out), dtype=torch.float32, device=dy.device) if out is None
           else out.view(n_out, k_out))
-    ops.gemm_tn(dy, x, dw, colsum=bias_out, split_k=0, M=n_out, N=k_out)   # 0 = kernel-chosen split
+    ops.gemm_tn(dy, x, dw, colsum=bias_out, split_k=0, M=n_out, N=k_out, x3=x3)   # 0 = kernel-chosen split
     return dw
 
 
@@ -224,7 +224,8 @@ class _Engine:
                 stop_block: int = -1, return_self_attention: bool = False, save: bool = False):
         """x3: fp32 [B, F, T] on the device; tok_ft: int32 [P, 2] kept patch tokens.  Returns (outputs, ctx)."""
         m, W = self.m, self.w
-        ops.set_f32_split(m.precision == "bf16x3")
+        x3m = m.precision == "bf16x3"      # split-bf16 products on fp32 tensors: an explicit argument of every product
+        gemm_nt = partial(ops.gemm_nt, x3=x3m)
         B, F, T = x3.shape
         P = int(tok_ft.shape[0])
         N = 2 + P
@@ -245,7 +246,7 @@ class _Engine:
 
         t_str, f_str = stripes if stripes is not None else (None, None)
         cols = ops.patch_im2col(x3, tok_ft, dt, perm=perm, lam=lam, t_stripes=t_str, f_stripes=f_str)
-        patches = ops.gemm_nt(cols, W.get(m.patch_embed.proj.weight, dt), m.patch_embed.proj.bias,
+        patches = gemm_nt(cols, W.get(m.patch_embed.proj.weight, dt), m.patch_embed.proj.bias,
                               out_dtype=torch.float32)
         Tt = m.time_new_pos_embed.shape[-1]
         x = ops.token_assemble(patches, m.cls_token.reshape(-1), m.dist_token.reshape(-1),
@@ -273,12 +274,12 @@ class _Engine:
             else:
                 r = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, dt, save_stats=save)
                 ln1, mean1, rstd1 = r if save else (r, None, None)
-            qkv = ops.gemm_nt(ln1, W.get(blk.attn.qkv.weight, dt), blk.attn.qkv.bias, out_dtype=dt)
+            qkv = gemm_nt(ln1, W.get(blk.attn.qkv.weight, dt), blk.attn.qkv.bias, out_dtype=dt)
             tail = self.head_tail and stop_block < 0 and i == nblocks - 1
             # (training needs the backward kernel that honours the restriction; otherwise the attention stays complete
             # and only the per-token part of the block is restricted)
             q_rows = HEAD_TOKENS if tail and (not save or ops.attn_bwd_rows_supported(dt, N)) else None
-            r = ops.attn_fwd(qkv, B, N, scale, save_lse=save, q_rows=q_rows)
+            r = ops.attn_fwd(qkv, B, N, scale, save_lse=save, q_rows=q_rows, x3=x3m)
             ao, lse = r if save else (r, None)
             ao_full, x_full, Mb = ao, x, M
             if tail:      # from here on the block lives on [B * 2, 768]
@@ -287,30 +288,30 @@ class _Engine:
                 Mb = B * HEAD_TOKENS
             if i == stop_block and return_self_attention:
                 # Block.forward(..., return_self_attention=True) returns attn(norm1(x)) (maest.py:414-416)
-                a = ops.gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=torch.float32)
+                a = gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=torch.float32)
                 return ops.embed_pool(a.reshape(B, N, EMBED_DIM)), None
             if split_add:
-                d1 = ops.gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=dt)
+                d1 = gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=dt)
                 r = ops.add_layernorm_fwd(x, d1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save_stats=save)
                 x1, ln2 = r[0], r[1]
                 mean2, rstd2 = (r[2], r[3]) if save else (None, None)
             else:
-                x1 = ops.gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=torch.float32,
+                x1 = gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=torch.float32,
                                  epi=ops.EPI_RESIDUAL, aux_in=x)
                 r = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save_stats=save)
                 ln2, mean2, rstd2 = r if save else (r, None, None)
             h = torch.empty((Mb, blk.mlp.fc1.out_features), dtype=dt, device=x.device) if save else None
-            g = ops.gemm_nt(ln2, W.get(blk.mlp.fc1.weight, dt), blk.mlp.fc1.bias, out_dtype=dt, epi=ops.EPI_GELU,
+            g = gemm_nt(ln2, W.get(blk.mlp.fc1.weight, dt), blk.mlp.fc1.bias, out_dtype=dt, epi=ops.EPI_GELU,
                             aux_out=h)
             if save:
                 ctx["blocks"].append(dict(x=x_full, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse, x1=x1,
                                           mean2=mean2, rstd2=rstd2, ln2=ln2, h=h, g=g, tail=tail, ao_full=ao_full,
                                           q_rows=q_rows))
             if split_add and i + 1 < nblocks:
-                pending = ops.gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=dt)
+                pending = gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=dt)
                 x = x1
             else:             # last block of this pass: nothing follows that could carry the add
-                x = ops.gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=torch.float32,
+                x = gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=torch.float32,
                                 epi=ops.EPI_RESIDUAL, aux_in=x1)
         xb = x.reshape(B, -1, EMBED_DIM)          # [B, N, 768], or [B, 2, 768] behind a restricted last block
         if stop_block >= 0:
@@ -321,14 +322,14 @@ class _Engine:
         if m.distilled_type == "mean":
             r2 = ops.layernorm_fwd(feat, hn.weight, hn.bias, hn.eps, dt, save_stats=save)
             hl, hmean, hrstd = r2 if save else (r2, None, None)
-            logits = ops.gemm_nt(hl, W.get(hw.weight, dt), hw.bias, out_dtype=torch.float32)
+            logits = gemm_nt(hl, W.get(hw.weight, dt), hw.bias, out_dtype=torch.float32)
             outs = (logits, feat)
         elif m.distilled_type == "separated":
             r2 = ops.layernorm_fwd(cls, hn.weight, hn.bias, hn.eps, dt, save_stats=save)
             hl, hmean, hrstd = r2 if save else (r2, None, None)
-            logits = ops.gemm_nt(hl, W.get(hw.weight, dt), hw.bias, out_dtype=torch.float32)
+            logits = gemm_nt(hl, W.get(hw.weight, dt), hw.bias, out_dtype=torch.float32)
             dlp = dist if dt == torch.float32 else ops.cast_weights(dist, dt)[0]
-            logits_d = ops.gemm_nt(dlp, W.get(m.head_dist.weight, dt), m.head_dist.bias, out_dtype=torch.float32)
+            logits_d = gemm_nt(dlp, W.get(m.head_dist.weight, dt), m.head_dist.bias, out_dtype=torch.float32)
             outs = (logits, logits_d, feat)
             if save:
                 ctx["dist_lp"] = dlp
@@ -346,7 +347,8 @@ class _Engine:
         gradient is written straight into the sink's flat bucket view and reported as soon as it is
         complete, so the RCCL all-reduce of a bucket overlaps with the rest of the backward."""
         m, W = self.m, self.w
-        ops.set_f32_split(m.precision == "bf16x3")
+        x3m = m.precision == "bf16x3"
+        gemm_nt = partial(ops.gemm_nt, x3=x3m)
         dt, B, N = ctx["dt"], ctx["B"], ctx["N"]
         Fp = m.freq_new_pos_embed.shape[2]
         M = B * N
@@ -394,11 +396,11 @@ class _Engine:
                 ev.record(main)            # dy, x and the zeroed destinations are ready at this point
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    _wgrad(dy, x, n_out, k_out, gw, gb)
+                    _wgrad(dy, x, n_out, k_out, gw, gb, x3m)
                 for t in (dy, x, gw, gb):
                     t.record_stream(side)  # keep the caching allocator from recycling them under the side stream
             else:
-                _wgrad(dy, x, n_out, k_out, gw, gb)
+                _wgrad(dy, x, n_out, k_out, gw, gb, x3m)
             done(name_w, gw if w_shape is None else gw.view(w_shape))
             done(name_b, gb)
 
@@ -410,7 +412,7 @@ class _Engine:
             dl = ops.cast_rows(dlogits, dt, cpad)     # fp32 [B, C] -> operand dtype [B, cpad], zero padded (K of the dgrad GEMM)
             wgrad(prefix + ".weight", prefix + ".bias", dl, inp_lp, C, EMBED_DIM)
             wt = W.get(lin.weight, dt, transposed=True, pad_cols_to=64)          # [768, cpad]
-            return ops.gemm_nt(dl, wt, None, out_dtype=out_dtype, M=B, N=EMBED_DIM, K=cpad)
+            return gemm_nt(dl, wt, None, out_dtype=out_dtype, M=B, N=EMBED_DIM, K=cpad)
 
         d_cls = d_dist = None
         g_h0w, g_h0b = buf("head.0.weight", EMBED_DIM), buf("head.0.bias", EMBED_DIM)
@@ -449,11 +451,11 @@ class _Engine:
             H = blk.mlp.fc1.out_features
             # fc2 (+ residual):  x2 = x1 + g W2^T + b2
             wgrad(p + "mlp.fc2.weight", p + "mlp.fc2.bias", dx_lp, s["g"], EMBED_DIM, H)
-            dh = ops.gemm_nt(dx_lp, W.get(blk.mlp.fc2.weight, dt, transposed=True), None, out_dtype=dt,
+            dh = gemm_nt(dx_lp, W.get(blk.mlp.fc2.weight, dt, transposed=True), None, out_dtype=dt,
                              epi=ops.EPI_MUL, aux_in=s["h"])
             # fc1
             wgrad(p + "mlp.fc1.weight", p + "mlp.fc1.bias", dh, s["ln2"], H, EMBED_DIM)
-            dln2 = ops.gemm_nt(dh, W.get(blk.mlp.fc1.weight, dt, transposed=True), None, out_dtype=dt)
+            dln2 = gemm_nt(dh, W.get(blk.mlp.fc1.weight, dt, transposed=True), None, out_dtype=dt)
             gw, gb = buf(p + "norm2.weight", EMBED_DIM), buf(p + "norm2.bias", EMBED_DIM)
             dx1, dx1_lp = ops.layernorm_bwd(dln2, s["x1"], blk.norm2.weight, s["mean2"], s["rstd2"], dx, gw, gb,
                                             lp_dtype=None if dt == torch.float32 else dt)
@@ -463,14 +465,14 @@ class _Engine:
                 dx1_lp = dx1
             # proj (+ residual)
             wgrad(p + "attn.proj.weight", p + "attn.proj.bias", dx1_lp, s["ao"], EMBED_DIM, EMBED_DIM)
-            dao = ops.gemm_nt(dx1_lp, W.get(blk.attn.proj.weight, dt, transposed=True), None, out_dtype=dt)
+            dao = gemm_nt(dx1_lp, W.get(blk.attn.proj.weight, dt, transposed=True), None, out_dtype=dt)
             if s["tail"]:
                 # back to the token-major layout: the head tokens' rows, zeros for the queries the kernel still visits
                 # (its first 32-row tile when it honours q_rows, every row otherwise)
                 dao = ops.scatter_head_rows(dao, B, N, HEAD_TOKENS, min(32, N) if s["q_rows"] else N)
-            dqkv = ops.attn_bwd(s["qkv"], s["ao_full"], dao, s["lse"], B, N, blk.attn.scale, q_rows=s["q_rows"])
+            dqkv = ops.attn_bwd(s["qkv"], s["ao_full"], dao, s["lse"], B, N, blk.attn.scale, q_rows=s["q_rows"], x3=x3m)
             wgrad(p + "attn.qkv.weight", p + "attn.qkv.bias", dqkv, s["ln1"], 3 * EMBED_DIM, EMBED_DIM)
-            dln1 = ops.gemm_nt(dqkv, W.get(blk.attn.qkv.weight, dt, transposed=True), None, out_dtype=dt)
+            dln1 = gemm_nt(dqkv, W.get(blk.attn.qkv.weight, dt, transposed=True), None, out_dtype=dt)
             gw, gb = buf(p + "norm1.weight", EMBED_DIM), buf(p + "norm1.bias", EMBED_DIM)
             dx, dx_lp = ops.layernorm_bwd(dln1, s["x"], blk.norm1.weight, s["mean1"], s["rstd1"], dx1, gw, gb,
                                           lp_dtype=None if dt == torch.float32 else dt,
@@ -499,14 +501,21 @@ class _Engine:
         return G
 
 
+class _GraphLease:
+    """Held by the autograd node of a forward that was replayed from a captured training graph, until its backward has
+    run (or the node is dropped): while it is alive the graph's static activation buffers must not be rewritten."""
+    __slots__ = ("__weakref__",)
+
+
 class _MaestFn(torch.autograd.Function):
     """The single autograd edge: forward = _Engine.forward(save=True); backward = _Engine.backward."""
 
     @staticmethod
     def forward(ctx, model, x3, dt, kw, names, *params):
         ctx.set_materialize_grads(False)      # outputs the loss does not use (the features) arrive as None, not as zeros
+        ctx.graph_lease = None
         if model.hip_graph and x3.is_cuda:
-            outs, saved = model._graph_train_forward(x3, dt, kw)
+            outs, saved, ctx.graph_lease = model._graph_train_forward(x3, dt, kw)
         else:
             outs, saved = model._engine.forward(x3, dt, save=True, **kw)
         ctx.saved = saved
@@ -521,6 +530,7 @@ class _MaestFn(torch.autograd.Function):
         sink = ctx.model._grad_sink
         G = ctx.model._engine.backward(ctx.saved, gout, sink)
         ctx.saved = None
+        ctx.graph_lease = None       # the graph's static activation buffers may be rewritten again
         if sink is not None:   # the sink (maest_amd.dist.GradReducer) installs param.grad itself
             return (None, None, None, None, None, *([None] * len(ctx.names)))
         grads = []
@@ -597,6 +607,7 @@ class MAEST(nn.Module):
         self._param_names = None
         self._tok_cache = {}
         self.hip_graph = False
+        self._toffset_choices = 1
         self._graphs = {}
         self._param_list = None
         self._grad_sink = None   # set to a maest_amd.dist.GradReducer for data-parallel training
@@ -605,8 +616,18 @@ class MAEST(nn.Module):
         """A fresh model of the same architecture, on the same device and in the same mode, holding copies of the
         parameters -- and NOTHING of the engine's run-time state (operand-copy caches keyed on the old parameters,
         side streams, captured HIP graphs, the data-parallel gradient sink with its flat buffer)."""
-        twin = type(self)(**self._init_kwargs)
-        twin.precision = self.precision
+        MAEST._skip_random_init = True          # every parameter is overwritten below
+        try:
+            twin = type(self)(**self._init_kwargs)
+        finally:
+            MAEST._skip_random_init = False
+        # configuration changed after construction travels too (patchout switched off for evaluation, numeric mode,
+        # graph replay, engine switches) -- run-time state does not
+        for k in ("precision", "u_patchout", "s_patchout_t", "s_patchout_f", "s_patchout_f_indices",
+                  "s_patchout_f_interleaved", "s_patchout_t_indices", "s_patchout_t_interleaved", "hip_graph"):
+            setattr(twin, k, getattr(self, k))
+        twin._engine.head_tail = self._engine.head_tail
+        twin._engine.overlap_wgrad = self._engine.overlap_wgrad
         dev = next(self.parameters()).device
         twin.to(dev)
         with torch.no_grad():
@@ -624,8 +645,12 @@ class MAEST(nn.Module):
         return twin
 
     # ---- reference API odds and ends --------------------------------------------------------
+    _skip_random_init = False     # clone_weights(): the twin's parameters are copies, not draws
+
     def init_weights(self, mode=""):
         assert mode in ("jax", "jax_nlhb", "nlhb", "")
+        if MAEST._skip_random_init:
+            return
         for p in (self.new_pos_embed, self.freq_new_pos_embed, self.time_new_pos_embed, self.dist_token,
                   self.cls_token):
             nn.init.trunc_normal_(p, std=0.02, a=-2.0, b=2.0)
@@ -762,8 +787,8 @@ class MAEST(nn.Module):
                 f"maest_amd runs on MI355X only: input is on {x.device}. Move the model and the input to a HIP "
                 "device (model.cuda(); x.cuda()). There is no CPU fallback.")
         x3 = x.reshape(B, F, T)
-        if x3.dtype != torch.float32:
-            x3 = x3.float()
+        if x3.dtype not in (torch.float32, torch.float16):   # float16 batches (the loader's, discogs/dataset.py:58-67) go
+            x3 = x3.float()                                  # straight into the patch-embedding operand load
         x3 = x3.contiguous()
         need_grad = (transformer_block == -1 and torch.is_grad_enabled()
                      and any(p.requires_grad for p in self.parameters()))
@@ -774,6 +799,8 @@ class MAEST(nn.Module):
             raise Exception(f"{Fp} frequency patches exceed the frequency positional table "
                             f"{tuple(self.freq_new_pos_embed.shape)}")
         tok_key = (Fp, Tp, str(x3.device))
+        # how many time-table offsets this call could have drawn (1: none drawn / pinned); the train-graph cache looks at it
+        self._toffset_choices = (1 + self.time_new_pos_embed.shape[-1] - Tp) if (self.training and _patchout is None) else 1
         if not self.training and _patchout is None and tok_key in self._tok_cache:
             toffset, tok_ft = self._tok_cache[tok_key]        # eval: deterministic, already on the device
         else:
@@ -781,9 +808,9 @@ class MAEST(nn.Module):
             if tok_ft.shape[0] < 1:
                 raise Exception("patchout removed every patch token")
             if x3.is_cuda and not tok_ft.is_cuda:     # training: a fresh list every step; no stream-draining copy
-                # the pinned staging tensor stays referenced until the next step's replaces it: the copy is asynchronous
-                self._tok_staging = tok_ft.contiguous().pin_memory()
-                tok_ft = self._tok_staging.to(x3.device, non_blocking=True)
+                # (asynchronous copy out of a pinned block; torch's caching host allocator holds the block back until the
+                # copy's stream event has completed)
+                tok_ft = tok_ft.contiguous().pin_memory().to(x3.device, non_blocking=True)
             else:
                 tok_ft = tok_ft.to(x3.device)
             if not self.training and _patchout is None:
@@ -836,7 +863,7 @@ class MAEST(nn.Module):
         if self._engine._weights_dirty:                  # a training step happened since the last eval forward
             self._engine.w.clear()
             self._engine._weights_dirty = False
-        key = (tuple(x3.shape), dt, self.precision, kw["toffset"], int(kw["tok_ft"].shape[0]), str(x3.device),
+        key = (tuple(x3.shape), x3.dtype, dt, self.precision, kw["toffset"], int(kw["tok_ft"].shape[0]), str(x3.device),
                sum(p._version for p in self.parameters()), self._engine.w.epoch)
         st = self._graphs.get(key)
         if st is None:                                   # first call: eager (fills the operand-copy caches)
@@ -860,21 +887,31 @@ class MAEST(nn.Module):
         """Training-mode forward (activations saved for the hand-written backward) replayed from a HIP graph
         (BASELINE configs[4]: "hipGraph-captured forward").  Per input signature: call 1 runs eagerly, call 2 captures,
         later calls copy the step's inputs (batch, kept-token list, mixup / stripe draws) into the graph's static
-        buffers and replay ~190 launches (weight recast included) as one.  The saved activations live in the graph's
-        private pool and are rewritten by every replay, so ONE training step may be in flight at a time -- which is
-        what forward / backward / optimizer.step() is."""
+        buffers and replay ~190 launches (weight recast included) as one.  Returns (outputs, ctx, graph state | None).
+
+        The saved activations live in the graph's private pool and are rewritten by every replay, so a graph serves ONE
+        forward at a time: the autograd node of that forward holds a lease on it until its backward has run (or the
+        node is dropped), and a second grad-enabled forward of the same signature in between (two-view / consistency losses, a teacher and a
+        student sharing the net) runs eagerly with its own activations instead of corrupting the first one's.
+        The time-table offset is a launch argument baked into the captured kernels (and part of the graph key): inputs
+        shorter than the table draw a fresh offset every step (models/maest.py:648-650); with more than 4 possible
+        offsets they are not captured at all (eager) instead of re-capturing almost every step."""
         eng = self._engine
+        if self._toffset_choices > 4:      # more offsets than the 8-entry graph cache should be spent on
+            return (*eng.forward(x3, dt, save=True, **kw), None)
         stripes = kw.get("stripes")
         dyn = {"tok_ft": kw["tok_ft"], "perm": kw["perm"], "lam": kw["lam"],
                "t_stripes": None if stripes is None else stripes[0], "f_stripes": None if stripes is None else stripes[1]}
-        key = ("train", tuple(x3.shape), dt, self.precision, kw["toffset"], str(x3.device),
-               tuple((k, None if v is None else tuple(v.shape)) for k, v in dyn.items()))
+        key = ("train", tuple(x3.shape), x3.dtype, dt, self.precision, kw["toffset"], str(x3.device), bool(eng.head_tail),
+               bool(self.training), tuple((k, None if v is None else tuple(v.shape)) for k, v in dyn.items()))
         st = self._graphs.get(key)
         if st is None:
             if len(self._graphs) >= 8:
                 self._graphs.clear()
-            self._graphs[key] = {"graph": None}
-            return eng.forward(x3, dt, save=True, **kw)
+            self._graphs[key] = {"graph": None, "lease": None}
+            return (*eng.forward(x3, dt, save=True, **kw), None)
+        if st["lease"] is not None and st["lease"]() is not None:
+            return (*eng.forward(x3, dt, save=True, **kw), None)
         if st["graph"] is None:
             sx = x3.clone()
             sdyn = {k: None if v is None else v.clone() for k, v in dyn.items()}
@@ -896,10 +933,12 @@ class MAEST(nn.Module):
                             for k, v in st["wcache"].items()}
             eng.w.epoch += 1
             eng._weights_dirty = True
+        lease = _GraphLease()
+        st["lease"] = weakref.ref(lease)
         st["graph"].replay()
         ctx = dict(st["ctx"])
         ctx["blocks"] = [dict(b) for b in st["ctx"]["blocks"]]      # backward empties these dicts as it goes
-        return tuple(o.clone() for o in st["outs"]), ctx
+        return tuple(o.clone() for o in st["outs"]), ctx, lease
 
     def predict_labels(self, x):
         with torch.no_grad():      # the result is detached anyway (maest.py:936-938): take the inference path

@@ -35,9 +35,6 @@ class _BCEWithLogitsFn(torch.autograd.Function):
         return ops.scale_dev_(dz, g.to(torch.float32).reshape(1).contiguous()), None, None, None, None
 
 
-_STAGING = []      # the last few pinned staging tensors of the per-step host draws
-
-
 def _mix_to_device(mix, device):
     """(perm, lam) host draws -> int32 / fp32 device tensors through pinned memory, without a stream-draining
     synchronous copy; done ONCE per step (the forward and the loss both consume them)."""
@@ -51,10 +48,9 @@ def _mix_to_device(mix, device):
         if t.device == dev:
             return t.contiguous()
         if dev.type == "cuda" and t.device.type == "cpu":
-            staged = t.contiguous().pin_memory()
-            _STAGING.append(staged)            # kept referenced while the asynchronous copy may still read it
-            del _STAGING[:-8]
-            return staged.to(dev, non_blocking=True)
+            # (the pinned block is not reused before the copy has run: torch's caching host allocator records the
+            # copy stream on it and holds the block back until that event has completed)
+            return t.contiguous().pin_memory().to(dev, non_blocking=True)
         return t.to(dev).contiguous()
     return put(perm, torch.int32), put(lam, torch.float32)
 
@@ -220,7 +216,9 @@ class Module(nn.Module):
     def get_optimizer(self, params=None):
         """models/module.py:237-243.  Same hyper-parameters as the reference; on the GPU the single-kernel ("fused")
         implementation of the same update: 0.6 ms instead of 1.7 ms per step for 85.9 M parameters."""
-        params = list(self.parameters() if params is None else params)
+        # the trained net's parameters only: the frozen SWA twin (a submodule here from __init__ on; the reference creates
+        # it in the SWA callback, after configure_optimizers) must not enter the optimizer's param groups / state_dict
+        params = list(self.net.parameters() if params is None else params)
         fused = bool(params) and all(p.is_cuda for p in params)
         if self.adamw:
             return torch.optim.AdamW(params, lr=self.lr, betas=(0.9, 0.999), eps=1e-08,

@@ -9,25 +9,16 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_ATOMIC, EPI_MUL, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F32, F32X3, call
+from ._lib import BF16, EPI_ATOMIC, EPI_MUL, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F16, F32, F32X3, call
 
 DT = {torch.float32: F32, torch.bfloat16: BF16}
 
-# "bf16x3" precision mode: tensors stay fp32, but the big matrix products (maest_gemm_nt, maest_attn_fwd) run as three
-# bf16 MFMAs on hi/lo splits of their fp32 operands (csrc/common.h: mma_chunk2).  The engine switches it per forward /
-# backward pass (single host thread per process, like the reference's callers).
-_F32_SPLIT = False
-
-
-def set_f32_split(on: bool):
-    global _F32_SPLIT
-    _F32_SPLIT = bool(on)
-
-
-def _mm_code(dtype):
-    """dtype code of a matrix-product operand: fp32 becomes MAEST_F32X3 while the split mode is on."""
-    return F32X3 if (_F32_SPLIT and dtype == torch.float32) else DT[dtype]
-
+def _mm_code(dtype, x3: bool):
+    """dtype code of a matrix-product operand.  `x3` ("bf16x3" precision mode): tensors stay fp32, but the product runs
+    as three bf16 MFMAs on hi/lo splits of the fp32 operands (csrc/common.h: mma_chunk2) -- MAEST_F32X3.  The mode is an
+    explicit argument of every matrix-product wrapper (the engine knows the model's mode); there is no process-wide
+    switch, so a direct fp32 caller always gets exact fp32 products whatever other models run in the process."""
+    return F32X3 if (x3 and dtype == torch.float32) else DT[dtype]
 
 
 class KernelTimer:
@@ -108,7 +99,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
             out: Optional[torch.Tensor] = None, out_dtype=None, epi: int = EPI_NONE,
             aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
             split_k: int = 1, M: Optional[int] = None, N: Optional[int] = None,
-            K: Optional[int] = None) -> torch.Tensor:
+            K: Optional[int] = None, x3: bool = False) -> torch.Tensor:
     """out[M,N] = epi(a[M,K] @ b[N,K]^T + bias).  a/b may carry padded leading dims (2-D views of
     bigger buffers): lda/ldb are taken from stride(0)."""
     assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype
@@ -131,13 +122,13 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     # timing bucket: the token-major GEMMs of the blocks apart from the few small ones (head, patch-embed remainder, the
     # last block's head-token rows), which run the 128x128 kernel and would blur the dominant kernel's figures
     _timed_call("maest_gemm_nt" if M >= 4096 else "maest_gemm_nt_small", 2.0 * M * N * K, _p(a), a.stride(0), _p(b),
-                b.stride(0), _mm_code(a.dtype), _p(out), out.stride(0), DT[out.dtype], M, N, K, _p(bias), epi, _p(aux_in),
+                b.stride(0), _mm_code(a.dtype, x3), _p(out), out.stride(0), DT[out.dtype], M, N, K, _p(bias), epi, _p(aux_in),
                 _p(aux_out), ld_aux, split_k, _s(a), _entry="maest_gemm_nt")
     return out
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, colsum: Optional[torch.Tensor] = None,
-            split_k: int = 1, M: Optional[int] = None, N: Optional[int] = None) -> torch.Tensor:
+            split_k: int = 1, M: Optional[int] = None, N: Optional[int] = None, x3: bool = False) -> torch.Tensor:
     """out[M,N] (fp32, pre-zeroed) += a[K,M]^T @ b[K,N];  colsum[M] (fp32, pre-zeroed) += a.sum(0)."""
     assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype and a.shape[0] == b.shape[0]
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.dtype == torch.float32
@@ -148,7 +139,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, colsum: Optiona
     for t in (a, b, out, colsum):
         if t is not None and not (t.is_cuda or _lib.host_emulation()):
             raise _lib.MaestHipError("maest_amd kernels need tensors on a HIP device; there is no CPU fallback")
-    _timed_call("maest_gemm_tn", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), _mm_code(a.dtype), _p(out2),
+    _timed_call("maest_gemm_tn", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), _mm_code(a.dtype, x3), _p(out2),
                 out2.stride(0), M, N, K, _p(colsum), split_k, _s(a))
     return out
 
@@ -252,7 +243,7 @@ def _attn_flops(B, N, q_rows, per_pair):
     return per_pair * B * HEADS * nq * N * HEAD_DIM
 
 
-def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False, q_rows=None):
+def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False, q_rows=None, x3: bool = False):
     """q_rows: only the first q_rows queries of every clip are wanted (rows beyond the 32-row tile that holds them are
     left unwritten in `out` / `lse`)."""
     _chk(qkv)
@@ -260,7 +251,7 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False, q_
     out = torch.empty((B * N, EMBED), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device) if save_lse else None
     _timed_call("maest_attn_fwd", _attn_flops(B, N, q_rows, 4.0), _p(qkv), _p(out), _p(lse), B, N,
-                _mm_code(qkv.dtype), scale, N if q_rows is None else q_rows, _s(qkv), _entry="maest_attn_fwd_rows")
+                _mm_code(qkv.dtype, x3), scale, N if q_rows is None else q_rows, _s(qkv), _entry="maest_attn_fwd_rows")
     return (out, lse) if save_lse else out
 
 
@@ -269,13 +260,13 @@ def attn_bwd_rows_supported(dtype, N: int) -> bool:
     return dtype == torch.bfloat16 and -(-N // 32) + 2 <= 12 and get_option("attn_bwd") == 0
 
 
-def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float, q_rows=None):
+def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float, q_rows=None, x3: bool = False):
     _chk(qkv, out, dout, lse)
     assert dout.dtype == qkv.dtype and out.dtype == qkv.dtype
     delta = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device)
     dqkv = torch.empty_like(qkv)
     _timed_call("maest_attn_bwd", _attn_flops(B, N, q_rows, 10.0), _p(qkv), _p(out), _p(dout), _p(lse),
-                _p(delta), _p(dqkv), B, N, _mm_code(qkv.dtype), scale, N if q_rows is None else q_rows, _s(qkv),
+                _p(delta), _p(dqkv), B, N, _mm_code(qkv.dtype, x3), scale, N if q_rows is None else q_rows, _s(qkv),
                 _entry="maest_attn_bwd_rows")
     return dqkv
 
@@ -300,10 +291,11 @@ def scatter_head_rows(xc: torch.Tensor, clips: int, n_tok: int, n_head: int, n_p
 
 
 def patch_im2col(x: torch.Tensor, tok_ft: torch.Tensor, dtype, perm=None, lam=None, t_stripes=None, f_stripes=None):
-    """x fp32 [B, F, T], tok_ft int32 [P, 2] -> im2col operand [B*P, 256] (SpecMasking stripes, mixup and patchout
-    fused).  t_stripes / f_stripes: int32 [B, n, 2] = (start, width) per clip, or None."""
+    """x fp32 or fp16 [B, F, T], tok_ft int32 [P, 2] -> im2col operand [B*P, 256] (SpecMasking stripes, mixup and
+    patchout fused; a float16 batch -- what the reference's loader hands out, discogs/dataset.py:58-67 -- is widened in
+    the load).  t_stripes / f_stripes: int32 [B, n, 2] = (start, width) per clip, or None."""
     _chk(x, tok_ft, perm, lam, t_stripes, f_stripes)
-    assert x.dtype == torch.float32 and x.dim() == 3 and tok_ft.dtype == torch.int32
+    assert x.dtype in (torch.float32, torch.float16) and x.dim() == 3 and tok_ft.dtype == torch.int32
     B, F, T = x.shape
     P = tok_ft.shape[0]
     n_t = n_f = 0
@@ -314,7 +306,7 @@ def patch_im2col(x: torch.Tensor, tok_ft: torch.Tensor, dtype, perm=None, lam=No
         assert f_stripes.dtype == torch.int32 and f_stripes.dim() == 3 and f_stripes.shape[0] == B and f_stripes.shape[2] == 2
         n_f = int(f_stripes.shape[1])
     out = torch.empty((B * P, 256), dtype=dtype, device=x.device)
-    call("maest_patch_im2col", _p(x), B, F, T, _p(perm), _p(lam), _p(tok_ft), P, _p(t_stripes) if n_t else None, n_t,
+    call("maest_patch_im2col", _p(x), F16 if x.dtype == torch.float16 else F32, B, F, T, _p(perm), _p(lam), _p(tok_ft), P, _p(t_stripes) if n_t else None, n_t,
          _p(f_stripes) if n_f else None, n_f, _p(out), DT[dtype], _s(x))
     return out
 

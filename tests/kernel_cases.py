@@ -297,6 +297,13 @@ def case_patch_embed(dev, dtype, B, T, patchout=0, mix=False, seed=30, masked=Fa
         xs = ops.spec_mask_(x.clone().to(dev), t_str.to(dev), f_str.to(dev))
         cols2 = ops.patch_im2col(xs, tok_dev, dtype)
         assert torch.equal(cols, cols2), "fused SpecMasking differs from spec_mask_ + im2col"
+    # a float16 batch (what the reference's loader hands out, discogs/dataset.py:58-67) widened inside the load must
+    # equal the same values passed as fp32, bit for bit
+    xh = x.half()
+    kw = dict(perm=None if perm is None else perm.to(dev), lam=None if lam is None else lam.to(dev),
+              t_stripes=None if t_str is None else t_str.to(dev), f_stripes=None if f_str is None else f_str.to(dev))
+    assert torch.equal(ops.patch_im2col(xh.to(dev), tok_dev, dtype, **kw),
+                       ops.patch_im2col(xh.float().to(dev), tok_dev, dtype, **kw)), "fp16 input path differs from x.float()"
     ref = F.unfold(xm.unsqueeze(1), kernel_size=16, stride=10)          # [B, 256, Fp*Tp]
     ref = ref.reshape(B, 256, Fp, Tp)
     if keep is not None:
@@ -494,27 +501,23 @@ def case_split_precision(dev, M=512, N=256, K=192, B=1, Ntok=75):
     a, b, bias, res = rnd((M, K), 50), rnd((N, K), 51), rnd((N,), 52), rnd((M, N), 53)
     ref = (a.double() @ b.double().t() + bias.double() + res.double())
     scale = ref.abs().max().item()
-    ops.set_f32_split(True)
-    try:
-        with ops.options(gemm_min_m=512):
-            c = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_dtype=torch.float32, epi=ops.EPI_RESIDUAL,
-                            aux_in=res.to(dev))
-        qkv = rnd((B * Ntok, 2304), 54)
-        out, lse = ops.attn_fwd(qkv.to(dev), B, Ntok, 0.125, save_lse=True)
-        # backward products: the wgrad form (256-tile TN kernel) and the attention backward
-        ta, tb = rnd((288, 256), 55), rnd((288, 512), 56)
-        tout = torch.zeros((256, 512), dtype=torch.float32, device=dev)
-        tcs = torch.zeros(256, dtype=torch.float32, device=dev)
-        with ops.options(gemm_variant=4):
-            ops.gemm_tn(ta.to(dev), tb.to(dev), tout, colsum=tcs, split_k=0)
-        xq = qkv.double().requires_grad_(True)
-        oref, lref = _attn_ref(xq, B, Ntok, 0.125)
-        dout = rnd((B * Ntok, 768), 57)
-        oref.backward(dout.double())
-        dqkv = ops.attn_bwd(qkv.to(dev), oref.detach().float().to(dev), dout.to(dev), lref.detach().float().contiguous().to(dev),
-                            B, Ntok, 0.125)
-    finally:
-        ops.set_f32_split(False)
+    with ops.options(gemm_min_m=512):
+        c = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_dtype=torch.float32, epi=ops.EPI_RESIDUAL,
+                        aux_in=res.to(dev), x3=True)
+    qkv = rnd((B * Ntok, 2304), 54)
+    out, lse = ops.attn_fwd(qkv.to(dev), B, Ntok, 0.125, save_lse=True, x3=True)
+    # backward products: the wgrad form (256-tile TN kernel) and the attention backward
+    ta, tb = rnd((288, 256), 55), rnd((288, 512), 56)
+    tout = torch.zeros((256, 512), dtype=torch.float32, device=dev)
+    tcs = torch.zeros(256, dtype=torch.float32, device=dev)
+    with ops.options(gemm_variant=4):
+        ops.gemm_tn(ta.to(dev), tb.to(dev), tout, colsum=tcs, split_k=0, x3=True)
+    xq = qkv.double().requires_grad_(True)
+    oref, lref = _attn_ref(xq, B, Ntok, 0.125)
+    dout = rnd((B * Ntok, 768), 57)
+    oref.backward(dout.double())
+    dqkv = ops.attn_bwd(qkv.to(dev), oref.detach().float().to(dev), dout.to(dev), lref.detach().float().contiguous().to(dev),
+                        B, Ntok, 0.125, x3=True)
     tref = ta.double().t() @ tb.double()
     et = (tout.double().cpu() - tref).abs().max().item() / tref.abs().max().item()
     assert et < 1e-4, f"split-bf16 TN GEMM: {et:.2e} of the output scale"

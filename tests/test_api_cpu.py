@@ -247,3 +247,27 @@ def test_explicit_patchout_draws_are_validated():
         net._resolve_tokens(12, 62, pinned=(3, keep))
     with pytest.raises(ValueError, match="kept time columns"):
         net._resolve_tokens(12, 40, pinned=(0, torch.tensor([0, 40])))
+
+
+def test_clone_carries_configuration_and_optimizer_sees_only_the_trained_net():
+    """copy.deepcopy / clone_weights (what the SWA callback does, helpers/swa_callback.py:9-44) keeps what
+    was changed after construction (patchout switched off, numeric mode, engine switches) and copies the parameters;
+    the optimizer of a module with an SWA twin holds the trained net's parameters only (the reference creates net_swa
+    after configure_optimizers)."""
+    import copy
+    import torch
+    from maest_amd import get_maest
+    from maest_amd.module import Module
+    net = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30, precision="bf16x3")
+    net.s_patchout_t = 0
+    net._engine.head_tail = False
+    net.eval()
+    twin = copy.deepcopy(net)
+    assert twin.s_patchout_t == 0 and twin.precision == "bf16x3" and twin._engine.head_tail is False and not twin.training
+    for (n, a), (_, b) in zip(twin.named_parameters(), net.named_parameters()):
+        assert torch.equal(a, b) and a.data_ptr() != b.data_ptr(), n
+    mod = Module(net=net, do_swa=True)
+    own = {id(p) for p in net.parameters()}
+    held = [p for g in mod.get_optimizer().param_groups for p in g["params"]]
+    assert len(held) == len(own) and all(id(p) in own for p in held)
+    assert not any(id(p) in own for p in mod.net_swa.parameters())

@@ -131,3 +131,38 @@ def test_validation_epoch_end_gathers_over_ranks_gloo():
         p.join(180)
         assert p.exitcode == 0, "worker failed"
     assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+
+
+def _one_rank_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from maest_amd.dist import GradReducer, init_from_env
+    assert init_from_env(backend="gloo", force=True) == (0, 0, 1) and dist.is_initialized()
+    params = [("blocks.0.mlp.fc1.weight", torch.nn.Parameter(torch.zeros(64, 8))),
+              ("norm.weight", torch.nn.Parameter(torch.zeros(8)))]
+    red = GradReducer(params, bucket_mb=0.0005, force_collective=True)
+    assert red.collective and len(red.buckets) == 2
+    red.reset()
+    for n in red.order:
+        red.grad_buffer(n).add_(3.0)
+        red.on_grad(n)
+    assert len(red._works) == 2          # both buckets were really exchanged
+    red.finish()
+    for n, p in params:
+        assert torch.equal(p.grad, torch.full_like(p, 3.0))      # one rank: identity, no 1/world scaling
+    plain = GradReducer(params)
+    assert not plain.collective
+    q.put("ok")
+    dist.destroy_process_group()
+
+
+def test_forced_collective_at_world_size_one_gloo():
+    """GradReducer(force_collective=True) behind a one-rank process group (init_from_env(force=True)): the bucket
+    all-reduces are issued and waited for although world == 1 -- the switch the GPU test uses to put RCCL on the
+    record with a single device (tests/tools/rccl_one_rank.py)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0, "worker failed"
+    assert q.get(timeout=5) == "ok"

@@ -169,3 +169,143 @@ def test_training_step_batch256_bf16_is_the_path_the_bench_times():
     print(f"bench path bf16 vs fp32 at B=256: loss {l16:.6f} vs {l32:.6f} (rel {le:.2e}); worst relative-L2 gradient "
           f"deviation {worst:.2e}\n  " + "\n  ".join(report))
     assert le < 3.5e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] / configs[4] at their per-GPU size: 30 s clips (96 x 1876), global batch 1024 over 8 GPUs = 128
+# clips per GPU (config_updates.py:143-148), s_patchout_t = 90 -> 875 tokens per clip in training (the bf16 step takes the
+# two-kernel attention backward, N > 320, and the 256-tile GEMMs at M = 112 000), 1685 tokens in evaluation.
+# Anchors to the oracle: test_30s_training_step_matches_the_oracle_fp32 (one clip, every gradient) and the two oracle
+# clips below.
+T30, B30 = 1876, 128
+
+
+def _model30(precision, n_classes=400, distilled_type="mean", **kw):
+    sd = O.make_state_dict(1875, n_classes=n_classes, seed=3131)
+    m = get_maest("discogs-maest-30s-pw-129e", pretrained=False, precision=precision, n_classes=n_classes,
+                  distilled_type=distilled_type, **kw)
+    m.load_state_dict(sd)
+    return m.to(DEV), sd
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_inference_30s_batch64_rows_are_independent_and_match_the_oracle(precision, gemm_options):
+    gemm_options(gemm_min_m=1024)          # the same GEMM kernel for the 2-clip (3370 rows) and the 64-clip batch
+    net, sd = _model30(precision)
+    net.eval()
+    Bi = 64
+    x = (0.2 * randn((Bi, 96, T30), 41) + 0.4).to(DEV)
+    with torch.no_grad():
+        full, feat = net(x)
+        assert full.shape == (Bi, 400) and torch.isfinite(full).all()
+        sel = [0, 63]
+        small, sfeat = net(x[sel])
+        assert torch.equal(full[sel], small), "a clip's logits must not depend on the batch around it"
+        assert torch.equal(feat[sel], sfeat)
+        perm = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).permutation(Bi)).to(DEV)
+        pl, _ = net(x[perm])
+        assert torch.equal(pl, full[perm]), "permuting the batch must permute the outputs"
+    want, wfeat = O.forward(x[sel].cpu(), sd, (96, 1875))
+    tol = 3e-2 if precision == "bf16" else 1e-3
+    e, ef = rel_err(small, want), rel_err(sfeat, wfeat)
+    print(f"30 s inference B=64 N=1685 {precision}: logits rel err {e:.2e}, features {ef:.2e}")
+    assert e < tol and ef < tol
+    if precision == "fp32":
+        assert torch.equal(small.cpu().argsort(dim=1, descending=True)[:, :10],
+                           want.argsort(dim=1, descending=True)[:, :10]), "top-10 label indices must be identical"
+
+
+def _grad_report(names, g32, g16, what, l32, l16, gate_norm=2e-2, gate_max=0.35, gate_loss=3.5e-4):
+    le = abs(l16 - l32) / abs(l32)
+    worst, report = 0.0, []
+    for n in names:
+        rms = g32[n].pow(2).mean().sqrt().item()
+        e_max = (g16[n] - g32[n]).abs().max().item() / max(rms, 1e-30)
+        e_norm = (g16[n] - g32[n]).norm().item() / max(g32[n].norm().item(), 1e-30)
+        report.append(f"{n}: |d|max/rms {e_max:.2e}  ||d||/||g|| {e_norm:.2e}")
+        worst = max(worst, e_norm)
+        assert e_norm < gate_norm, f"{what} {n}: bf16 gradient deviates from fp32 by {e_norm:.2e} (relative L2)"
+        assert e_max < gate_max, f"{what} {n}: bf16 gradient element off by {e_max:.2e} x RMS"
+    print(f"{what}: loss {l16:.6f} vs {l32:.6f} (rel {le:.2e}); worst relative-L2 gradient deviation {worst:.2e}\n  "
+          + "\n  ".join(report))
+    assert le < gate_loss, f"{what}: loss deviates by {le:.2e}"
+
+
+def test_training_step_30s_batch128_fp32_quarters_and_bf16():
+    """configs[3] per-GPU shape, B = 128 x (96 x 1876), patchout 90 (N = 875).  (a) fp32: the step equals the mean of
+    its four 32-clip quarter steps (mixup partners in-quarter) -- with the one-clip oracle test this carries the parity
+    of the small batch to the full one; (b) the bf16 step -- the path bench.py's `train30s` times: two-kernel attention
+    backward, gemm_nt256w at M = 112 000 -- against that fp32 step on the same draws, gates as at 10 s."""
+    x = randn((B30, 1, 96, T30), 51).to(DEV)
+    rng = np.random.Generator(np.random.PCG64(52))
+    y = torch.from_numpy((rng.random((B30, 400)) < 0.00625).astype(np.float32)).to(DEV)
+    Q = B30 // 4
+    perm = torch.cat([torch.from_numpy(rng.permutation(Q)) + q * Q for q in range(4)])
+    lam = torch.from_numpy(np.maximum(b := rng.beta(0.3, 0.3, B30).astype(np.float32), 1 - b))
+    Tp = (T30 - 16) // 10 + 1
+    keep = torch.from_numpy(np.sort(rng.permutation(Tp)[: Tp - 90]))
+    po = (0, keep)
+    names = ["blocks.0.attn.qkv.weight", "blocks.0.attn.qkv.bias", "blocks.4.attn.proj.weight", "blocks.6.mlp.fc1.weight",
+             "blocks.11.mlp.fc2.weight", "blocks.5.norm1.weight", "patch_embed.proj.weight", "time_new_pos_embed",
+             "freq_new_pos_embed", "cls_token", "head.1.weight", "norm.weight"]
+    res = {}
+    for precision in ("fp32", "bf16"):
+        net, _ = _model30(precision, input_t=1875, s_patchout_t=90)
+        net.train()
+        mod = Module(net=net, mixup_alpha=0.3)
+        params = dict(net.named_parameters())
+
+        def step(xs, ys, mix):
+            for p in net.parameters():
+                p.grad = None
+            loss = mod.training_step((xs, None, ys), 0, _mixup=mix, _patchout=po)
+            loss.backward()
+            return loss.item(), {n: params[n].grad.detach().float().clone() for n in names}
+
+        res[precision] = step(x, y, (perm, lam))
+        if precision == "fp32":
+            acc_loss, acc = 0.0, {n: torch.zeros_like(res["fp32"][1][n]) for n in names}
+            for q in range(4):
+                s = slice(q * Q, (q + 1) * Q)
+                lq, gq = step(x[s], y[s], (perm[s] - q * Q, lam[s]))
+                acc_loss += lq / 4
+                for n in names:
+                    acc[n] += gq[n] / 4
+            lf, gf = res["fp32"]
+            assert abs(lf - acc_loss) <= 2e-6 * abs(acc_loss), (lf, acc_loss)
+            for n in names:
+                e = rel_err(gf[n], acc[n])
+                assert e < 2e-4, f"{n}: full-batch gradient differs from the mean of the quarter steps by {e:.2e}"
+        del net, mod, params, step
+        torch.cuda.empty_cache()
+    (l32, g32), (l16, g16) = res["fp32"], res["bf16"]
+    _grad_report(names, g32, g16, "30 s training step B=128 N=875, bf16 vs fp32", l32, l16)
+
+
+def test_teacher_student_step_30s_batch128_from_waveforms_bf16_vs_fp32():
+    """configs[4] at its per-GPU size: 128 x 30 s of 16 kHz audio -> log-mel kernel -> mixup -> separated heads (519
+    classes) -> (BCE + BCE) / 2, bf16 against fp32 on the same draws (the B = 2 composite test anchors fp32 to the oracle)."""
+    from maest_amd.module import TeacherStudentModule
+    rng = np.random.Generator(np.random.PCG64(61))
+    w = torch.from_numpy((rng.random((B30, (T30 - 1) * 256), dtype=np.float32) * 2 - 1) * 0.5).to(DEV)
+    y = torch.from_numpy((rng.random((B30, 519)) < 0.005).astype(np.float32)).to(DEV)
+    yt = torch.from_numpy((rng.random((B30, 519)) < 0.005).astype(np.float32)).to(DEV)
+    perm = torch.from_numpy(rng.permutation(B30))
+    lam = torch.from_numpy(np.maximum(b := rng.beta(0.3, 0.3, B30).astype(np.float32), 1 - b))
+    Tp = (T30 - 16) // 10 + 1
+    keep = torch.from_numpy(np.sort(rng.permutation(Tp)[: Tp - 90]))
+    names = ["blocks.0.attn.qkv.weight", "blocks.7.mlp.fc2.weight", "blocks.11.attn.proj.weight", "head.1.weight",
+             "head_dist.weight", "dist_token", "patch_embed.proj.weight", "time_new_pos_embed"]
+    res = {}
+    for precision in ("fp32", "bf16"):
+        net, _ = _model30(precision, n_classes=519, distilled_type="separated", input_t=1875, s_patchout_t=90)
+        net.train()
+        mod = TeacherStudentModule(net=net, mixup_alpha=0.3)
+        loss = mod.training_step((w, None, y, yt), 0, _mixup=(perm, lam), _patchout=(0, keep))
+        loss.backward()
+        params = dict(net.named_parameters())
+        res[precision] = (loss.item(), {n: params[n].grad.detach().float().clone() for n in names})
+        del net, mod, params
+        torch.cuda.empty_cache()
+    (l32, g32), (l16, g16) = res["fp32"], res["bf16"]
+    _grad_report(names, g32, g16, "30 s teacher-student step B=128 from waveforms, bf16 vs fp32", l32, l16)

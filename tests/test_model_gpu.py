@@ -643,6 +643,19 @@ def test_hip_graph_captured_training_forward_equals_eager():
     for (l, g1, g2), (le, ge1, ge2) in zip(outs, [e1, e1, e2, e1]):
         assert abs(l - le) <= 3e-7 * abs(le), (l, le)
         assert rel_err(g1, ge1) < 1e-4 and rel_err(g2, ge2) < 1e-4
+    # two grad-enabled forwards of the same signature before either backward (two-view losses): the captured
+    # graph's static activation buffers belong to the first until its backward has run -- the second must not replay
+    net.zero_grad(set_to_none=True)
+    la = mod.training_step((x, None, y), 0, _mixup=mix, _patchout=po)
+    lb = mod.training_step((x, None, y), 0, _mixup=mix, _patchout=po)
+    leased = lambda: sum(st.get("lease") is not None and st["lease"]() is not None for st in net._graphs.values())
+    assert leased() == 1
+    (la + lb).backward()
+    del la, lb
+    assert leased() == 0
+    assert abs(la.item() - e1[0]) <= 3e-7 * abs(e1[0]) and abs(lb.item() - e1[0]) <= 3e-7 * abs(e1[0])
+    assert rel_err(net.blocks[5].mlp.fc1.weight.grad, 2 * e1[1]) < 1e-4
+    assert rel_err(net.patch_embed.proj.weight.grad, 2 * e1[2]) < 1e-4
     # an optimizer step between replays: the recast inside the graph must pick the new weights up
     opt = mod.get_optimizer()
     l0 = step(x, mix, po)[0]
@@ -732,6 +745,44 @@ def test_data_parallel_two_gpus_over_rccl():
     r = subprocess.run([sys.executable, tool, "--backend", "nccl"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "weights identical after 3 steps" in r.stdout
+
+
+def test_float16_batches_go_straight_into_the_operand_load():
+    """The reference's loader hands out float16 mel batches [B, 1, 96, T] (discogs/dataset.py:58-67) and the module
+    feeds them to the net as they are (models/module.py:77-86): here they are widened inside the patch-embedding
+    operand load, with no x.float() pass over the batch -- eval logits and a training step (mixup fused into the same
+    load) equal, bit for bit, the same values passed as fp32."""
+    g = np.load(os.path.join(GOLD, "g5_train_step.npz"))
+    net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision="fp32")
+    x, y, mix, po = _g5_batch(g)
+    xh = x.half()
+    net.eval()
+    with torch.no_grad():
+        a, fa = net(xh.clone())
+        b, fb = net(xh.float())
+    assert torch.equal(a, b) and torch.equal(fa, fb)
+    net.train()
+    mod = Module(net=net, mixup_alpha=0.3)
+    res = []
+    for xin in (xh, xh.float()):
+        net.zero_grad(set_to_none=True)
+        loss = mod.training_step((xin, None, y), 0, _mixup=mix, _patchout=po)
+        loss.backward()
+        res.append((loss.item(), net.patch_embed.proj.weight.grad.clone()))
+    assert res[0][0] == res[1][0]
+    assert rel_err(res[0][1], res[1][1]) < 1e-6       # (split-K atomics order)
+
+
+def test_data_parallel_rccl_one_rank_forced_collective():
+    """RCCL on the record with one GPU: backend "nccl" at world size 1, every bucket all-reduce of three real training
+    steps forced through librccl (asynchronous launch from the wgrad side stream, wait in finish(), fused AdamW on the
+    bucket views); results bit-identical to the same steps without a collective (tests/tools/rccl_one_rank.py)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "rccl_one_rank.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "weights and gradients identical" in r.stdout
 
 
 def test_validation_loop_matches_the_oracle_and_scikit_learn():
