@@ -140,37 +140,58 @@ __device__ __forceinline__ void stage256_pair(char* smem, int region, const f32x
         }
 }
 
+// The second operand of the RESIDUAL / MUL epilogues (aux_in, 16 bytes per output chunk) for one staging pass, fetched
+// into registers BEFORE the pass is staged: the loads fly under the LDS staging and the barrier instead of sitting, four
+// at a time, between the LDS read and the store of the drain loop (each batch a full L2-miss latency: the dgrad through
+// GELU' -- 128 KiB of aux per tile, nowhere in cache -- spent a third of its tile time there).  Rows beyond M are clamped
+// (loaded, never stored): an unconditional load keeps the compiler from waiting for it at a join.
+template <int OSZ, int ROWS, int NTH = 512>
+struct AuxRegs {
+    static constexpr int CPR = 256 * OSZ / 16;
+    static constexpr int NCH = ROWS * CPR / NTH;
+    chunk16 v[NCH];
+    __device__ __forceinline__ void load(const void* aux, int64_t ld_aux, int mbase, int n0, int M, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTH;
+            const int row = c / CPR, cc = c - row * CPR;
+            int gm = mbase + row;
+            gm = gm < M ? gm : M - 1;
+            v[i] = *reinterpret_cast<const chunk16*>(reinterpret_cast<const char*>(aux) +
+                                                     ((int64_t)gm * ld_aux + n0 + cc * (16 / OSZ)) * OSZ);
+        }
+    }
+};
+
+template <int OSZ, int MODE>
+__device__ __forceinline__ chunk16 apply_aux(chunk16 v, const chunk16& r) {
+    if (MODE == 1 || (MODE == 2 && OSZ == 4)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = MODE == 1 ? f2u(u2f(v[e]) + u2f(r[e])) : f2u(u2f(v[e]) * u2f(r[e]));
+    } else if (MODE == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t vw = v[e], rw = r[e];
+            const float lo = u2f(vw << 16) * u2f(rw << 16);
+            const float hi = u2f(vw & 0xffff0000u) * u2f(rw & 0xffff0000u);
+            v[e] = pack_bf2(lo, hi);
+        }
+    }
+    return v;
+}
+
 template <int OSZ, int MODE, int ROWS = Epi256<OSZ>::ROWS>
-__device__ __forceinline__ void drain256(const char* smem, void* dst, int64_t ld, const void* aux, int64_t ld_aux,
+__device__ __forceinline__ void drain256(const char* smem, void* dst, int64_t ld, const AuxRegs<OSZ, ROWS>* aux,
                                          int mbase, int n0, int M, int N, int tid) {
     using E = Epi256<OSZ>;
-#pragma unroll 4
-    for (int c = tid; c < ROWS * E::CPR; c += 512) {
+#pragma unroll
+    for (int i = 0; i < ROWS * E::CPR / 512; ++i) {
+        const int c = tid + i * 512;
         const int row = c / E::CPR, cc = c - row * E::CPR;
         const int gm = mbase + row, gn = n0 + cc * E::EPC;
-        if (gm >= M || gn >= N) continue;
         chunk16 v = *reinterpret_cast<const chunk16*>(smem + row * E::PITCH + cc * 16);
-        if (MODE == 1) {
-            const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(aux) + (int64_t)gm * ld_aux + gn);
-            v[0] = f2u(u2f(v[0]) + r.x); v[1] = f2u(u2f(v[1]) + r.y);
-            v[2] = f2u(u2f(v[2]) + r.z); v[3] = f2u(u2f(v[3]) + r.w);
-        } else if (MODE == 2) {
-            if (OSZ == 4) {
-                const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(aux) + (int64_t)gm * ld_aux + gn);
-                v[0] = f2u(u2f(v[0]) * r.x); v[1] = f2u(u2f(v[1]) * r.y);
-                v[2] = f2u(u2f(v[2]) * r.z); v[3] = f2u(u2f(v[3]) * r.w);
-            } else {
-                const chunk16 r = *reinterpret_cast<const chunk16*>(reinterpret_cast<const bf16_t*>(aux) + (int64_t)gm * ld_aux + gn);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t vw = v[e], rw = r[e];
-                    const float lo = bf2f((bf16_t)(vw & 0xffffu)) * bf2f((bf16_t)(rw & 0xffffu));
-                    const float hi = bf2f((bf16_t)(vw >> 16)) * bf2f((bf16_t)(rw >> 16));
-                    v[e] = pack_bf2(lo, hi);
-                }
-            }
-        }
-        // streaming output: written once, re-read by a later kernel after > L2-size of other traffic
+        if (MODE != 0) v = apply_aux<OSZ, MODE>(v, aux->v[i]);
+        if (gm >= M || gn >= N) continue;
         // streaming output: written once, re-read by a later kernel after > L2-size of other traffic
         __builtin_nontemporal_store(v, reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ));
     }
@@ -191,12 +212,13 @@ __device__ __forceinline__ void epilogue256(char* smem, const f32x16_t (&acc)[2]
             const int mbase = m0 + pwm * 128 + mt0 * 32;
             if (wm == pwm) stage256_pair<OSZ, EXACT, PMT>(smem, REGION, acc, p.bias, n0, p.N, mt0, wn, lane);
             __syncthreads();
-            drain256<OSZ, 0, PR>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
-            drain256<OSZ, 0, PR>(smem + REGION, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
+            drain256<OSZ, 0, PR>(smem, p.C, p.ldc, nullptr, mbase, n0, p.M, p.N, tid);
+            drain256<OSZ, 0, PR>(smem + REGION, p.aux_out, p.ld_aux, nullptr, mbase, n0, p.M, p.N, tid);
             __syncthreads();
         }
         return;
     }
+    const bool with_aux = p.epi == MAEST_EPI_RESIDUAL || p.epi == MAEST_EPI_MUL;   // block-uniform
 #pragma unroll
     for (int ps = 0; ps < E::PASSES; ++ps) {
         const int pwm = ps / (4 / E::MT);
@@ -204,24 +226,20 @@ __device__ __forceinline__ void epilogue256(char* smem, const f32x16_t (&acc)[2]
         const int mbase = m0 + pwm * 128 + mt0 * 32;
         const bool mine = (wm == pwm);   // wave-uniform
         if (p.epi == MAEST_EPI_GELU) {
-            if (p.aux_out != nullptr) {
-                if (mine) stage256<OSZ, 2, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
-                __syncthreads();
-                drain256<OSZ, 0>(smem, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
-                __syncthreads();
-            }
             if (mine) stage256<OSZ, 1, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
             __syncthreads();
-            drain256<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
+            drain256<OSZ, 0, E::ROWS>(smem, p.C, p.ldc, nullptr, mbase, n0, p.M, p.N, tid);
         } else {
+            AuxRegs<OSZ, E::ROWS> ax;
+            if (with_aux) ax.load(p.aux_in, p.ld_aux, mbase, n0, p.M, tid);      // in flight across the staging
             if (mine) stage256<OSZ, 0, EXACT>(smem, acc, p.bias, n0, p.N, mt0, wn, lane);
             __syncthreads();
             if (p.epi == MAEST_EPI_RESIDUAL)
-                drain256<OSZ, 1>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
+                drain256<OSZ, 1, E::ROWS>(smem, p.C, p.ldc, &ax, mbase, n0, p.M, p.N, tid);
             else if (p.epi == MAEST_EPI_MUL)
-                drain256<OSZ, 2>(smem, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
+                drain256<OSZ, 2, E::ROWS>(smem, p.C, p.ldc, &ax, mbase, n0, p.M, p.N, tid);
             else
-                drain256<OSZ, 0>(smem, p.C, p.ldc, nullptr, 0, mbase, n0, p.M, p.N, tid);
+                drain256<OSZ, 0, E::ROWS>(smem, p.C, p.ldc, nullptr, mbase, n0, p.M, p.N, tid);
         }
         __syncthreads();
     }
@@ -542,20 +560,29 @@ __device__ __forceinline__ void epilogueW_run(char* smem, const f32x16_t (&acc)[
                 else stageT<OSZ, 0, EXACT, 256>(buf, 0, acc[0][mt], acc[1][mt], p.bias, n0, p.N, wm * 32, wn, lane);
             }
     };
+    // aux_in of the RESIDUAL / MUL forms: fetched one pass ahead into registers (see AuxRegs)
+    AuxRegs<OSZ, 32> ax[2][2];                                  // [pass parity][32-row group]
+    auto prefetch = [&](int ps) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+            ax[ps & 1][half].load(p.aux_in, p.ld_aux, m0 + half * 128 + ps * 32, n0, p.M, tid);
+    };
     auto drain = [&](int ps, const char* buf) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                  // the two 32-row groups of the pass are 128 rows apart
             const int mbase = m0 + half * 128 + ps * 32;
             const char* src = buf + half * 32 * E::PITCH;
-            drainT<OSZ, MODE, 256, 512>(src, 32, p.C, p.ldc, p.aux_in, p.ld_aux, mbase, n0, p.M, p.N, tid);
-            if (PAIR) drainT<OSZ, 0, 256, 512>(src + REGION, 32, p.aux_out, p.ld_aux, nullptr, 0, mbase, n0, p.M, p.N, tid);
+            drain256<OSZ, MODE, 32>(src, p.C, p.ldc, &ax[ps & 1][half], mbase, n0, p.M, p.N, tid);
+            if (PAIR) drain256<OSZ, 0, 32>(src + REGION, p.aux_out, p.ld_aux, nullptr, mbase, n0, p.M, p.N, tid);
         }
     };
+    if (MODE != 0) prefetch(0);
     stage(0, smem);
     __syncthreads();
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         char* cur = smem + (DOUBLE ? (ps & 1) * BUF : 0);
+        if (MODE != 0 && ps < 3) prefetch(ps + 1);
         drain(ps, cur);
         if (!DOUBLE && ps < 3) __syncthreads();                 // single buffer: everybody has drained before the refill
         if (ps < 3) stage(ps + 1, smem + (DOUBLE ? ((ps + 1) & 1) * BUF : 0));
@@ -596,7 +623,57 @@ __device__ __forceinline__ void epilogueW(char* smem, const f32x16_t (&acc)[2][4
 #else
 #define MAEST_LOOP_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
-template <typename T, int EPIV, bool X3 = false>
+// ---- epilogue of the 128-row variant (MTW = 2: each wave owns 64 x 64 outputs): both wave groups stage their m-tiles at
+// once -- the whole 128 x 256 tile (two passes of 64 rows for the fp32 value + GELU' pair, which would not fit) -- one
+// barrier, then the drain with aux_in prefetched into registers before the staging.
+template <int OSZ, bool EXACT, int MODE, bool PAIR>
+__device__ __forceinline__ void epilogueH_run(char* smem, const f32x16_t (&acc)[2][2], const Gemm256Params& p, int m0,
+                                              int n0, int wm, int wn, int lane, int tid, bool gelu) {
+    using E = EpiT<OSZ, 256>;
+    constexpr int PMT = (PAIR && OSZ == 4) ? 1 : 2;             // m-tiles per wave and pass
+    constexpr int GR = 32 * PMT;                                // rows per wave group and pass
+    constexpr int REGION = 2 * GR * E::PITCH;                   // value region; the GELU' region follows
+#pragma unroll
+    for (int ps = 0; ps < 2 / PMT; ++ps) {
+        AuxRegs<OSZ, GR> ax[2];
+        if (MODE != 0) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) ax[g].load(p.aux_in, p.ld_aux, m0 + g * 64 + ps * GR, n0, p.M, tid);
+        }
+#pragma unroll
+        for (int mi = 0; mi < PMT; ++mi) {
+            const int mt = ps * PMT + mi;
+            const int lrow = wm * GR + mi * 32;
+            if (PAIR) stageT<OSZ, 3, EXACT, 256>(smem, REGION, acc[0][mt], acc[1][mt], p.bias, n0, p.N, lrow, wn, lane);
+            else if (gelu) stageT<OSZ, 1, EXACT, 256>(smem, 0, acc[0][mt], acc[1][mt], p.bias, n0, p.N, lrow, wn, lane);
+            else stageT<OSZ, 0, EXACT, 256>(smem, 0, acc[0][mt], acc[1][mt], p.bias, n0, p.N, lrow, wn, lane);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int mbase = m0 + g * 64 + ps * GR;
+            const char* src = smem + g * GR * E::PITCH;
+            drain256<OSZ, MODE, GR>(src, p.C, p.ldc, &ax[g], mbase, n0, p.M, p.N, tid);
+            if (PAIR) drain256<OSZ, 0, GR>(src + REGION, p.aux_out, p.ld_aux, nullptr, mbase, n0, p.M, p.N, tid);
+        }
+        if (ps + 1 < 2 / PMT) __syncthreads();
+    }
+}
+template <int OSZ, bool EXACT>
+__device__ __forceinline__ void epilogueH(char* smem, const f32x16_t (&acc)[2][2], const Gemm256Params& p, int m0,
+                                          int n0, int wm, int wn, int lane, int tid) {
+    const bool gelu = p.epi == MAEST_EPI_GELU;
+    if (gelu && p.aux_out != nullptr) epilogueH_run<OSZ, EXACT, 0, true>(smem, acc, p, m0, n0, wm, wn, lane, tid, true);
+    else if (p.epi == MAEST_EPI_RESIDUAL) epilogueH_run<OSZ, EXACT, 1, false>(smem, acc, p, m0, n0, wm, wn, lane, tid, false);
+    else if (p.epi == MAEST_EPI_MUL) epilogueH_run<OSZ, EXACT, 2, false>(smem, acc, p, m0, n0, wm, wn, lane, tid, false);
+    else epilogueH_run<OSZ, EXACT, 0, false>(smem, acc, p, m0, n0, wm, wn, lane, tid, gelu);
+}
+
+// MTW = 32-row m-tiles per wave: 4 -> the 256 x 256 tile described above; 2 -> a 128 x 256 tile (64 x 64 outputs per wave,
+// A units of 128 rows in the same 32 KiB ring slots, EPIV ignored), used for the LAST PARTIAL ROUND of a launch: with
+// 870 tiles on 256 CUs (the N = 768 shapes at M = 74240) the fourth round runs 102 workgroups on an otherwise idle chip;
+// as 204 half tiles it fills the chip once and takes about half the time (gemm_nt256_try).
+template <typename T, int EPIV, bool X3 = false, int MTW = 4>
 __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -604,57 +681,68 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     const int wave = tid >> 6;          // 0..7
     const int wm = wave >> 2, wn = wave & 3;
     const int h = lane >> 5;
+    constexpr int NA = MTW;             // LDS-DMA instructions per wave and A unit (8 rows each): 4 / 2
+    constexpr int BM = 64 * MTW;        // tile rows: 256 / 128
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
     const int tile_m = wg / p.tiles_n;
     const int tile_n = wg - tile_m * p.tiles_n;
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int m0 = tile_m * BM, n0 = tile_n * 256;
 
     constexpr int ELT = (int)sizeof(T);
     constexpr int KS = W2_ROWB / ELT;        // 64 / 32 elements per stage
     const int nstages = p.K / KS;
 
-    // LDS-DMA map: instruction i (0..3) of this wave fills rows [(wave*4+i)*8, +8) of a unit; lane -> (row, chunk)
-    const char* a_src[4];
+    // LDS-DMA map: instruction i of this wave fills rows [(wave*NA+i)*8, +8) of an A unit, [(wave*4+i)*8, +8) of a B unit
+    const char* a_src[NA];
     const char* b_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + (lane >> 3);
         const int csrc = (lane & 7) ^ ((r >> 1) & 7);        // source-side swizzle
-        int ra = m0 + r;
-        if (ra > p.M - 1) ra = p.M - 1;
         int rb = n0 + r;
         if (rb > p.N - 1) rb = p.N - 1;
-        a_src[i] = p.A + (int64_t)ra * p.lda * ELT + csrc * 16;
         b_src[i] = p.B + (int64_t)rb * p.ldb * ELT + csrc * 16;
     }
-    const int dma_off = wave * 4 * 1024;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int r = (wave * NA + i) * 8 + (lane >> 3);
+        const int csrc = (lane & 7) ^ ((r >> 1) & 7);
+        int ra = m0 + r;
+        if (ra > p.M - 1) ra = p.M - 1;
+        a_src[i] = p.A + (int64_t)ra * p.lda * ELT + csrc * 16;
+    }
+    const int dma_off_a = wave * NA * 1024, dma_off_b = wave * 4 * 1024;
 
-    f32x16_t acc[2][4];   // [nt][mt]
+    f32x16_t acc[2][MTW];   // [nt][mt]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < MTW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // one LDS-DMA instruction of unit (stage, A | B) into ring buffer `buf`; past-the-end stages re-load the last stage
+    // into a dead buffer (keeps the vmcnt arithmetic uniform)
+    auto issue_one = [&](int stage, bool is_b, int buf, int i) {
+        const int sc = stage < nstages ? stage : nstages - 1;
+        const char* src = (is_b ? b_src[i] : a_src[i < NA ? i : 0]) + (int64_t)sc * W2_ROWB;
+        char* dst = smem + buf * W2_UNIT + (is_b ? dma_off_b : dma_off_a) + i * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
     // unit u = 2*stage + (0: A, 1: B) lives in buffer u % NBUF
     auto issue_unit = [&](int stage, bool is_b, int buf) {
-        const int sc = stage < nstages ? stage : nstages - 1;   // past-the-end: re-load the last stage into a dead buffer
-        char* dst = smem + buf * W2_UNIT + dma_off;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const char* src = (is_b ? b_src[i] : a_src[i]) + (int64_t)sc * W2_ROWB;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)
+            if (is_b || i < NA) issue_one(stage, is_b, buf, i);
     };
 
-    int a_off[4], b_off[2], a_swz[4], b_swz[2];
+    int a_off[MTW], b_off[2], a_swz[MTW], b_swz[2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int row = wm * 128 + mt * 32 + (lane & 31);
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int row = wm * (32 * MTW) + mt * 32 + (lane & 31);
         a_off[mt] = row * W2_ROWB;
         a_swz[mt] = (row >> 1) & 7;
     }
@@ -665,10 +753,10 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
         b_swz[nt] = (row >> 1) & 7;
     }
 
-    chunk16 fa[2][4], fb[2][2];
+    chunk16 fa[2][MTW], fb[2][2];
 #ifdef MAEST_ABLATE_NO_DSREAD
     for (int i = 0; i < 2; ++i) {
-        for (int j = 0; j < 4; ++j) fa[i][j] = chunk16{0x3f803f80u + (uint32_t)lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        for (int j = 0; j < MTW; ++j) fa[i][j] = chunk16{0x3f803f80u + (uint32_t)lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
         for (int j = 0; j < 2; ++j) fb[i][j] = chunk16{0x3f803f80u, 0x3f803f80u + (uint32_t)lane, 0x3f803f80u, 0x3f803f80u};
     }
 #endif
@@ -682,32 +770,31 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
         for (int ks = 0; ks < 2; ++ks) {
             const int kc = 4 * kh + 2 * ks + h;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
                 fa[ks][mt] = *reinterpret_cast<const chunk16*>(la + a_off[mt] + ((kc ^ a_swz[mt]) << 4));
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 fb[ks][nt] = *reinterpret_cast<const chunk16*>(lb + b_off[nt] + ((kc ^ b_swz[nt]) << 4));
         }
     };
-    // COMPUTE phase with one operand unit's DMA (4 instructions of this wave) spread between the 16 MFMAs: the
+    // COMPUTE phase with one operand unit's DMA (this wave's 4 -- or NA -- instructions) spread between the MFMAs: the
     // memory front end accepts about one 8-line instruction per 30 clk per CU, so the four waves of a group
     // feed it at exactly its rate, never in a burst, and a wave is never parked in the queue while it owes MFMAs.
     auto compute = [&](bool dma, int stage, bool is_b, int buf) {
-        const int sc = stage < nstages ? stage : nstages - 1;   // past-the-end: re-load the last stage into a dead buffer
-        char* dst = smem + buf * W2_UNIT + dma_off;
+        const int ndma = is_b ? 4 : NA;
         __builtin_amdgcn_s_setprio(1);
         if constexpr (X3) {
             // split-bf16: the two k chunks of a fragment pair feed ONE K = 16 MFMA triple (common.h: mma_chunk2)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MTW; ++mt) {
                     mma_chunk2<T, true>(acc[nt][mt], fb[0][nt], fb[1][nt], fa[0][mt], fa[1][mt]);
-                    if (dma && (mt & 1)) {
-                        const int i = nt * 2 + (mt >> 1);
-                        const char* src = (is_b ? b_src[i] : a_src[i]) + (int64_t)sc * W2_ROWB;
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                    if (MTW == 4) {
+                        if (dma && (mt & 1)) issue_one(stage, is_b, buf, nt * 2 + (mt >> 1));
+                    } else {
+                        const int i = nt * 2 + mt;
+                        if (dma && i < ndma) issue_one(stage, is_b, buf, i);
                     }
                 }
             }
@@ -717,18 +804,14 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MTW; ++mt) {
 #ifndef MAEST_ABLATE_NO_MFMA
                     mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
 #endif
                 }
 #ifndef MAEST_ABLATE_NO_DMA
-                if (dma) {
-                    const int i = ks * 2 + nt;
-                    const char* src = (is_b ? b_src[i] : a_src[i]) + (int64_t)sc * W2_ROWB;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-                }
+                const int i = ks * 2 + nt;
+                if (dma && i < ndma) issue_one(stage, is_b, buf, i);
 #endif
             }
         }
@@ -742,7 +825,7 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     issue_unit(1, false, 2);
     issue_unit(1, true, 3);
     issue_unit(2, false, 4);
-    MAEST_WAIT_VMCNT(12);            // stage 0 landed (this wave's share)
+    MAEST_WAIT_VMCNT(2 * NA + 4);    // stage 0 landed (this wave's share): A_1 B_1 A_2 may still fly
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger (wave-uniform)
     // Per stage j, group A (wm == 0) passes barriers  b1 b2 b3 b4  as
@@ -753,7 +836,8 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     // Refills ride inside COMPUTE phases (see compute()):
     //   group A: COMPUTE(j,0) B_{j+1} -> A_{j-1}'s buffer,  COMPUTE(j,1) A_{j+2} -> B_{j-1}'s buffer
     //   group B: COMPUTE(j,0) A_{j+2} -> B_{j-1}'s buffer,  COMPUTE(j,1) B_{j+2} -> A_j's buffer (free since b4(j))
-    // so that every load has at least three phases to land; only the A unit issued last may still fly at b4.
+    // so that every load has at least three phases to land; only the A unit issued last (NA instructions) may still
+    // fly at b4.
     int abuf = 0, bbuf = 1;          // buffers of A_j, B_j
     for (int j = 0; j < nstages; ++j) {
         const int abuf_prev = next(abuf, W2_NBUF - 2), bbuf_prev = next(bbuf, W2_NBUF - 2);
@@ -769,12 +853,12 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
             MAEST_LOOP_BARRIER();           // b3
             compute(j > 0, j + 2, false, bbuf_prev);
 #ifndef MAEST_ABLATE_NO_VMWAIT
-            MAEST_WAIT_VMCNT(4);
+            MAEST_WAIT_VMCNT(NA);
 #endif
             MAEST_LOOP_BARRIER();           // b4
         } else {
 #ifndef MAEST_ABLATE_NO_VMWAIT
-            __builtin_amdgcn_s_waitcnt(0x0074);     // vmcnt(4) lgkmcnt(0)
+            __builtin_amdgcn_s_waitcnt(0x0070 | NA);     // vmcnt(NA) lgkmcnt(0)
 #else
             __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
@@ -788,7 +872,10 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();          // un-stagger
     MAEST_WAIT_VMCNT(0);   // drain the past-the-end loads before LDS is reused
     __syncthreads();       // LDS becomes the C staging area
-    if (EPIV == 0) {        // two-pass epilogue of the 64-byte-slice kernel
+    if constexpr (MTW == 2) {
+        if (p.out_dtype == MAEST_BF16) epilogueH<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+        else epilogueH<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
+    } else if (EPIV == 0) { // two-pass epilogue of the 64-byte-slice kernel
         if (p.out_dtype == MAEST_BF16) epilogue256<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
         else epilogue256<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
     } else if (EPIV == 1) { // four passes, double buffered
@@ -800,11 +887,11 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     }
 }
 
-template <typename T, int EPIV, bool X3 = false>
+template <typename T, int EPIV, bool X3 = false, int MTW = 4>
 static int launch256w(Gemm256Params& p, hipStream_t stream) {
     static DeviceOnce once;
-    ensure_dynamic_lds(once, &gemm_nt256w_kernel<T, EPIV, X3>, W2_SMEM);
-    hipLaunchKernelGGL((gemm_nt256w_kernel<T, EPIV, X3>), dim3(p.tiles_m * p.tiles_n), dim3(512), W2_SMEM, stream, p);
+    ensure_dynamic_lds(once, &gemm_nt256w_kernel<T, EPIV, X3, MTW>, W2_SMEM);
+    hipLaunchKernelGGL((gemm_nt256w_kernel<T, EPIV, X3, MTW>), dim3(p.tiles_m * p.tiles_n), dim3(512), W2_SMEM, stream, p);
     return check_launch("maest_gemm_nt(256w)");
 }
 
@@ -976,10 +1063,50 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
         // one-pass form never.  MAEST_OPT_GEMM_EPILOGUE = 0 / 1 / 2 forces one of them (-1 = this default).
         const int eopt = option(MAEST_OPT_GEMM_EPILOGUE);
         const int ev = eopt >= 0 ? eopt : (epi == MAEST_EPI_RESIDUAL ? 1 : 0);
-        if (x3) return ev == 1 ? launch256w<float, 1, true>(p, stream) : launch256w<float, 0, true>(p, stream);
-        if (ev == 1) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 1>(p, stream) : launch256w<float, 1>(p, stream);
-        if (ev == 2) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 2>(p, stream) : launch256w<float, 2>(p, stream);
-        return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 0>(p, stream) : launch256w<float, 0>(p, stream);
+        auto full = [&](Gemm256Params& q) {
+            if (x3) return ev == 1 ? launch256w<float, 1, true>(q, stream) : launch256w<float, 0, true>(q, stream);
+            if (ev == 1) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 1>(q, stream) : launch256w<float, 1>(q, stream);
+            if (ev == 2) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 2>(q, stream) : launch256w<float, 2>(q, stream);
+            return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 0>(q, stream) : launch256w<float, 0>(q, stream);
+        };
+        auto half = [&](Gemm256Params& q) {        // 128 x 256 tiles (gemm_nt256w_kernel, MTW = 2)
+            q.tiles_m = (q.M + 127) / 128;
+            if (x3) return launch256w<float, 0, true, 2>(q, stream);
+            return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 0, false, 2>(q, stream) : launch256w<float, 0, false, 2>(q, stream);
+        };
+        // The last partial round.  One workgroup per CU and equal tiles: a launch runs in ceil(tiles / 256) rounds and the
+        // last one may be nearly empty (N = 768 at M = 74240: 870 tiles = 3.4 rounds -- measured 1093 TFLOP/s against
+        // 1226 at M = 65280, exactly 3 rounds).  When at most half a round is left over, the rows of the full rounds
+        // go to one launch and the remaining rows to a second one in 128-row tiles (twice the workgroups, about half the
+        // time each): 3 + ~0.6 instead of 4 rounds.  MAEST_OPT_GEMM_TAIL: 0 off, 1 (default) automatic, 2 every tile a
+        // 128-row tile (tests).
+        const int tail = option(MAEST_OPT_GEMM_TAIL);
+        if (tail == 2) return half(p);
+        const int ncu = 256;
+        const int tiles = p.tiles_m * p.tiles_n;
+        const int rounds = tiles / ncu;
+        if (tail == 1 && rounds >= 1 && tiles % ncu != 0) {
+            const int mf = rounds * ncu / p.tiles_n;            // m-tiles of the full rounds
+            const int rows_left = M - mf * 256;
+            const int half_wgs = ((rows_left + 127) / 128) * p.tiles_n;
+            if (mf > 0 && rows_left > 0 && half_wgs <= ncu) {
+                const int64_t esz = in_dtype == MAEST_BF16 ? 2 : 4, osz = out_dtype == MAEST_BF16 ? 2 : 4;
+                Gemm256Params a = p, b = p;
+                a.M = mf * 256;
+                a.tiles_m = mf;
+                const int rc = full(a);
+                if (rc != MAEST_OK) return rc;
+                const int64_t r0 = (int64_t)mf * 256;
+                b.M = rows_left;
+                b.A = p.A + r0 * lda * esz;
+                b.C = (char*)C + r0 * ldc * osz;
+                // aux_in: fp32 for RESIDUAL, the output dtype for MUL; aux_out (GELU'): the output dtype
+                if (aux_in) b.aux_in = (const char*)aux_in + r0 * ld_aux * (epi == MAEST_EPI_RESIDUAL ? 4 : osz);
+                if (aux_out) b.aux_out = (char*)aux_out + r0 * ld_aux * osz;
+                return half(b);
+            }
+        }
+        return full(p);
     }
     if (variant != 2 && (N % 256) == 0) {
         p.tiles_n = N / 256;

@@ -41,6 +41,14 @@ def test_emu_gemm_256_tile_full_line_stages(emu, dtype, gemm_options):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_emu_gemm_128_row_tiles_of_the_last_partial_round(emu, dtype, gemm_options):
+    """gemm_nt256w_kernel<MTW = 2>: 128 x 256 tiles (A units of 128 rows in the same ring, vmcnt(2) waits, one-pass
+    epilogue with the aux operand prefetched), forced onto every tile; 576 rows = 4.5 tiles (ragged last tile)."""
+    gemm_options(gemm_min_m=512, gemm_tail=2)
+    KC.case_gemm(emu, dtype, 576, 256, 192 if dtype == torch.float32 else 384, identity=False)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_emu_gemm_tn_256_tile_lds_dma_kernel(emu, dtype, gemm_options):
     """M, N multiples of 256 and K a multiple of the slice route to gemm256.hip:gemm_tn256_kernel."""
     gemm_options(gemm_variant=4)   # take the 256-tile kernel although there are only 2 tiles

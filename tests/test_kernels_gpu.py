@@ -26,6 +26,26 @@ def test_gemm_big_tile_kernels_at_small_m(dtype, shape, gemm_options):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(1120, 2304, 768), (2560, 768, 3072)])
+def test_gemm_128_row_tiles_forced(dtype, shape, gemm_options):
+    """gemm_nt256w_kernel<MTW = 2> (the kernel of the last partial round) on every tile, every epilogue"""
+    gemm_options(gemm_min_m=512, gemm_tail=2)
+    KC.case_gemm(DEV, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_last_partial_round_split(dtype):
+    """66000 x 768: 774 tiles of 256 rows = 3 rounds + 6 tiles -> rows 0..65535 in 256-row tiles, the remaining 464
+    rows (3.6 tiles of 128, ragged) in a second launch through offset pointers -- every epilogue and its aux operand"""
+    KC.case_gemm(DEV, dtype, 66000, 768, 768, identity=False)
+
+
+def test_split_bf16_products_128_row_tiles(gemm_options):
+    gemm_options(gemm_tail=2)
+    KC.case_split_precision(DEV)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("shape", [(1121, 768, 3072), (2300, 2304, 768), (64, 400, 768), (7, 519 + 57, 768), (5184, 768, 256), (4640, 768, 3072), (2320, 2304, 768), (2304, 768, 768)])
 def test_gemm_tn(dtype, shape):
     K, M, N = shape

@@ -651,7 +651,6 @@ def test_hip_graph_captured_training_forward_equals_eager():
     leased = lambda: sum(st.get("lease") is not None and st["lease"]() is not None for st in net._graphs.values())
     assert leased() == 1
     (la + lb).backward()
-    del la, lb
     assert leased() == 0
     assert abs(la.item() - e1[0]) <= 3e-7 * abs(e1[0]) and abs(lb.item() - e1[0]) <= 3e-7 * abs(e1[0])
     assert rel_err(net.blocks[5].mlp.fc1.weight.grad, 2 * e1[1]) < 1e-4
