@@ -184,6 +184,8 @@ def build_case(args, dev, rank, world, mode, T, B, patchout, reducer_kw=None):
         net._engine.head_tail = False
     if args.serial_kernels:
         net._engine.overlap_wgrad = False
+    if args.no_fold_delta:
+        net._engine.fold_delta = False
     mod = (TeacherStudentModule if ts else Module)(net=net, mixup_alpha=0.3)
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
     if ts:   # 30 s of synthetic 16 kHz audio per clip; the log-mel front end runs inside every step
@@ -375,6 +377,8 @@ def main():
                     help="evaluate the last block on every token (A/B reference for the head-token restriction)")
     ap.add_argument("--serial-kernels", action="store_true",
                     help="disable the side-stream overlap of weight-gradient GEMMs (for kernel profiling)")
+    ap.add_argument("--no-fold-delta", action="store_true",
+                    help="attention backward: delta = rowsum(dO * O) by its own kernel instead of the proj dgrad GEMM's epilogue (A/B)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: create the one-rank RCCL communicator and push every gradient bucket through its "
                          "all-reduce anyway (the data-parallel exchange path on a single GPU)")
@@ -470,7 +474,8 @@ def main():
         # ---- the other single-GPU BASELINE configurations, driver-visible on the same line (default run only)
         default_line = (world == 1 and args.mode == "train" and args.frames is None and args.batch is None
                         and args.patchout is None and not args.hip_graph and not args.no_side_cases
-                        and not args.complete_last_block and not args.serial_kernels and not args.force_collective)
+                        and not args.complete_last_block and not args.serial_kernels and not args.force_collective
+                        and not args.no_fold_delta)
         if default_line:
             del case, net, step
             torch.cuda.empty_cache()

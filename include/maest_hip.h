@@ -50,6 +50,7 @@ extern "C" {
 #define MAEST_EPI_RESIDUAL 2 /* C(fp32) = acc + bias + aux_in(fp32)                      */
 #define MAEST_EPI_MUL 3      /* C = acc * aux_in   (aux_in in out_dtype; dgrad through GELU)  */
 #define MAEST_EPI_ATOMIC 4   /* C(fp32) += acc   (split-K accumulate, C pre-zeroed)      */
+#define MAEST_EPI_ROWDOT 5   /* internal to maest_gemm_nt_rowdot (not accepted by maest_gemm_nt) */
 
 int maest_version(void);
 const char* maest_last_error(void);
@@ -78,12 +79,25 @@ int maest_get_option(int opt, int* value);
  * nn.Linear: models/maest.py:353,355,361,376 ; :197-199,203-206 ; :572,579 ; nn.Conv2d :238-240.
  *   C[M,N] = epilogue( sum_k A[m,k] * B[n,k] )      A:[M,K] lda, B:[N,K] ldb (both k-contiguous)
  * in_dtype = dtype of A and B; out_dtype = dtype of C / aux_out (and aux_in for MUL).
- * GELU uses libm erf in fp32 mode and the Abramowitz-Stegun 7.1.26 erf (|err| <= 1.5e-7) in bf16 mode.
+ * GELU uses libm erf in fp32 mode and a 4-term erf of the Abramowitz-Stegun 7.1.26 form (|err| <= 1.7e-6) in bf16 mode.
  * K must be a multiple of 64 (bf16) / 32 (fp32): callers zero-pad.  bias: fp32 [N] or NULL. */
 int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int in_dtype,
                   void* C, int64_t ldc, int out_dtype, int M, int N, int K,
                   const float* bias, int epi, const void* aux_in, void* aux_out, int64_t ld_aux,
                   int split_k, void* stream);
+
+/* ---- the same GEMM (no epilogue other than the bias) plus, out of the same C-tile pass, the dot products of every row of
+ * the STORED C (rounded to out_dtype) with the same row of `other` (out_dtype, [M, N], ld_other), per group of 64
+ * columns:
+ *   rowdot[((m / rows_per_item) * (N / 64) + g) * rows_per_item + m % rows_per_item] = sum_{c < 64} C[m, 64 g + c] * other[m, 64 g + c]
+ * (fp32, [M / rows_per_item, N / 64, rows_per_item]).  With C = dO (the gradient of the attention output, produced by the
+ * dgrad GEMM of the output projection, models/maest.py:376), other = O and rows_per_item = tokens per clip this is the
+ * `delta = rowsum(dO * O)` per (clip, head, query) the attention backward needs: pass it to maest_attn_bwd_rows with
+ * out = NULL and the separate pass over dO and O disappears.  N % 64 == 0, M % rows_per_item == 0.  Shapes the 256-row
+ * tile kernels do not take run the plain GEMM followed by a small reduction kernel (same result). */
+int maest_gemm_nt_rowdot(const void* A, int64_t lda, const void* B, int64_t ldb, int in_dtype, void* C, int64_t ldc,
+                         int out_dtype, int M, int N, int K, const float* bias, const void* other, int64_t ld_other,
+                         float* rowdot, int rows_per_item, void* stream);
 
 /* ---- wgrad + bias grad, no transposed copies ("TN": both operands token-major as they sit in HBM) ----
  *   C[M,N] (fp32, ACCUMULATED: zero it first) += sum_k A[k,m] * B[k,n]      A:[K,M] lda, B:[K,N] ldb
@@ -145,7 +159,8 @@ int maest_layernorm_bwd_headres(const void* dy, int64_t lddy, int dy_dtype, cons
  * lse: fp32 [B, 12, N] log-sum-exp of the scaled scores (saved for backward) or NULL. */
 int maest_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int dtype, float scale,
                    void* stream);
-/* delta: fp32 [B,12,N] workspace (rowsum(dO*O)); dqkv: [B*N, 2304] same layout as qkv. */
+/* delta: fp32 [B,12,N] workspace (rowsum(dO*O)); dqkv: [B*N, 2304] same layout as qkv.
+ * out == NULL: `delta` already holds rowsum(dO*O) (maest_gemm_nt_rowdot) and is only read. */
 int maest_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                    float* delta, void* dqkv, int B, int N, int dtype, float scale, void* stream);
 /* Attention of the LAST block, where only the first q_rows tokens of a clip (cls, dist) are read by what follows

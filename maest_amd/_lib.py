@@ -25,6 +25,7 @@ _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 # name -> argtypes, in the order of include/maest_hip.h
 SIGNATURES = {
     "maest_gemm_nt": [_P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _I, _P, _P, _L, _I, _P],
+    "maest_gemm_nt_rowdot": [_P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _P, _L, _P, _I, _P],
     "maest_gemm_tn": [_P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _P, _I, _P],
     "maest_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
     "maest_cast_weights": [_P, _P, _P, _I, _I, _I, _P],

@@ -1130,8 +1130,9 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
         const int nkw = (N + 31) / 32;
         if (nkw + 2 <= FB_MAXW && option(MAEST_OPT_ATTN_BWD) == 0) {     // DMA-fed form (+ the delta kernel)
             const int64_t items = (int64_t)B * N * NHEADS * 4;
-            hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
-                               (const T*)out, (const T*)dout, delta, B, N, q_rows);
+            if (out != nullptr)      // (NULL: the caller filled `delta` already, maest_gemm_nt_rowdot)
+                hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
+                                   (const T*)out, (const T*)dout, delta, B, N, q_rows);
             static DeviceOnce once_g;
             ensure_dynamic_lds(once_g, &attn_bwd_fused2_kernel, attn_bwd_fused2_smem(32 * (FB_MAXW - 2)));
             const int waves = nkw + 2 < 8 ? 8 : nkw + 2;
@@ -1165,8 +1166,9 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
     ensure_dynamic_lds(once_a, &attn_bwd_dkdv_kernel<T, X3>, smem_a);
     ensure_dynamic_lds(once_b, &attn_bwd_dq_kernel<T, X3>, smem_b);
     const int64_t items = (int64_t)B * N * NHEADS * 4;
-    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
-                       (const T*)out, (const T*)dout, delta, B, N, N);
+    if (out != nullptr)
+        hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
+                           (const T*)out, (const T*)dout, delta, B, N, N);
     dim3 grid(((N + 127) / 128) * NHEADS * B);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, X3>), grid, dim3(256), smem_a, st, (const T*)qkv, (const T*)dout, lse,
                        (const float*)delta, (T*)dqkv, B, N, scale);
@@ -1199,7 +1201,9 @@ extern "C" int maest_attn_fwd(const void* qkv, void* out, float* lse, int B, int
 extern "C" int maest_attn_bwd_rows(const void* qkv, const void* out, const void* dout, const float* lse,
                                    float* delta, void* dqkv, int B, int N, int dtype, float scale, int q_rows,
                                    void* stream) {
-    MAEST_REQUIRE(qkv && out && dout && lse && delta && dqkv, "maest_attn_bwd: null pointer");
+    MAEST_REQUIRE(qkv && dout && lse && delta && dqkv, "maest_attn_bwd: null pointer");
+    MAEST_REQUIRE(out != nullptr || option(MAEST_OPT_ATTN_BWD) != 2,
+                  "maest_attn_bwd: out = NULL (delta given) is not served by the register-fed fused form (MAEST_OPT_ATTN_BWD = 2)");
     MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_bwd: bad shape B=%d N=%d", B, N);
     MAEST_REQUIRE(q_rows > 0 && q_rows <= N, "maest_attn_bwd_rows: q_rows = %d outside 1..N", q_rows);
     MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3, "maest_attn_bwd: bad dtype %d", dtype);

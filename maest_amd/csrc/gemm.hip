@@ -517,10 +517,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmParams p) {
 
 int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int in_dtype, void* C, int64_t ldc,
                    int out_dtype, int M, int N, int K, const float* bias, int epi, const void* aux_in, void* aux_out,
-                   int64_t ld_aux, hipStream_t stream);   // gemm256.hip
+                   int64_t ld_aux, hipStream_t stream, float* rowdot = nullptr, int ntok = 0);   // gemm256.hip
 
 int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C, int64_t ldc, int M,
                    int N, int K, float* colsum, int split_k, hipStream_t stream);   // gemm256.hip
+
+// rowdot[item, g, q] = sum_{c < 64} c_mat[m, 64 g + c] * other[m, 64 g + c], m = item * ntok + q: four lanes per (row, group).
+// The stand-alone form of the MAEST_EPI_ROWDOT epilogue (shapes the 256-row-tile kernels do not take).
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ c_mat, int64_t ldc, const T* __restrict__ other,
+                                                     int64_t ld_other, float* __restrict__ rowdot, int M, int groups, int ntok) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)M * groups;
+    int64_t item = gid >> 2;
+    const int quarter = (int)(gid & 3);
+    const bool valid = item < total;
+    if (!valid) item = total - 1;
+    const int64_t row = item / groups;
+    const int g = (int)(item - row * groups);
+    const T* pc = c_mat + row * ldc + g * 64 + quarter * 16;
+    const T* po = other + row * ld_other + g * 64 + quarter * 16;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += elem_traits<T>::to_f32(pc[i]) * elem_traits<T>::to_f32(po[i]);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (valid && quarter == 0) {
+        const int64_t it = row / ntok, q = row - it * ntok;
+        rowdot[(it * groups + g) * ntok + q] = acc;
+    }
+}
 
 template <typename T>
 static int launch_gemm_nt(GemmParams& p, int split_k, hipStream_t stream) {
@@ -596,6 +622,42 @@ extern "C" int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     split_k = (total + p.k_slices_per_split - 1) / p.k_slices_per_split;
     return in_dtype == MAEST_BF16 ? launch_gemm_nt<bf16_t>(p, split_k, (hipStream_t)stream)
                                   : launch_gemm_nt<float>(p, split_k, (hipStream_t)stream);
+}
+
+extern "C" int maest_gemm_nt_rowdot(const void* A, int64_t lda, const void* B, int64_t ldb, int in_dtype, void* C,
+                                    int64_t ldc, int out_dtype, int M, int N, int K, const float* bias, const void* other,
+                                    int64_t ld_other, float* rowdot, int rows_per_item, void* stream) {
+    MAEST_REQUIRE(A && B && C && other && rowdot, "maest_gemm_nt_rowdot: null pointer");
+    MAEST_REQUIRE(M > 0 && N > 0 && K > 0 && (N % 64) == 0, "maest_gemm_nt_rowdot: bad shape M=%d N=%d K=%d (N %% 64 == 0)", M, N, K);
+    MAEST_REQUIRE(rows_per_item > 0 && (M % rows_per_item) == 0, "maest_gemm_nt_rowdot: M=%d is not a multiple of rows_per_item=%d",
+                  M, rows_per_item);
+    MAEST_REQUIRE(out_dtype == MAEST_F32 || out_dtype == MAEST_BF16, "maest_gemm_nt_rowdot: bad out_dtype %d", out_dtype);
+    const int osz = out_dtype == MAEST_BF16 ? 2 : 4, epc = 16 / osz;
+    MAEST_REQUIRE((ld_other % epc) == 0 && ((uintptr_t)other % 16) == 0 && (ldc % epc) == 0 && ((uintptr_t)C % 16) == 0,
+                  "maest_gemm_nt_rowdot: C / other rows must be 16-byte aligned");
+    const bool x3 = in_dtype == MAEST_F32X3;
+    const int in_plain = x3 ? MAEST_F32 : in_dtype;
+    MAEST_REQUIRE(in_plain == MAEST_F32 || in_plain == MAEST_BF16, "maest_gemm_nt_rowdot: bad in_dtype %d", in_dtype);
+    const int elt = in_plain == MAEST_BF16 ? 2 : 4;
+    if (K % (GEMM_ROWB / elt) == 0 && (lda * elt) % 16 == 0 && (ldb * elt) % 16 == 0 && ((uintptr_t)A % 16) == 0 &&
+        ((uintptr_t)B % 16) == 0 && (bias == nullptr || ((uintptr_t)bias % 16) == 0)) {
+        const int rc = gemm_nt256_try(A, lda, B, ldb, in_dtype, C, ldc, out_dtype, M, N, K, bias, MAEST_EPI_ROWDOT, other,
+                                      nullptr, ld_other, (hipStream_t)stream, rowdot, rows_per_item);
+        if (rc >= 0) return rc;
+    }
+    const int rc = maest_gemm_nt(A, lda, B, ldb, in_dtype, C, ldc, out_dtype, M, N, K, bias, MAEST_EPI_NONE, nullptr, nullptr,
+                                 0, 1, stream);
+    if (rc != MAEST_OK) return rc;
+    const int groups = N / 64;
+    const int64_t threads = (int64_t)M * groups * 4;
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (out_dtype == MAEST_BF16)
+        hipLaunchKernelGGL(rowdot_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)C, ldc,
+                           (const bf16_t*)other, ld_other, rowdot, M, groups, rows_per_item);
+    else
+        hipLaunchKernelGGL(rowdot_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)C, ldc,
+                           (const float*)other, ld_other, rowdot, M, groups, rows_per_item);
+    return check_launch("maest_gemm_nt_rowdot");
 }
 
 extern "C" int maest_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C,

@@ -43,6 +43,9 @@ struct Gemm256Params {
     int M, N, K;
     int out_dtype, epi;
     int tiles_m, tiles_n;
+    float* rowdot;      // MAEST_EPI_ROWDOT: fp32 [rows / ntok, N / 64, ntok]
+    int ntok;
+    int row0;           // row of the whole problem this launch's row 0 is (second launch of a split problem)
 };
 
 template <int OSZ>
@@ -180,9 +183,12 @@ __device__ __forceinline__ chunk16 apply_aux(chunk16 v, const chunk16& r) {
     return v;
 }
 
+// MODE 0 plain, 1 RESIDUAL (+ aux), 2 MUL (* aux), 3 ROWDOT: plain store, and rowdot[item, column group of 64, row in item]
+// = sum of the stored values times aux over the group (the 8 / 16 lanes that hold a group's chunks are neighbours)
 template <int OSZ, int MODE, int ROWS = Epi256<OSZ>::ROWS>
 __device__ __forceinline__ void drain256(const char* smem, void* dst, int64_t ld, const AuxRegs<OSZ, ROWS>* aux,
-                                         int mbase, int n0, int M, int N, int tid) {
+                                         int mbase, int n0, int M, int N, int tid, float* rowdot = nullptr, int ntok = 1,
+                                         int row0 = 0) {
     using E = Epi256<OSZ>;
 #pragma unroll
     for (int i = 0; i < ROWS * E::CPR / 512; ++i) {
@@ -190,7 +196,23 @@ __device__ __forceinline__ void drain256(const char* smem, void* dst, int64_t ld
         const int row = c / E::CPR, cc = c - row * E::CPR;
         const int gm = mbase + row, gn = n0 + cc * E::EPC;
         chunk16 v = *reinterpret_cast<const chunk16*>(smem + row * E::PITCH + cc * 16);
-        if (MODE != 0) v = apply_aux<OSZ, MODE>(v, aux->v[i]);
+        if (MODE == 1 || MODE == 2) v = apply_aux<OSZ, MODE>(v, aux->v[i]);
+        if (MODE == 3) {
+            const chunk16 r = aux->v[i];
+            float d = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (OSZ == 4) d += u2f(v[e]) * u2f(r[e]);
+                else d += u2f(v[e] << 16) * u2f(r[e] << 16) + u2f(v[e] & 0xffff0000u) * u2f(r[e] & 0xffff0000u);
+            }
+            constexpr int GL = 64 * OSZ / 16;          // lanes per 64-column group: 8 / 16
+#pragma unroll
+            for (int m = 1; m < GL; m <<= 1) d += __shfl_xor(d, m, 64);
+            if ((cc & (GL - 1)) == 0 && gm < M && gn < N) {
+                const int item = (gm + row0) / ntok, q = gm + row0 - item * ntok;
+                rowdot[((int64_t)item * (N >> 6) + (gn >> 6)) * ntok + q] = d;
+            }
+        }
         if (gm >= M || gn >= N) continue;
         // streaming output: written once, re-read by a later kernel after > L2-size of other traffic
         __builtin_nontemporal_store(v, reinterpret_cast<chunk16*>(reinterpret_cast<char*>(dst) + ((int64_t)gm * ld + gn) * OSZ));
@@ -218,7 +240,7 @@ __device__ __forceinline__ void epilogue256(char* smem, const f32x16_t (&acc)[2]
         }
         return;
     }
-    const bool with_aux = p.epi == MAEST_EPI_RESIDUAL || p.epi == MAEST_EPI_MUL;   // block-uniform
+    const bool with_aux = p.epi == MAEST_EPI_RESIDUAL || p.epi == MAEST_EPI_MUL || p.epi == MAEST_EPI_ROWDOT;   // block-uniform
 #pragma unroll
     for (int ps = 0; ps < E::PASSES; ++ps) {
         const int pwm = ps / (4 / E::MT);
@@ -238,6 +260,8 @@ __device__ __forceinline__ void epilogue256(char* smem, const f32x16_t (&acc)[2]
                 drain256<OSZ, 1, E::ROWS>(smem, p.C, p.ldc, &ax, mbase, n0, p.M, p.N, tid);
             else if (p.epi == MAEST_EPI_MUL)
                 drain256<OSZ, 2, E::ROWS>(smem, p.C, p.ldc, &ax, mbase, n0, p.M, p.N, tid);
+            else if (p.epi == MAEST_EPI_ROWDOT)
+                drain256<OSZ, 3, E::ROWS>(smem, p.C, p.ldc, &ax, mbase, n0, p.M, p.N, tid, p.rowdot, p.ntok, p.row0);
             else
                 drain256<OSZ, 0, E::ROWS>(smem, p.C, p.ldc, nullptr, mbase, n0, p.M, p.N, tid);
         }
@@ -653,7 +677,7 @@ __device__ __forceinline__ void epilogueH_run(char* smem, const f32x16_t (&acc)[
         for (int g = 0; g < 2; ++g) {
             const int mbase = m0 + g * 64 + ps * GR;
             const char* src = smem + g * GR * E::PITCH;
-            drain256<OSZ, MODE, GR>(src, p.C, p.ldc, &ax[g], mbase, n0, p.M, p.N, tid);
+            drain256<OSZ, MODE, GR>(src, p.C, p.ldc, &ax[g], mbase, n0, p.M, p.N, tid, p.rowdot, p.ntok, p.row0);
             if (PAIR) drain256<OSZ, 0, GR>(src + REGION, p.aux_out, p.ld_aux, nullptr, mbase, n0, p.M, p.N, tid);
         }
         if (ps + 1 < 2 / PMT) __syncthreads();
@@ -666,6 +690,7 @@ __device__ __forceinline__ void epilogueH(char* smem, const f32x16_t (&acc)[2][2
     if (gelu && p.aux_out != nullptr) epilogueH_run<OSZ, EXACT, 0, true>(smem, acc, p, m0, n0, wm, wn, lane, tid, true);
     else if (p.epi == MAEST_EPI_RESIDUAL) epilogueH_run<OSZ, EXACT, 1, false>(smem, acc, p, m0, n0, wm, wn, lane, tid, false);
     else if (p.epi == MAEST_EPI_MUL) epilogueH_run<OSZ, EXACT, 2, false>(smem, acc, p, m0, n0, wm, wn, lane, tid, false);
+    else if (p.epi == MAEST_EPI_ROWDOT) epilogueH_run<OSZ, EXACT, 3, false>(smem, acc, p, m0, n0, wm, wn, lane, tid, false);
     else epilogueH_run<OSZ, EXACT, 0, false>(smem, acc, p, m0, n0, wm, wn, lane, tid, gelu);
 }
 
@@ -1035,8 +1060,12 @@ static int launch256x128(Gemm256Params& p, hipStream_t stream) {
 // Called by maest_gemm_nt for large, 16-byte-friendly problems.  Returns -1 when the shape does not qualify.
 int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int in_dtype, void* C, int64_t ldc,
                    int out_dtype, int M, int N, int K, const float* bias, int epi, const void* aux_in, void* aux_out,
-                   int64_t ld_aux, hipStream_t stream) {
+                   int64_t ld_aux, hipStream_t stream, float* rowdot, int ntok) {
     if (epi == MAEST_EPI_ATOMIC) return -1;
+    // the row-dot side output lives in the epilogues of the full-line kernel only (two-pass form / 128-row tiles)
+    if (epi == MAEST_EPI_ROWDOT && ((N % 256) != 0 || option(MAEST_OPT_GEMM_VARIANT) == 1 || option(MAEST_OPT_GEMM_VARIANT) == 2 ||
+                                    (K * (in_dtype == MAEST_BF16 ? 2 : 4)) % W2_ROWB != 0))
+        return -1;
     const bool x3 = in_dtype == MAEST_F32X3;     // fp32 tensors, split-bf16 products (full-line kernel only)
     if (x3) in_dtype = MAEST_F32;
     // below ~8k rows the 256-row tiles leave most CUs idle (M = 560: 9-36 workgroups); the 128x128 kernel's finer
@@ -1051,6 +1080,7 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
     p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux;
     p.M = M; p.N = N; p.K = K; p.out_dtype = out_dtype; p.epi = epi;
+    p.rowdot = rowdot; p.ntok = ntok > 0 ? ntok : 1; p.row0 = 0;
     p.tiles_m = (M + 255) / 256;
     // Measured (scratch/gemm_ab.py): the one-workgroup-per-CU 256x256 kernel wins on every ViT shape but the
     // value-only GELU epilogue; the 256x128 two-per-CU kernel serves N % 256 != 0 and MAEST_GEMM_VARIANT=2.
@@ -1062,7 +1092,7 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
         // outputs by 1-5 %, the four-pass double-buffered form for the fp32 residual outputs by 3-5 %, the
         // one-pass form never.  MAEST_OPT_GEMM_EPILOGUE = 0 / 1 / 2 forces one of them (-1 = this default).
         const int eopt = option(MAEST_OPT_GEMM_EPILOGUE);
-        const int ev = eopt >= 0 ? eopt : (epi == MAEST_EPI_RESIDUAL ? 1 : 0);
+        const int ev = epi == MAEST_EPI_ROWDOT ? 0 : (eopt >= 0 ? eopt : (epi == MAEST_EPI_RESIDUAL ? 1 : 0));
         auto full = [&](Gemm256Params& q) {
             if (x3) return ev == 1 ? launch256w<float, 1, true>(q, stream) : launch256w<float, 0, true>(q, stream);
             if (ev == 1) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 1>(q, stream) : launch256w<float, 1>(q, stream);
@@ -1102,6 +1132,9 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
                 b.C = (char*)C + r0 * ldc * osz;
                 // aux_in: fp32 for RESIDUAL, the output dtype for MUL; aux_out (GELU'): the output dtype
                 if (aux_in) b.aux_in = (const char*)aux_in + r0 * ld_aux * (epi == MAEST_EPI_RESIDUAL ? 4 : osz);
+                // (row-dot: the second launch sees rows r0.. as its rows 0..; r0 is a multiple of 256, not of ntok in
+                // general, so it gets the item / row arithmetic through an offset of its own)
+                b.row0 = (int)r0;
                 if (aux_out) b.aux_out = (char*)aux_out + r0 * ld_aux * osz;
                 return half(b);
             }

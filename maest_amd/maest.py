@@ -200,6 +200,9 @@ class _Engine:
         # queries, proj, norm2 and MLP -- forward and backward -- only on those two rows of every clip.  Outputs and
         # gradients are the ones of the full evaluation (the skipped rows feed nothing and receive no gradient).
         self.head_tail = True
+        # the attention backward's delta = rowsum(dO * O) comes out of the epilogue of the proj dgrad GEMM (which produces
+        # dO) instead of a separate pass over dO and O (ops.gemm_nt_rowdot)
+        self.fold_delta = True
         self._weights_dirty = False
         self._side = {}
 
@@ -465,12 +468,20 @@ class _Engine:
                 dx1_lp = dx1
             # proj (+ residual)
             wgrad(p + "attn.proj.weight", p + "attn.proj.bias", dx1_lp, s["ao"], EMBED_DIM, EMBED_DIM)
-            dao = gemm_nt(dx1_lp, W.get(blk.attn.proj.weight, dt, transposed=True), None, out_dtype=dt)
+            wt_proj = W.get(blk.attn.proj.weight, dt, transposed=True)
             if s["tail"]:
+                dao = gemm_nt(dx1_lp, wt_proj, None, out_dtype=dt)
                 # back to the token-major layout: the head tokens' rows, zeros for the queries the kernel still visits
                 # (its first 32-row tile when it honours q_rows, every row otherwise)
                 dao = ops.scatter_head_rows(dao, B, N, HEAD_TOKENS, min(32, N) if s["q_rows"] else N)
-            dqkv = ops.attn_bwd(s["qkv"], s["ao_full"], dao, s["lse"], B, N, blk.attn.scale, q_rows=s["q_rows"], x3=x3m)
+                dqkv = ops.attn_bwd(s["qkv"], s["ao_full"], dao, s["lse"], B, N, blk.attn.scale, q_rows=s["q_rows"], x3=x3m)
+            elif self.fold_delta and ops.get_option("attn_bwd") != 2:
+                # delta = rowsum(dO * O) per (clip, head, query) out of the C-tile pass of the GEMM that produces dO
+                dao, delta = ops.gemm_nt_rowdot(dx1_lp, wt_proj, s["ao_full"], N, out_dtype=dt, x3=x3m)
+                dqkv = ops.attn_bwd(s["qkv"], None, dao, s["lse"], B, N, blk.attn.scale, x3=x3m, delta=delta)
+            else:
+                dao = gemm_nt(dx1_lp, wt_proj, None, out_dtype=dt)
+                dqkv = ops.attn_bwd(s["qkv"], s["ao_full"], dao, s["lse"], B, N, blk.attn.scale, x3=x3m)
             wgrad(p + "attn.qkv.weight", p + "attn.qkv.bias", dqkv, s["ln1"], 3 * EMBED_DIM, EMBED_DIM)
             dln1 = gemm_nt(dqkv, W.get(blk.attn.qkv.weight, dt, transposed=True), None, out_dtype=dt)
             gw, gb = buf(p + "norm1.weight", EMBED_DIM), buf(p + "norm1.bias", EMBED_DIM)

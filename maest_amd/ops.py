@@ -127,6 +127,28 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm_nt_rowdot(a: torch.Tensor, b: torch.Tensor, other: torch.Tensor, rows_per_item: int, *, out_dtype=None,
+                   bias: Optional[torch.Tensor] = None, x3: bool = False):
+    """c[M,N] = a[M,K] @ b[N,K]^T (+ bias) in out_dtype and, from the same C-tile pass, rowdot[M / rows_per_item, N / 64,
+    rows_per_item] = per (row, 64-column group) dot products of the stored c with `other` (same shape / dtype as c):
+    the attention backward's delta = rowsum(dO * O) out of the GEMM that produces dO (include/maest_hip.h)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    out_dtype = out_dtype or a.dtype
+    assert other.shape == (M, N) and other.dtype == out_dtype and other.stride(1) == 1 and M % rows_per_item == 0
+    _chk(bias)
+    for t in (a, b, other):
+        if not (t.is_cuda or _lib.host_emulation()):
+            raise _lib.MaestHipError("maest_amd kernels need tensors on a HIP device; there is no CPU fallback")
+    c = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    rowdot = torch.empty((M // rows_per_item, N // 64, rows_per_item), dtype=torch.float32, device=a.device)
+    _timed_call("maest_gemm_nt" if M >= 4096 else "maest_gemm_nt_small", 2.0 * M * N * K, _p(a), a.stride(0), _p(b),
+                b.stride(0), _mm_code(a.dtype, x3), _p(c), c.stride(0), DT[out_dtype], M, N, K, _p(bias), _p(other),
+                other.stride(0), _p(rowdot), rows_per_item, _s(a), _entry="maest_gemm_nt_rowdot")
+    return c, rowdot
+
+
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, colsum: Optional[torch.Tensor] = None,
             split_k: int = 1, M: Optional[int] = None, N: Optional[int] = None, x3: bool = False) -> torch.Tensor:
     """out[M,N] (fp32, pre-zeroed) += a[K,M]^T @ b[K,N];  colsum[M] (fp32, pre-zeroed) += a.sum(0)."""
@@ -260,10 +282,16 @@ def attn_bwd_rows_supported(dtype, N: int) -> bool:
     return dtype == torch.bfloat16 and -(-N // 32) + 2 <= 12 and get_option("attn_bwd") == 0
 
 
-def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float, q_rows=None, x3: bool = False):
-    _chk(qkv, out, dout, lse)
-    assert dout.dtype == qkv.dtype and out.dtype == qkv.dtype
-    delta = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device)
+def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float, q_rows=None, x3: bool = False, delta=None):
+    """`delta` (fp32 [B, 12, N] = rowsum(dO * O), from gemm_nt_rowdot) given: `out` is not needed (pass None)."""
+    _chk(qkv, out, dout, lse, delta)
+    assert dout.dtype == qkv.dtype and (out is None or out.dtype == qkv.dtype)
+    if delta is None:
+        assert out is not None
+        delta = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device)
+    else:
+        assert delta.shape == (B, HEADS, N) and delta.dtype == torch.float32 and delta.is_contiguous()
+        out = None
     dqkv = torch.empty_like(qkv)
     _timed_call("maest_attn_bwd", _attn_flops(B, N, q_rows, 10.0), _p(qkv), _p(out), _p(dout), _p(lse),
                 _p(delta), _p(dqkv), B, N, _mm_code(qkv.dtype, x3), scale, N if q_rows is None else q_rows, _s(qkv),

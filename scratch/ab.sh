@@ -1,0 +1,24 @@
+#!/bin/bash
+# Paired A/B on ONE box (boxes differ by +-3 %: a claim below that is only worth something same-lease): the two bench
+# command lines are run alternately, REPS times each, and the per-pair deltas are reported.
+#   scratch/ab.sh <tag> "<args A>" "<args B>" [reps]
+tag=$1; A=$2; B=$3; reps=${4:-3}
+mkdir -p gpurun_out/$tag
+for i in $(seq 1 $reps); do
+  python bench.py --no-cpu-baseline --no-kernel-timing --no-side-cases --steps 20 $A > gpurun_out/$tag/a$i.json 2>/dev/null
+  python bench.py --no-cpu-baseline --no-kernel-timing --no-side-cases --steps 20 $B > gpurun_out/$tag/b$i.json 2>/dev/null
+done
+python - "$tag" "$A" "$B" "$reps" <<'PY'
+import json, sys
+tag, A, B, reps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+rows = []
+for i in range(1, reps + 1):
+    a = json.loads(open(f"gpurun_out/{tag}/a{i}.json").read().strip().splitlines()[-1])["ms_per_step"]
+    b = json.loads(open(f"gpurun_out/{tag}/b{i}.json").read().strip().splitlines()[-1])["ms_per_step"]
+    rows.append((a, b))
+print(f"A = bench.py {A!r}\nB = bench.py {B!r}")
+for a, b in rows:
+    print(f"  A {a:8.3f} ms   B {b:8.3f} ms   B - A {b - a:+7.3f} ms ({100 * (b / a - 1):+5.2f} %)")
+d = sorted(b - a for a, b in rows)
+print(f"  median paired delta {d[len(d) // 2]:+.3f} ms/step")
+PY

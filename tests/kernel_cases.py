@@ -75,6 +75,23 @@ def case_gemm(dev, dtype, M, N, K, seed=0, identity=True):
     close(acc, ref - bias, rt, at * math.sqrt(K / 64), "gemm split-k")
 
 
+def case_gemm_rowdot(dev, dtype, M, N, K, ntok, seed=7):
+    """maest_gemm_nt_rowdot: C = A B^T + bias in `dtype`, and rowdot[item, 64-column group, row in item] = the dot
+    product of the STORED row segment of C with `other` -- the attention backward's delta out of the dgrad GEMM's
+    epilogue.  Reference: the products of the returned C itself (exactly the values the kernel multiplied)."""
+    a = rnd((M, K), seed).to(dtype)
+    b = rnd((N, K), seed + 1).to(dtype)
+    bias = rnd((N,), seed + 2)
+    other = rnd((M, N), seed + 3).to(dtype)
+    c, rd = ops.gemm_nt_rowdot(a.to(dev), b.to(dev), other.to(dev), ntok, out_dtype=dtype, bias=bias.to(dev))
+    ref = a.float() @ b.float().t() + bias
+    rt, at = (1e-5, 4e-7 * K) if dtype == torch.float32 else (1e-2, 1e-2 * math.sqrt(K / 64))
+    close(c, ref, rt, at, "gemm rowdot: C")
+    assert rd.shape == (M // ntok, N // 64, ntok)
+    want = (c.float().cpu() * other.float()).reshape(M // ntok, ntok, N // 64, 64).sum(-1).permute(0, 2, 1)
+    close(rd, want, 1e-5, 1e-5 * math.sqrt(64) * float(c.float().abs().max()), "gemm rowdot: per-(row, group) dot products")
+
+
 def case_gemm_tn(dev, dtype, K, M, N, seed=3, lda_pad=0):
     """wgrad form: out[M,N] += a[K,M]^T b[K,N], colsum[M] += a.sum(0); ragged K (token tail)."""
     a_full = rnd((K, M + lda_pad), seed).to(dtype)

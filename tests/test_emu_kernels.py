@@ -49,6 +49,18 @@ def test_emu_gemm_128_row_tiles_of_the_last_partial_round(emu, dtype, gemm_optio
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_emu_gemm_rowdot(emu, dtype, gemm_options):
+    """the row-dot side output: stand-alone reduction behind the 128x128 kernel, the two-pass epilogue of the full-line
+    kernel, and the one-pass epilogue of its 128-row-tile variant"""
+    K = 64 if dtype == torch.float32 else 128
+    KC.case_gemm_rowdot(emu, dtype, 150, 128, K, 75)
+    gemm_options(gemm_min_m=512)
+    KC.case_gemm_rowdot(emu, dtype, 512, 256, K, 64)
+    gemm_options(gemm_min_m=512, gemm_tail=2)
+    KC.case_gemm_rowdot(emu, dtype, 576, 256, K, 96)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_emu_gemm_tn_256_tile_lds_dma_kernel(emu, dtype, gemm_options):
     """M, N multiples of 256 and K a multiple of the slice route to gemm256.hip:gemm_tn256_kernel."""
     gemm_options(gemm_variant=4)   # take the 256-tile kernel although there are only 2 tiles

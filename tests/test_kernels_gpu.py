@@ -40,6 +40,17 @@ def test_gemm_last_partial_round_split(dtype):
     KC.case_gemm(DEV, dtype, 66000, 768, 768, identity=False)
 
 
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_rowdot(dtype, gemm_options):
+    """delta = rowsum(dO * O) out of the proj dgrad GEMM: the bench shape (74240 x 768 x 768, 290 tokens per clip: rows
+    0..65535 in 256-row tiles + the last partial round in 128-row tiles, whose rows start in the middle of a clip), a
+    small shape through the stand-alone reduction, and the 256-row kernels forced onto a small M"""
+    KC.case_gemm_rowdot(DEV, dtype, 74240, 768, 768, 290)
+    KC.case_gemm_rowdot(DEV, dtype, 1120, 768, 768, 280)
+    gemm_options(gemm_min_m=512)
+    KC.case_gemm_rowdot(DEV, dtype, 1120, 768, 768, 560)
+
+
 def test_split_bf16_products_128_row_tiles(gemm_options):
     gemm_options(gemm_tail=2)
     KC.case_split_precision(DEV)
