@@ -46,7 +46,7 @@ def flops_per_clip_fwd_not_executed(N, attn_rows):
     return 2 * (N - 2) * 768 * (768 + 3072 + 3072) + 4 * (N - attn_rows) * N * 768
 
 
-PMC_TRAFFIC_FILE = "profiles/r02c_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r03a_pmc_traffic.json"
 
 
 def pmc_traffic():
@@ -54,7 +54,7 @@ def pmc_traffic():
     be collected by bench.py on itself: the figure is read from the committed summary of separate rocprofv3 --pmc
     passes over THIS command (scratch/profile_round.sh), i.e. a constant from an earlier run of the same binary,
     and is labelled as such in the JSON line (`traffic_source`).  (None, reason) when the file is absent."""
-    for name in (PMC_TRAFFIC_FILE, "profiles/r01g_pmc_traffic.json"):
+    for name in (PMC_TRAFFIC_FILE, "profiles/r02c_pmc_traffic.json"):
         try:
             with open(os.path.join(REPO, name)) as f:
                 return json.load(f)["traffic_bytes_per_launch"], (

@@ -3,9 +3,9 @@
 # of the dominant GEMM with a FETCH/WRITE calibration on known byte counts + SQ utilisation counters of the hot kernels
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-TAG=${1:-r02a}; O=gpurun_out/$TAG; mkdir -p $O
-timeout 400 python bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/${TAG}_bench_train_b256.json
-timeout 400 python bench.py --mode infer --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/${TAG}_bench_infer_b256.json
+TAG=${1:-r03a}; O=gpurun_out/$TAG; mkdir -p $O
+timeout 600 python bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/${TAG}_bench_train_b256.json
+timeout 400 python bench.py --mode infer --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/${TAG}_bench_infer_b256.json
 timeout 400 python bench.py --mode ts --steps 5 --warmup 2 2>/dev/null | tail -1 > $O/${TAG}_bench_ts_b128.json
 timeout 400 python bench.py --frames 1876 --batch 128 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_train30s_b128.json
 timeout 400 python bench.py --mode infer --frames 1876 --batch 64 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_infer30s_b64.json
@@ -41,14 +41,18 @@ if ln and "FETCH_SIZE" in ln:
     fetch_factor = (74240 * 768 * 4) / ln["FETCH_SIZE"]["avg_bytes"]
 write_factor = (74240 * 768 * 2) / ln["WRITE_SIZE"]["avg_bytes"] if ln and "WRITE_SIZE" in ln else None
 nt = {k: v for k, v in bench.items() if "gemm_nt256w" in k}
-launches = sum(cs["FETCH_SIZE"][0] for cs in nt.values()) if nt else 0
-fetch = sum(cs["FETCH_SIZE"][1] for cs in nt.values()) * 1024 / max(launches, 1)
-write = sum(cs["WRITE_SIZE"][1] for cs in nt.values()) * 1024 / max(sum(cs["WRITE_SIZE"][0] for cs in nt.values()), 1)
 steps = 4   # 1 warm-up + 3 steps profiled
+# per GEMM CALL (bench.py times a call, i.e. the 256-row-tile launch plus, where the last partial round is split off, the
+# 128-row-tile launch behind it): 91 calls per training step
+calls = 91 * steps
+kernel_launches = sum(cs["FETCH_SIZE"][0] for cs in nt.values()) if nt else 0
+launches = calls
+fetch = sum(cs["FETCH_SIZE"][1] for cs in nt.values()) * 1024 / calls
+write = sum(cs["WRITE_SIZE"][1] for cs in nt.values()) * 1024 / calls
 out = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 "
                  f"--no-cpu-baseline --no-kernel-timing --serial-kernels  (scratch/profile_round.sh {TAG})",
-       "kernel": "gemm_nt256w_kernel<bf16, epilogue 0 | 1> (all launches of a step)",
-       "launches_per_step": launches // steps,
+       "kernel": "gemm_nt256w_kernel<bf16, ...> (256-row and 128-row tile instantiations: all launches of a step)",
+       "launches_per_step": launches // steps, "kernel_launches_per_step": kernel_launches // steps,
        "fetch_bytes_per_launch_raw": fetch, "write_bytes_per_launch": write,
        "fetch_correction": "x2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM section)",
        "calibration": {"what": "scratch/fetch_calib.py under the same two --pmc passes: counter bytes vs known bytes",
