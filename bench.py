@@ -214,7 +214,8 @@ def build_case(args, dev, rank, world, mode, T, B, patchout, reducer_kw=None):
             if reducer is not None:
                 reducer.finish()
             opt.step()
-            opt.zero_grad(set_to_none=reducer is None)
+            if reducer is None:      # (with a reducer the gradients are views of its flat buffer, zeroed by reset())
+                opt.zero_grad(set_to_none=True)
             return loss
     else:
         net.eval()
