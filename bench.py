@@ -500,6 +500,13 @@ def main():
                                        else cpu_baseline_infer(cb, T))
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"error": repr(e)}
+        # RCCL writes a version banner through C stdio, which (redirected to a file or pipe) would otherwise be flushed at
+        # exit, BEHIND the JSON line: flush it out first so that the JSON line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # pragma: no cover
+            pass
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

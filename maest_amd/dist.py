@@ -85,17 +85,28 @@ class GradReducer:
         """Destination the engine should write `name`'s gradient into (a view of the flat buffer)."""
         return self.views.get(name)
 
-    def on_grad(self, name):
-        """Engine callback: the gradient of `name` is complete in its view."""
+    def note_grad(self, name) -> Optional[int]:
+        """Engine callback, host-side bookkeeping only: the gradient of `name` is complete in its view.  Returns the
+        index of the bucket this completes when that bucket has to be exchanged (-> reduce_bucket), else None."""
         b = self.bucket_of.get(name)
         if b is None:
-            return
+            return None
         self._pending[b] -= 1
-        if self._pending[b] == 0 and self.collective:
-            bk = self.buckets[b]
-            w = dist.all_reduce(self.flat[bk["start"]:bk["end"]], op=dist.ReduceOp.SUM, group=self.group,
-                                async_op=True)
-            self._works.append(w)
+        return b if (self._pending[b] == 0 and self.collective) else None
+
+    def reduce_bucket(self, b: int):
+        """Launch the asynchronous all-reduce of bucket `b`.  It is ordered after the stream that is current at the call:
+        the caller makes that stream wait for every stream that wrote gradients of the bucket (maest.py: a dedicated
+        stream that waits for the dgrad and the wgrad stream ONCE PER BUCKET -- neither of them is held up)."""
+        bk = self.buckets[b]
+        w = dist.all_reduce(self.flat[bk["start"]:bk["end"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(w)
+
+    def on_grad(self, name):
+        """note_grad + reduce_bucket on the current stream (callers with a single stream: the host-logic tests)."""
+        b = self.note_grad(name)
+        if b is not None:
+            self.reduce_bucket(b)
 
     def finish(self):
         """Wait for the exchanges, average, install param.grad views."""

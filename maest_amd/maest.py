@@ -222,6 +222,12 @@ class _Engine:
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
 
+    def _comm_stream(self, dev):
+        key = "comm:" + str(dev)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
+
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, x3: torch.Tensor, dt, *, toffset: int, tok_ft: torch.Tensor, perm, lam, stripes=None,
                 stop_block: int = -1, return_self_attention: bool = False, save: bool = False):
@@ -383,14 +389,22 @@ class _Engine:
         def done(name, g):
             G[name] = g
             if sink is not None:
-                if side is not None:      # the bucket's all-reduce must be ordered after BOTH streams
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    side.wait_event(ev)
-                    with torch.cuda.stream(side):
-                        sink.on_grad(name)
+                b = sink.note_grad(name)          # host-side count; a bucket index when its last gradient has landed
+                if b is None:
+                    return
+                if side is not None:
+                    # The bucket's all-reduce must be ordered after BOTH streams (LayerNorm / embedding gradients come from
+                    # the dgrad stream, weight gradients from the side stream).  A third stream waits for the two and
+                    # issues it, ONCE PER BUCKET: neither producer stream is held up.  (Round 2 made the side stream wait
+                    # for the main stream at every one of the 157 gradients, which locked the two streams together: the
+                    # one-rank forced collective showed +3 ms per step with no RCCL kernel in the trace.)
+                    comm = self._comm_stream(dev)
+                    comm.wait_stream(main)
+                    comm.wait_stream(side)
+                    with torch.cuda.stream(comm):
+                        sink.reduce_bucket(b)
                 else:
-                    sink.on_grad(name)
+                    sink.reduce_bucket(b)
 
         def wgrad(name_w, name_b, dy, x, n_out, k_out, w_shape=None):
             gw, gb = buf(name_w, n_out, k_out), buf(name_b, n_out)

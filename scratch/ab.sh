@@ -5,16 +5,17 @@
 tag=$1; A=$2; B=$3; reps=${4:-3}
 mkdir -p gpurun_out/$tag
 for i in $(seq 1 $reps); do
-  python bench.py --no-cpu-baseline --no-kernel-timing --no-side-cases --steps 20 $A > gpurun_out/$tag/a$i.json 2>/dev/null
-  python bench.py --no-cpu-baseline --no-kernel-timing --no-side-cases --steps 20 $B > gpurun_out/$tag/b$i.json 2>/dev/null
+  python bench.py --no-cpu-baseline --no-kernel-timing --no-side-cases --steps 20 $A > gpurun_out/$tag/a$i.json 2> gpurun_out/$tag/a$i.err
+  python bench.py --no-cpu-baseline --no-kernel-timing --no-side-cases --steps 20 $B > gpurun_out/$tag/b$i.json 2> gpurun_out/$tag/b$i.err
 done
 python - "$tag" "$A" "$B" "$reps" <<'PY'
 import json, sys
 tag, A, B, reps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 rows = []
 for i in range(1, reps + 1):
-    a = json.loads(open(f"gpurun_out/{tag}/a{i}.json").read().strip().splitlines()[-1])["ms_per_step"]
-    b = json.loads(open(f"gpurun_out/{tag}/b{i}.json").read().strip().splitlines()[-1])["ms_per_step"]
+    line = lambda f: next(l for l in open(f).read().splitlines() if l.startswith('{"metric"'))
+    a = json.loads(line(f"gpurun_out/{tag}/a{i}.json"))["ms_per_step"]
+    b = json.loads(line(f"gpurun_out/{tag}/b{i}.json"))["ms_per_step"]
     rows.append((a, b))
 print(f"A = bench.py {A!r}\nB = bench.py {B!r}")
 for a, b in rows:
