@@ -805,6 +805,9 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     // COMPUTE phase with one operand unit's DMA (this wave's 4 -- or NA -- instructions) spread between the MFMAs: the
     // memory front end accepts about one 8-line instruction per 30 clk per CU, so the four waves of a group
     // feed it at exactly its rate, never in a burst, and a wave is never parked in the queue while it owes MFMAs.
+#ifdef MAEST_ABLATE_ROLLING
+    int roll_q = 0;
+#endif
     auto compute = [&](bool dma, int stage, bool is_b, int buf) {
         const int ndma = is_b ? 4 : NA;
         __builtin_amdgcn_s_setprio(1);
@@ -840,6 +843,24 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
 #endif
             }
         }
+#ifdef MAEST_ABLATE_ROLLING
+        // timing experiment: what would the stores of the PREVIOUS tile's C cost if they rode in this tile's main loop?
+        // One full-line 16-byte store per COMPUTE phase (16 per wave and tile = its 128 x 64 bf16 sub-tile), data from
+        // a fragment register (wrong on purpose), optionally through a wave-private LDS bounce (ROLLING=2).
+        if (roll_q < 16) {
+            const int row = wm * 128 + roll_q * 8 + (lane >> 3);
+            chunk16 v = fa[0][0];
+#if MAEST_ABLATE_ROLLING >= 2
+            char* bounce = smem + 4 * W2_UNIT + wave * 4096 + lane * 16;     // (buffer 4: wrong on purpose)
+            *reinterpret_cast<chunk8*>(bounce) = chunk8{v[0], v[1]};
+            *reinterpret_cast<chunk8*>(bounce + 8) = chunk8{v[2], v[3]};
+            v = *reinterpret_cast<const chunk16*>(bounce + ((lane & 7) ^ 5) * 16 - (lane & 7) * 16);
+#endif
+            __builtin_nontemporal_store(v, reinterpret_cast<chunk16*>(reinterpret_cast<char*>(p.C) +
+                                        ((int64_t)(m0 + row) * p.ldc + n0 + wn * 64) * 2 + (lane & 7) * 16));
+        }
+        ++roll_q;
+#endif
         __builtin_amdgcn_s_setprio(0);
     };
     auto next = [](int b, int by) { b += by; return b >= W2_NBUF ? b - W2_NBUF : b; };
@@ -897,6 +918,18 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();          // un-stagger
     MAEST_WAIT_VMCNT(0);   // drain the past-the-end loads before LDS is reused
     __syncthreads();       // LDS becomes the C staging area
+#if defined(MAEST_ABLATE_NO_EPILOGUE) || defined(MAEST_ABLATE_ROLLING)
+    // timing experiments: no C-tile epilogue at all (results are not stored); the accumulators are kept alive
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" :: "v"(acc[i][j]));
+#endif
+        }
+    return;
+#endif
     if constexpr (MTW == 2) {
         if (p.out_dtype == MAEST_BF16) epilogueH<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
         else epilogueH<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
