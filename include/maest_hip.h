@@ -67,7 +67,11 @@ const char* maest_last_error(void);
 #define MAEST_OPT_GEMM_EPILOGUE 2
 #define MAEST_OPT_ATTN_BWD 3 /* env MAEST_ATTN_BWD, default 0: fused one-pass attention backward where it applies
                                 (bf16, N <= 320), query tiles fed by LDS-DMA; 1 = always the two-kernel dK/dV + dQ
-                                form; 2 = the fused form with register-fed tiles and the delta computed in flight */
+                                form; 2 = the fused form with register-fed tiles and the delta computed in flight;
+                                3 = as 0 without the persistent form (one workgroup per (batch, head) at every shape).
+                                Under 0, complete backward passes with 257 <= N <= 320 run the persistent form (one
+                                workgroup per CU walks its (batch, head) items, the next item's K / V / query tiles
+                                arriving while the current one computes) */
 #define MAEST_OPT_GEMM_TAIL 5 /* env MAEST_GEMM_TAIL, default 1: the last partial round of a large NT GEMM runs in 128-row
                                  tiles (a second launch) when at most half a round of 256-row tiles is left over; 0: off;
                                  2: every tile a 128-row tile (tests) */

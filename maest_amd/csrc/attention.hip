@@ -886,6 +886,24 @@ __device__ __forceinline__ void mma_transposed_swz(f32x16_t (&acc)[2], const cha
     }
 }
 
+// MAEST_ATTN_PROF: timing instrumentation only (scratch/attn_prof.py builds a second library with it; never defined in
+// the product build): shader-clock stamps of every wave of the workgroups with blockIdx % 256 == 5, per query tile.
+#ifdef MAEST_ATTN_PROF
+__device__ unsigned long long* g_attn_prof = nullptr;
+#define PROF_DECL() unsigned long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); pst[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PROF_FLUSH(t) do { if (g_attn_prof != nullptr && (blockIdx.x & 255) == 5 && lane == 0) { \
+        unsigned long long* d_ = g_attn_prof + ((((blockIdx.x >> 8) * FB_MAXW + wave) * 16 + (t)) * 8); \
+        for (int k_ = 0; k_ < 8; ++k_) d_[k_] = pst[k_]; } } while (0)
+#define PROF_FLUSH3(g) do { if (g_attn_prof != nullptr && blockIdx.x == 5 && lane == 0 && (g) < 128) { \
+        unsigned long long* d_ = g_attn_prof + ((wave * 128 + (g)) * 8); \
+        for (int k_ = 0; k_ < 8; ++k_) d_[k_] = pst[k_]; } } while (0)
+#else
+#define PROF_DECL() ((void)0)
+#define PROF_STAMP(k) ((void)0)
+#define PROF_FLUSH(t) ((void)0)
+#define PROF_FLUSH3(g) ((void)0)
+#endif
 __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf16_t* __restrict__ qkv,
                                                                         const bf16_t* __restrict__ dout,
                                                                         const float* __restrict__ lse,
@@ -920,6 +938,9 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
 
     const bool key_wave = wave < nkw;
     const int aux = wave - nkw;                    // 0: Q feeder + dQ[:, 0:32], 1: dO feeder + dQ[:, 32:64]; >= 2: filler
+#ifdef MAEST_ATTN_PROF
+    const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- prologue, all waves: K of every key block -> LDS by DMA
     dma_rows128(k_lds, kbase, QKV_LD, 0, wave, nkw * 4, nwaves, N, lane);
@@ -940,7 +961,9 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
         MAEST_ATTN_WAIT_VM0();                             // this wave's share of the K DMA (and its fragments) landed
         __builtin_amdgcn_s_barrier();                      // K in LDS, query tile 0 staged
         int buf = 0;
+        PROF_DECL();
         for (int t = 0; t < nqt; ++t) {
+            PROF_STAMP(0);
             const char* q_lds = qbuf0 + buf * F2_QBUF;
             const char* do_lds = q_lds + 32 * 128;
             const float* lse_lds = reinterpret_cast<const float*>(q_lds + 2 * 32 * 128);
@@ -950,6 +973,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
             for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
             mma_rows_swz(s, q_lds, 0, lane, kf);         // S[q][key]
             mma_rows_swz(dp, do_lds, 0, lane, vf);       // dP[q][key]
+            PROF_STAMP(1);
             char* ds_row = ds0 + (t & 1) * DSBUF + key * FB_DS_PITCH;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -972,11 +996,16 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
                 w[1] = key_ok ? pack_bf2(dp[4 * g + 2], dp[4 * g + 3]) : 0u;
                 *reinterpret_cast<chunk8*>(ds_row + ql * 2) = w;
             }
+            PROF_STAMP(2);
             mma_transposed_swz(dv, do_lds, 0, lane, s);   // dV^T[d][key] += dO^T[d][q] P[q][key]
             mma_transposed_swz(dk, q_lds, 0, lane, dp);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            PROF_STAMP(3);
             buf = buf == 2 ? 0 : buf + 1;
             __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): the dS tile is written
+            PROF_STAMP(4);
             __builtin_amdgcn_s_barrier();
+            PROF_STAMP(5);
+            PROF_FLUSH(t);
         }
         __builtin_amdgcn_s_barrier();                      // the aux waves are done with K and the last dS tile
         // dK / dV: registers -> this wave's private LDS patch (row = key, 128 B of d) -> whole rows, 16 B per lane
@@ -1029,25 +1058,43 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
             if (aux == 0) *dstp = live ? v * LOG2E : -NEG_BIG;   // padded rows: lse = +BIG -> P = 2^(-BIG) = 0
             else *dstp = live ? v : 0.0f;
         };
+        // K^T[32 d of this wave][every key] stays in REGISTERS for the whole (batch, head) (80 registers at 10 key blocks: the
+        // aux waves have them to spare under the 168 budget), gathered once from the K tile after the first barrier; a dQ
+        // job then reads only its dS^T fragments -- two blocks ahead of the MFMAs that consume them.  (The per-tile
+        // timeline, scratch/attn_prof.py, showed the aux waves arriving LAST at every barrier: 2200 of their 3650 cycles
+        // per tile were this product, 16 transpose reads in front of every 4 MFMAs.)
+        chunk16 ktf[FB_MAXW - 2][2];
+        auto kt_load = [&]() {
+            if (aux > 1) return;
+#pragma unroll
+            for (int kb = 0; kb < FB_MAXW - 2; ++kb)
+                if (kb < nkw) {
+                    ktf[kb][0] = frag_from_rows_swz(k_lds, kb * 32, 0, aux, lane);                 // K^T[d][key]
+                    ktf[kb][1] = frag_from_rows_swz(k_lds, kb * 32, 1, aux, lane);
+                }
+        };
         auto dq_compute = [&](f32x16_t& acc, int t) {      // dQ^T[32 d of this wave][32 q of tile t]
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             if (aux > 1) return;
             const char* ds = ds0 + (t & 1) * DSBUF;
-            for (int kb = 0; kb < nkw; kb += 2) {
-                const int kb1 = kb + 1 < nkw ? kb + 1 : kb;     // odd count: the last trip re-reads a block, weight 0
-                chunk16 a[4], bq[4];
+            chunk16 bq[3][2];                              // dS^T[key][q] of blocks kb, kb + 1, kb + 2
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    a[s] = frag_from_rows_swz(k_lds, kb * 32, s, aux, lane);                      // K^T[d][key]
-                    bq[s] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb * 32, s, 0, lane);            // dS^T[key][q]
-                    a[2 + s] = frag_from_rows_swz(k_lds, kb1 * 32, s, aux, lane);
-                    bq[2 + s] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb1 * 32, s, 0, lane);
+            for (int kb = 0; kb < 2; ++kb)
+                if (kb < nkw) {
+                    bq[kb][0] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb * 32, 0, 0, lane);
+                    bq[kb][1] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb * 32, 1, 0, lane);
                 }
-                if (kb + 1 >= nkw) { bq[2] = chunk16{0u, 0u, 0u, 0u}; bq[3] = chunk16{0u, 0u, 0u, 0u}; }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma_chunk<T>(acc, a[j], bq[j]);
-            }
+            for (int kb = 0; kb < FB_MAXW - 2; ++kb)
+                if (kb < nkw) {
+                    if (kb + 2 < nkw) {
+                        bq[(kb + 2) % 3][0] = frag_from_rows_bf16<FB_DS_PITCH>(ds, (kb + 2) * 32, 0, 0, lane);
+                        bq[(kb + 2) % 3][1] = frag_from_rows_bf16<FB_DS_PITCH>(ds, (kb + 2) * 32, 1, 0, lane);
+                    }
+                    mma_chunk<T>(acc, ktf[kb][0], bq[kb % 3][0]);
+                    mma_chunk<T>(acc, ktf[kb][1], bq[kb % 3][1]);
+                }
         };
         auto dq_store = [&](const f32x16_t& acc, int t) {
             if (t < 0 || aux > 1) return;
@@ -1071,18 +1118,27 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
         MAEST_ATTN_WAIT_VM0();
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();                      // K in LDS, query tile 0 staged (tile 1 landed too)
+        kt_load();
+        PROF_DECL();
         for (int t = 0; t < nqt; ++t) {
             // Everything issued one step ago has landed by now: the DMA of tile t + 1, and the dQ stores of job
             // t - 2, which were issued BEFORE the dQ product of that step -- a store issued right in front of this
             // wait would put its latency on the critical path (vmcnt counts stores too on gfx950).
+            PROF_STAMP(0);
             MAEST_ATTN_WAIT_VM0();
+            PROF_STAMP(1);
             stat_store(st_next, t + 1);
             tile_dma(t + 2);                               // lands during this step and the next one
             st_next = stat_load(t + 2);
             dq_store(dq_prev, t - 2);
+            PROF_STAMP(2);
             if (t > 0) dq_compute(dq_prev, t - 1);
+            PROF_STAMP(3);
             __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): statistics of tile t + 1 are in LDS
+            PROF_STAMP(4);
             __builtin_amdgcn_s_barrier();
+            PROF_STAMP(5);
+            PROF_FLUSH(t);
         }
         dq_store(dq_prev, nqt - 2);
         dq_compute(dq_prev, nqt - 1);
@@ -1097,11 +1153,335 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
         __builtin_amdgcn_s_barrier();                      // LDS may be reused by the key waves' epilogue
         __syncthreads();
     }
+#ifdef MAEST_ATTN_PROF
+    {
+        unsigned long long pst[8] = {prof_t0, __builtin_amdgcn_s_memtime(), __builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0};
+        PROF_FLUSH(15);
+    }
+#endif
 }
 
 static int attn_bwd_fused2_smem(int N) {
     const int nkw = (N + 31) / 32;
     return nkw * 32 * 128 + 2 * nkw * 32 * FB_DS_PITCH + 3 * F2_QBUF;
+}
+
+// =================================================================================== fused backward, persistent (bf16, 257 <= N <= 320)
+// The per-tile timeline of attn_bwd_fused2_kernel (MAEST_ATTN_PROF, scratch/attn_prof.py; B = 256, N = 290) shows a workgroup
+// living 58 k cycles of which 12.4 k pass before its first query tile (K, the K / V fragments and two query tiles fetched
+// by all 256 workgroups of a round at once: 150 KB per CU at the ~11 B/clk/CU an all-CU burst gets) and 7 k after its last
+// one (dK / dV staging and stores): a third of the time the matrix pipe has nothing to do, and HBM idles during the tiles.
+// Here a workgroup is PERSISTENT -- one per CU, walking its (batch, head) items -- and everything item i + 1 needs is
+// fetched while item i computes:
+//   * K and V of the next item arrive by LDS-DMA (both live in LDS now, 2 x 40 KiB; the key waves take their K / V fragments
+//     from there at an item's first tile and the aux waves their K^T registers, after which the tiles are free for the next
+//     item's prefetch: one 1-KiB piece per key wave and step, steps 1 .. nqt - 1);
+//   * the query-tile ring simply runs on across the item boundary (tiles of the next item follow two steps ahead), and so
+//     do the statistics and the dQ jobs of the aux waves (job g - 1 computed at step g, stored at step g + 1);
+//   * all LDS-DMA is issued by the KEY waves (it was 500 of the aux waves' 3650 cycles per tile, and they arrived last at
+//     every barrier): waves 0..3 one Q piece, 4..7 one dO piece per step, retired by a counted vmcnt one step later;
+//   * dK / dV leave the registers as 16-byte row pieces (one half-wave exchange per piece) at the first step of the NEXT
+//     item -- no LDS staging (LDS is never free here), and issued behind the end-of-step wait so that the counted vmcnt
+//     only ever keeps LOADS of the current step in flight (stores may complete out of order with loads).
+// Shapes: q_rows == N and 9 <= ceil(N / 32) <= 10 (the prefetch needs nkw * (nkw - 1) >= 8 * nkw piece slots and eight
+// key waves for the tile pieces): the 10 s training shapes N = 281, 290.  Everything else keeps attn_bwd_fused2_kernel.
+__device__ __forceinline__ void row_frags_lds_swz(chunk16 (&f)[4], const char* tile, int row, int h) {
+    const char* rp = tile + row * 128;
+    const int fz = swz128(row);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const chunk16*>(rp + (((2 * s + h) ^ fz) << 4));
+}
+// dK^T / dV^T accumulator pair [64 d][32 keys] (lane = key, registers = d: d = 32 db + 8 g + 4 h + j) -> 16-byte pieces of
+// the key's row: the two half-waves exchange one 8-byte quarter so that lane (key, h) owns d = 32 db + 8 (pair + 2 h) .. + 7
+__device__ __forceinline__ void store_dT_rows16(const f32x16_t (&acc)[2], bf16_t* row_ptr, int lane, float mul, bool ok) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        uint32_t pk[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            pk[g][0] = pack_bf2(acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul);
+            pk[g][1] = pack_bf2(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
+        }
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+            const uint32_t s0 = h ? pk[pair][0] : pk[pair + 2][0], s1 = h ? pk[pair][1] : pk[pair + 2][1];
+            const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 32, 64), r1 = (uint32_t)__shfl_xor((int)s1, 32, 64);
+            chunk16 c;
+            c[0] = h ? r0 : pk[pair][0];
+            c[1] = h ? r1 : pk[pair][1];
+            c[2] = h ? pk[pair + 2][0] : r0;
+            c[3] = h ? pk[pair + 2][1] : r1;
+            if (ok) *reinterpret_cast<chunk16*>(row_ptr + db * 32 + 8 * (pair + 2 * h)) = c;
+        }
+    }
+}
+
+__global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused3_kernel(const bf16_t* __restrict__ qkv,
+                                                                        const bf16_t* __restrict__ dout,
+                                                                        const float* __restrict__ lse,
+                                                                        const float* __restrict__ delta,
+                                                                        bf16_t* __restrict__ dqkv, int B, int N,
+                                                                        float scale) {
+    using T = bf16_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nkw = (N + 31) >> 5, nqt = nkw;      // key waves = key blocks = query tiles (9 or 10)
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;            // nkw + 2
+    // LDS map: K [nkw*32][128 B] | V [nkw*32][128 B] | 2 x dS [nkw*32][32 q] | 3 x { Q tile, dO tile, lse[32], delta[32] }
+    const int DSBUF = nkw * 32 * FB_DS_PITCH;
+    char* k_lds = smem;
+    char* v_lds = smem + nkw * 32 * 128;
+    char* ds0 = v_lds + nkw * 32 * 128;
+    char* qbuf0 = ds0 + 2 * DSBUF;
+
+    const int items = B * NHEADS, stride = gridDim.x, it0 = blockIdx.x;
+    const int nitems = (items - it0 + stride - 1) / stride;
+    const int total = nitems * nqt;                // steps (= query tiles) of this workgroup
+
+    auto q_of = [&](int it) { return qkv + (int64_t)(it / NHEADS) * N * QKV_LD + (it % NHEADS) * HD; };
+    auto do_of = [&](int it) { return dout + (int64_t)(it / NHEADS) * N * OUT_LD + (it % NHEADS) * HD; };
+    auto dq_of = [&](int it) { return dqkv + (int64_t)(it / NHEADS) * N * QKV_LD + (it % NHEADS) * HD; };
+
+    const bool key_wave = wave < nkw;
+    const int aux = wave - nkw;                    // 0: lse + dQ[:, 0:32], 1: delta + dQ[:, 32:64]
+
+    // ---- prologue, all waves: K and V of the first item -> LDS by DMA
+    {
+        const T* kb0 = q_of(it0) + NHEADS * HD;
+        dma_rows128(k_lds, kb0, QKV_LD, 0, wave, nkw * 4, nwaves, N, lane);
+        dma_rows128(v_lds, kb0 + NHEADS * HD, QKV_LD, 0, wave, nkw * 4, nwaves, N, lane);
+    }
+
+    if (key_wave) {
+        // =============================================================================== key waves
+        const int key = wave * 32 + (lane & 31);
+        const bool key_ok = key < N;
+        const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
+        // this wave's piece of query tile t of item `it` -> ring slot (waves 0..3: 8 rows of Q, 4..7: 8 rows of dO)
+        auto tile_piece = [&](int it, int t, int slot, int lv) {
+            const bool isdo = wave >= 4;
+            const int j = wave & 3;
+            char* dst = qbuf0 + slot * F2_QBUF + (isdo ? 32 * 128 : 0);
+            dma_rows128(dst, isdo ? do_of(it) : q_of(it), isdo ? OUT_LD : QKV_LD, t * 32, j, j + 1, 1, N, lv);
+        };
+        if (wave < 8) { tile_piece(it0, 0, 0, lane); tile_piece(it0, 1, 1, lane); }
+        chunk16 kf[4], vf[4];
+        f32x16_t dk[2], dv[2];
+        MAEST_ATTN_WAIT_VM0();                             // this wave's share of K, V and of tiles 0, 1 landed
+        __builtin_amdgcn_s_barrier();
+        int it = it0, t = 0, slot = 0;                     // the tile of this step
+        int it2 = it0, t2 = 2, slot2 = 2;                  // the tile two steps ahead (its DMA is issued now)
+        PROF_DECL();
+        for (int g = 0; g < total; ++g) {
+            PROF_STAMP(0);
+            const bool first = t == 0, last = t == nqt - 1;
+            const int itn = it + stride;                   // next item of this workgroup
+            // the lane index as the DMA address arithmetic sees it is redefined every step: hoisted out of the loop, the
+            // per-lane source offsets are spilled, and the reload's compiler-placed vmcnt(0) drains the pieces in flight
+            // (measured: 1900 cycles per step in front of the first MFMA)
+            int lv = lane;
+#if defined(__AMDGCN__)
+            asm volatile("" : "+v"(lv));
+#endif
+#ifndef MAEST_ABLATE_F3
+#define MAEST_ABLATE_F3 0      // timing experiments only (scratch/attn_ablate.sh; results wrong on purpose): bit 0 no dK / dV stores,
+#endif                         // 1 no K / V prefetch, 2 no tile pieces, 3 no dQ product, 4 no dQ stores, 5 no softmax math, 6 no dV / dK products
+            if (first && g > 0 && !(MAEST_ABLATE_F3 & 1)) {  // dK, dV of the item that ended a step ago
+                T* row = dq_of(it - stride) + (uint32_t)(key * QKV_LD + NHEADS * HD);
+                store_dT_rows16(dk, row, lane, scale, key_ok);
+                store_dT_rows16(dv, row + NHEADS * HD, lane, 1.0f, key_ok);
+            }
+            // LDS-DMA of this step: the next item's K / V piece first, the tile piece second
+            bool pref = false;
+            if (!first && itn < items && !(MAEST_ABLATE_F3 & 2)) {
+                const int pidx = (t - 1) * nkw + wave;
+                if (pidx < 8 * nkw) {
+                    const bool isv = pidx >= 4 * nkw;
+                    const int j = isv ? pidx - 4 * nkw : pidx;
+                    const T* base = q_of(itn) + (isv ? 2 : 1) * NHEADS * HD;
+                    dma_rows128(isv ? v_lds : k_lds, base, QKV_LD, 0, j, j + 1, 1, N, lv);
+                    pref = true;
+                }
+            }
+            const bool tp = wave < 8 && g + 2 < total && !(MAEST_ABLATE_F3 & 4);
+            if (tp) tile_piece(it2, t2, slot2, lv);
+            if (first) {
+                row_frags_lds_swz(kf, k_lds, key, h);
+                row_frags_lds_swz(vf, v_lds, key, h);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.0f; dv[db][r] = 0.0f; }
+            }
+            const char* q_lds = qbuf0 + slot * F2_QBUF;
+            const char* do_lds = q_lds + 32 * 128;
+            const float* lse_lds = reinterpret_cast<const float*>(q_lds + 2 * 32 * 128);
+            const float* dl_lds = lse_lds + 32;
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+            PROF_STAMP(1);
+            mma_rows_swz(s, q_lds, 0, lane, kf);         // S[q][key]
+            mma_rows_swz(dp, do_lds, 0, lane, vf);       // dP[q][key]
+            PROF_STAMP(2);
+            char* ds_row = ds0 + (g & 1) * DSBUF + key * FB_DS_PITCH;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int ql = 8 * gq + 4 * h;           // local q of register 4 gq (4 consecutive rows)
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_lds + ql);
+                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dl_lds + ql);
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const int r = 4 * gq + e;
+                    const f32x2_t sv = {s[r], s[r + 1]}, nl = {-l4[e], -l4[e + 1]};
+                    const f32x2_t dpv = {dp[r], dp[r + 1]}, dl = {d4[e], d4[e + 1]};
+                    const f32x2_t ev = __builtin_elementwise_fma(sv, c2v, nl);
+                    const f32x2_t pv = (MAEST_ABLATE_F3 & 32) ? ev : f32x2_t{fast_exp2<T>(ev[0]), fast_exp2<T>(ev[1])};
+                    const f32x2_t dsv = (MAEST_ABLATE_F3 & 32) ? dpv : pv * (dpv - dl);
+                    s[r] = pv[0]; s[r + 1] = pv[1];       // P
+                    dp[r] = dsv[0]; dp[r + 1] = dsv[1];   // dS (unscaled)
+                }
+                chunk8 w;                                 // a padded key contributes nothing to dQ
+                w[0] = key_ok ? pack_bf2(dp[4 * gq], dp[4 * gq + 1]) : 0u;
+                w[1] = key_ok ? pack_bf2(dp[4 * gq + 2], dp[4 * gq + 3]) : 0u;
+                *reinterpret_cast<chunk8*>(ds_row + ql * 2) = w;
+            }
+            PROF_STAMP(3);
+            if (!(MAEST_ABLATE_F3 & 64)) {
+            mma_transposed_swz(dv, do_lds, 0, lane, s);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+            mma_transposed_swz(dk, q_lds, 0, lane, dp);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dv[0][r] += s[r]; dk[0][r] += dp[r]; }
+            }
+            PROF_STAMP(4);
+            // end of step: the pieces issued a step ago have landed (only this step's may still fly); at an item's last
+            // step its K / V prefetch piece too (the next step reads K and V)
+            const int keep = (tp ? 1 : 0) + ((pref && !last) ? 1 : 0);
+            if (keep == 0) __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+            else if (keep == 1) __builtin_amdgcn_s_waitcnt(0x0071);     // vmcnt(1) lgkmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x0072);                    // vmcnt(2) lgkmcnt(0)
+            PROF_STAMP(5);
+            __builtin_amdgcn_s_barrier();
+            PROF_STAMP(6);
+            PROF_FLUSH3(g);
+            slot = slot == 2 ? 0 : slot + 1;
+            slot2 = slot2 == 2 ? 0 : slot2 + 1;
+            if (++t == nqt) { t = 0; it = itn; }
+            if (++t2 == nqt) { t2 = 0; it2 += stride; }
+        }
+        {                                                  // dK, dV of the last item
+            T* row = dq_of(it - stride) + (uint32_t)(key * QKV_LD + NHEADS * HD);
+            store_dT_rows16(dk, row, lane, scale, key_ok);
+            store_dT_rows16(dv, row + NHEADS * HD, lane, 1.0f, key_ok);
+        }
+    } else {
+        // =============================================================================== aux waves
+        const float* sbase = aux == 0 ? lse : delta;       // per-row statistic this wave carries: lse (scaled) / delta
+        auto stat_load = [&](int it, int t) -> float {     // (unconditional, clamped)
+            int row = t * 32 + (lane & 31);
+            row = row < N ? row : N - 1;
+            return sbase[(int64_t)it * N + row];
+        };
+        auto stat_store = [&](float v, int t, int slot) {
+            if (lane >= 32) return;
+            const bool live = t * 32 + lane < N;
+            float* dstp = reinterpret_cast<float*>(qbuf0 + slot * F2_QBUF + 2 * 32 * 128) + (aux == 0 ? 0 : 32) + lane;
+            if (aux == 0) *dstp = live ? v * LOG2E : -NEG_BIG;   // padded rows: lse = +BIG -> P = 2^(-BIG) = 0
+            else *dstp = live ? v : 0.0f;
+        };
+        chunk16 ktf[FB_MAXW - 2][2];                       // K^T[32 d of this wave][every key] of the current item
+        auto kt_load = [&]() {
+#pragma unroll
+            for (int kb = 0; kb < FB_MAXW - 2; ++kb)
+                if (kb < nkw) {
+                    ktf[kb][0] = frag_from_rows_swz(k_lds, kb * 32, 0, aux, lane);
+                    ktf[kb][1] = frag_from_rows_swz(k_lds, kb * 32, 1, aux, lane);
+                }
+        };
+        auto dq_compute = [&](f32x16_t& acc, int gj) {     // dQ^T[32 d of this wave][32 q] of the tile of step gj
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const char* ds = ds0 + (gj & 1) * DSBUF;
+            chunk16 bq[3][2];                              // dS^T[key][q] of blocks kb, kb + 1, kb + 2
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bq[kb][0] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb * 32, 0, 0, lane);
+                bq[kb][1] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb * 32, 1, 0, lane);
+            }
+#pragma unroll
+            for (int kb = 0; kb < FB_MAXW - 2; ++kb)
+                if (kb < nkw) {
+                    if (kb + 2 < nkw) {
+                        bq[(kb + 2) % 3][0] = frag_from_rows_bf16<FB_DS_PITCH>(ds, (kb + 2) * 32, 0, 0, lane);
+                        bq[(kb + 2) % 3][1] = frag_from_rows_bf16<FB_DS_PITCH>(ds, (kb + 2) * 32, 1, 0, lane);
+                    }
+                    mma_chunk<T>(acc, ktf[kb][0], bq[kb % 3][0]);
+                    mma_chunk<T>(acc, ktf[kb][1], bq[kb % 3][1]);
+                }
+        };
+        auto dq_store = [&](const f32x16_t& acc, T* out_item, int t) {
+            const int q = t * 32 + (lane & 31);
+            if (q < N) {
+                T* row = out_item + (uint32_t)(q * QKV_LD + aux * 32);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    store4<T>(row + 8 * gq + 4 * h, acc[4 * gq] * scale, acc[4 * gq + 1] * scale, acc[4 * gq + 2] * scale,
+                              acc[4 * gq + 3] * scale);
+            }
+        };
+        // prologue: statistics of tile 0 stored, of tile 1 in flight
+        stat_store(stat_load(it0, 0), 0, 0);
+        float st_next = stat_load(it0, 1);
+        f32x16_t dq_prev;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq_prev[r] = 0.0f;
+        MAEST_ATTN_WAIT_VM0();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();                      // K, V in LDS, query tiles 0 and 1 staged
+        kt_load();
+        int it = it0, t = 0;                               // the tile of this step
+        int t1 = 1, slot1 = 1;                             // the next tile (its statistics are stored now)
+        int it2 = it0, t2 = 2;                             // two ahead (its statistic is loaded now)
+        T* out1 = nullptr; int tj1 = 0;                    // job g - 1: computed now
+        T* out2 = nullptr; int tj2 = 0;                    // job g - 2: stored now
+        PROF_DECL();
+        for (int g = 0; g < total; ++g) {
+            // everything issued a step ago has landed: the statistic of tile g + 1 and the dQ stores of job g - 3
+            PROF_STAMP(0);
+            MAEST_ATTN_WAIT_VM0();
+            PROF_STAMP(1);
+            if (g + 1 < total) stat_store(st_next, t1, slot1);
+            if (g + 2 < total) st_next = stat_load(it2, t2);
+            if (out2 != nullptr && !(MAEST_ABLATE_F3 & 16)) dq_store(dq_prev, out2, tj2);
+            PROF_STAMP(2);
+            if (out1 != nullptr && !(MAEST_ABLATE_F3 & 8)) dq_compute(dq_prev, g - 1);
+            PROF_STAMP(3);
+            if (t == 0 && g > 0) kt_load();                // the item that starts now (its K arrived during the previous one)
+            PROF_STAMP(4);
+            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): statistics of tile g + 1 are in LDS
+            PROF_STAMP(5);
+            __builtin_amdgcn_s_barrier();
+            PROF_STAMP(6);
+            PROF_FLUSH3(g);
+            out2 = out1; tj2 = tj1;
+            out1 = dq_of(it); tj1 = t;
+            slot1 = slot1 == 2 ? 0 : slot1 + 1;
+            if (++t == nqt) { t = 0; it += stride; }
+            if (++t1 == nqt) t1 = 0;
+            if (++t2 == nqt) { t2 = 0; it2 += stride; }
+        }
+        if (out2 != nullptr) dq_store(dq_prev, out2, tj2);
+        dq_compute(dq_prev, total - 1);
+        dq_store(dq_prev, out1, tj1);
+    }
+}
+
+static int attn_bwd_fused3_smem(int N) {
+    const int nkw = (N + 31) / 32;
+    return 2 * nkw * 32 * 128 + 2 * nkw * 32 * FB_DS_PITCH + 3 * F2_QBUF;
 }
 
 static int attn_bwd_fused_smem(int N) {
@@ -1128,11 +1508,21 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
     if constexpr (sizeof(T) == 2) {
         // bf16 and at most 10 key blocks (the 10 s training shapes, N = 281 / 290): one fused pass per (batch, head)
         const int nkw = (N + 31) / 32;
-        if (nkw + 2 <= FB_MAXW && option(MAEST_OPT_ATTN_BWD) == 0) {     // DMA-fed form (+ the delta kernel)
+        const int abw = option(MAEST_OPT_ATTN_BWD);
+        if (nkw + 2 <= FB_MAXW && (abw == 0 || abw == 3)) {     // DMA-fed forms (+ the delta kernel)
             const int64_t items = (int64_t)B * N * NHEADS * 4;
             if (out != nullptr)      // (NULL: the caller filled `delta` already, maest_gemm_nt_rowdot)
                 hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
                                    (const T*)out, (const T*)dout, delta, B, N, q_rows);
+            if (abw == 0 && q_rows == N && nkw >= 9) {          // persistent form: one workgroup per CU walks the (batch, head) items
+                static DeviceOnce once_p;
+                ensure_dynamic_lds(once_p, &attn_bwd_fused3_kernel, attn_bwd_fused3_smem(32 * (FB_MAXW - 2)));
+                const int ncu = 256, nitems = B * NHEADS;
+                hipLaunchKernelGGL(attn_bwd_fused3_kernel, dim3(nitems < ncu ? nitems : ncu), dim3((nkw + 2) * 64),
+                                   attn_bwd_fused3_smem(N), st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                                   (const float*)delta, (bf16_t*)dqkv, B, N, scale);
+                return check_launch("maest_attn_bwd(fused, persistent)");
+            }
             static DeviceOnce once_g;
             ensure_dynamic_lds(once_g, &attn_bwd_fused2_kernel, attn_bwd_fused2_smem(32 * (FB_MAXW - 2)));
             const int waves = nkw + 2 < 8 ? 8 : nkw + 2;
@@ -1144,7 +1534,7 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
     }
     if (q_rows < N) {
         set_error("maest_attn_bwd_rows: q_rows = %d < N = %d is served by the fused bf16 kernel only (N <= %d, "
-                  "MAEST_OPT_ATTN_BWD = 0)", q_rows, N, 32 * (FB_MAXW - 2));
+                  "MAEST_OPT_ATTN_BWD = 0 or 3)", q_rows, N, 32 * (FB_MAXW - 2));
         return MAEST_ERR_INVALID;
     }
     if constexpr (sizeof(T) == 2) {
@@ -1180,6 +1570,12 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
 }  // namespace maest
 
 using namespace maest;
+
+#ifdef MAEST_ATTN_PROF
+extern "C" int maest_debug_attn_prof(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), &p, sizeof(p));
+}
+#endif
 
 extern "C" int maest_attn_fwd_rows(const void* qkv, void* out, float* lse, int B, int N, int dtype, float scale,
                                    int q_rows, void* stream) {

@@ -279,7 +279,7 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False, q_
 
 def attn_bwd_rows_supported(dtype, N: int) -> bool:
     """Whether maest_attn_bwd_rows serves q_rows < N for this shape (the fused bf16 kernel: include/maest_hip.h)."""
-    return dtype == torch.bfloat16 and -(-N // 32) + 2 <= 12 and get_option("attn_bwd") == 0
+    return dtype == torch.bfloat16 and -(-N // 32) + 2 <= 12 and get_option("attn_bwd") in (0, 3)
 
 
 def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float, q_rows=None, x3: bool = False, delta=None):

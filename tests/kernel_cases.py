@@ -234,6 +234,13 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2):
         with ops.options(attn_bwd=2):     # the fused form with register-fed tiles (delta computed in flight)
             dq3 = ops.attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
         close(dq3, g, rt, at, "attention backward (fused, register-fed)")
+        if N > 256:
+            # the default call above took the PERSISTENT form (one workgroup per CU walking its (batch, head) items); the
+            # one-workgroup-per-item form against the oracle as well, and the two bit for bit (same sums in the same order)
+            with ops.options(attn_bwd=3):
+                dq4 = ops.attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
+            close(dq4, g, rt, at, "attention backward (fused, one workgroup per item)")
+            assert torch.equal(dq4, dqkv), "persistent and per-item fused attention backward differ"
 
 
 def case_attention_head_rows(dev, dtype, B, N, seed=25):

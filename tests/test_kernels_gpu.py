@@ -88,6 +88,14 @@ def test_attention(dtype, BN):
     KC.case_attention(DEV, dtype, *BN)
 
 
+@pytest.mark.parametrize("BN", [(24, 290), (23, 281), (22, 257), (43, 320)])
+def test_attention_backward_persistent_crosses_item_boundaries(BN):
+    """B * 12 > 256 (batch, head) items: workgroups of the persistent fused backward walk more than one item (the next
+    item's K / V / query tiles prefetched under the current one, dK / dV stored a step late); against the fp32 autograd
+    oracle and bit for bit against the one-workgroup-per-item form."""
+    KC.case_attention(DEV, torch.bfloat16, *BN)
+
+
 def test_split_bf16_products():
     """precision="bf16x3" kernels at model shapes: 1e-4 of the output scale against fp64."""
     e, eo = KC.case_split_precision(DEV, M=8192, N=768, K=768, B=2, Ntok=290)
