@@ -256,6 +256,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(c
     float m_run = NEG_BIG, l_run = 0.0f;
     const float c2 = scale * LOG2E;
 
+#ifndef MAEST_ABLATE_FWD
+#define MAEST_ABLATE_FWD 0     // timing experiments only (scratch/attn_ablate.sh fwd; results wrong on purpose): bit 0 no softmax math,
+#endif                         // 1 no P V products, 2 no S products, 3 no K / V tile refills, 4 no O store
     const int ntiles = (N + 63) / 64;
     TileRegs<T> kr, vr;
     tile_load<T>(kr, kbase, QKV_LD, 0, N, tid);
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(c
     for (int kt = 0; kt < ntiles; ++kt) {
         const char* k_lds = smem + (kt & 1) * 2 * C::TILE;
         const char* v_lds = k_lds + C::TILE;
-        const bool more = kt + 1 < ntiles;
+        const bool more = kt + 1 < ntiles && !(MAEST_ABLATE_FWD & 8);
         if (more) {
             tile_load<T>(kr, kbase, QKV_LD, (kt + 1) * 64, N, tid);
             tile_load<T>(vr, vbase, QKV_LD, (kt + 1) * 64, N, tid);
@@ -277,8 +280,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(c
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
-            mma_rows<T, X3>(s[kb], k_lds, kb * 32, lane, qf);
+            for (int r = 0; r < 16; ++r) s[kb][r] = (MAEST_ABLATE_FWD & 4) ? (float)(lane + r) : 0.0f;
+            if (!(MAEST_ABLATE_FWD & 4)) mma_rows<T, X3>(s[kb], k_lds, kb * 32, lane, qf);
         }
         // online softmax in the scaled log2 domain: p = 2^(s*c2 - m).  Only the ragged last tile pays for
         // key masking; the elementwise work is written on float pairs (v_pk_fma_f32 / v_pk_add_f32).
@@ -290,10 +293,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(c
                     if (kt * 64 + kb * 32 + frag_row(r, lane) >= N) s[kb][r] = NEG_BIG;
         }
         float mx = NEG_BIG;
+        if (!(MAEST_ABLATE_FWD & 1)) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx * c2);
         const float alpha = fast_exp2<T>(m_run - m_new);
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(c
             for (int r = 0; r < 16; r += 2) {
                 const f32x2_t sv = {s[kb][r], s[kb][r + 1]};
                 const f32x2_t e = __builtin_elementwise_fma(sv, c2v, nm);
-                const f32x2_t pv = {fast_exp2<T>(e[0]), fast_exp2<T>(e[1])};
+                const f32x2_t pv = (MAEST_ABLATE_FWD & 1) ? sv : f32x2_t{fast_exp2<T>(e[0]), fast_exp2<T>(e[1])};
                 s[kb][r] = pv[0];
                 s[kb][r + 1] = pv[1];
                 ps += pv;
@@ -318,7 +323,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(c
             for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         // O^T[d][q] += V^T[d][key] P^T[key][q]   (V^T gathered from the row-major V tile)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) mma_transposed<T, X3>(o, v_lds, kb * 32, lane, s[kb]);
+        for (int kb = 0; kb < 2; ++kb) {
+            if (!(MAEST_ABLATE_FWD & 2)) mma_transposed<T, X3>(o, v_lds, kb * 32, lane, s[kb]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[kb][r] += s[kb][r];
+            }
+        }
         }
         if (more) {
             char* nk = smem + ((kt + 1) & 1) * 2 * C::TILE;
@@ -329,7 +340,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(c
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q < N && wave_active) {
+    if (q < N && wave_active && (!(MAEST_ABLATE_FWD & 16) || l_tot == 12345.0f)) {
+        // (staging O through LDS for whole-row stores was measured: no gain at N = 290, -16 % at N = 560 -- the O write costs
+        // its HBM bytes, not its access pattern; profiles/r03_attn_fwd_ablation.txt)
         store_dT<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv);
         if (lse != nullptr && h == 0) lse[((int64_t)b * NHEADS + head) * N + q] = m_run * LN2 + logf(l_tot);
     }
