@@ -4,14 +4,14 @@
 //  Spectrogram(n_fft=512, hop=256, power=2, center=True/reflect) :29-34 and MelScale(96, slaney) :36-42;
 //  constants :16-24.)
 //
-// Algorithmically HBM-bound (0.88 MB / 10 s clip in+out vs ~7 MFLOP of FFT); as written it is instruction-issue bound
-// (~800 VALU / LDS instructions per frame and wave: 0.25 ms for 256 clips = 0.11 of the HBM roofline, 1.0 M clips/s --
-// 200x the rate the training step consumes them at).  A workgroup owns 64 consecutive frames
-// of one clip so that the [96, T] output is written as 256-byte runs along T; each of its 4 waves
-// transforms 16 frames, one at a time (the next frame's samples in flight), entirely in LDS and without block barriers: the 512 real samples are packed as 256
-// complex points, transformed by 4 radix-4 DIF stages (one butterfly per lane per stage), unpacked
-// to the 257-bin one-sided spectrum, and projected onto the mel bands with the filterbank stored in
-// band-sparse form (each triangular band touches <= fb_stride consecutive bins).  All arithmetic is fp32.
+// Algorithmically HBM-bound (0.88 MB / 10 s clip in+out vs ~7 MFLOP of FFT); instruction-issue bound as written.  A
+// workgroup owns 64 consecutive frames of one clip so that the [96, T] output is written as 256-byte runs along T; each of
+// its 4 waves transforms 16 frames, FOUR at a time (16 lanes per frame, 16 complex points per lane; the next four frames'
+// samples in flight), without block barriers: the 512 real samples are packed as 256 complex points and transformed as
+// 256 = 16 x 16 -- two 16-point DFTs in registers around one exchange through LDS --, unpacked to the 257-bin one-sided
+// spectrum, and projected onto the mel bands with the filterbank stored in band-sparse form (each triangular band touches
+// <= fb_stride consecutive bins).  All arithmetic is fp32.  (Rounds 1-2: one frame per wave, four radix-4 stages through
+// LDS, ~800 instructions per frame and wave = 0.11 of the HBM roofline; DESIGN.md section 4 has the before / after.)
 #include "common.h"
 
 namespace maest {
@@ -29,7 +29,11 @@ struct cplx {
 };
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+// (fused multiply-adds written out: the library is built with -ffp-contract=off for the bit-exact fp32 paths elsewhere; the mel
+//  front end is checked against its oracle to 2e-4 after the log, and its kernel is bound by instruction issue)
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return {__builtin_fmaf(a.re, b.re, -(a.im * b.im)), __builtin_fmaf(a.re, b.im, a.im * b.re)};
+}
 __device__ __forceinline__ cplx mul_neg_i(cplx a) { return {a.im, -a.re}; }   // a * (-i)
 __device__ __forceinline__ int rev4_256(int k) {  // reverse the four base-4 digits of k
     return ((k & 3) << 6) | (((k >> 2) & 3) << 4) | (((k >> 4) & 3) << 2) | ((k >> 6) & 3);
@@ -43,35 +47,71 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// sample fetch of frame t: the 8 samples lane `lane` packs as complex points lane + 64 j.  INTERIOR (block-uniform: all 64
-// frames of the block lie inside the clip and the clip starts 8-byte aligned): four plain 8-byte loads; otherwise
-// clamped (frames >= T are computed on the last frame's data and not stored) and reflect-padded, sample by sample
-template <bool INTERIOR>
-__device__ __forceinline__ void mel_fetch(float (&x)[4][2], const float* __restrict__ wsrc, int t, int T, int S, int lane) {
-    if (INTERIOR) {
-        const float* p0 = wsrc + t * MEL_HOP - MEL_NFFT / 2 + 2 * lane;
+// ---- 16-point DFT in registers: v[n] (n = 4 a + b) -> Y[k] (k = c + 4 d) left at v[4 c + d] (base-4 digit reversal)
+__device__ __forceinline__ void dft4(cplx& a0, cplx& a1, cplx& a2, cplx& a3) {
+    const cplx b0 = cadd(a0, a2), b1 = csub(a0, a2), b2 = cadd(a1, a3), b3 = mul_neg_i(csub(a1, a3));
+    a0 = cadd(b0, b2); a1 = cadd(b1, b3); a2 = csub(b0, b2); a3 = csub(b1, b3);
+}
+__device__ __forceinline__ void dft16(cplx (&v)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float2 v = *reinterpret_cast<const float2*>(p0 + 128 * j);
-            x[j][0] = v.x; x[j][1] = v.y;
+    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);     // over a: v[4 c + b] = T[c][b]
+    // T[c][b] *= exp(-2 pi i b c / 16)
+    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], cplx{C1, -S1});
+    v[4 * 2 + 1] = cmul(v[4 * 2 + 1], cplx{R, -R});
+    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], cplx{S1, -C1});
+    v[4 * 1 + 2] = cmul(v[4 * 1 + 2], cplx{R, -R});
+    v[4 * 2 + 2] = mul_neg_i(v[4 * 2 + 2]);
+    v[4 * 3 + 2] = cmul(v[4 * 3 + 2], cplx{-R, -R});
+    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], cplx{S1, -C1});
+    v[4 * 2 + 3] = cmul(v[4 * 2 + 3], cplx{-R, -R});
+    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], cplx{-C1, S1});
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);   // over b: v[4 c + d] = Y[c + 4 d]
+}
+__device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k >> 2); }    // where dft16 leaves Y[k]
+
+// the 16 complex points (= 32 samples) of frame t that lane l of a 16-lane group packs: z[16 n1 + l], n1 = 0..15.
+// INTERIOR (block-uniform: all 64 frames of the block lie inside the clip and the clip starts 8-byte aligned): plain 8-byte
+// loads, 16 lanes = one 128-byte line; otherwise clamped (frames >= T take the last frame's data and are not stored) and
+// reflect-padded sample by sample
+template <bool INTERIOR>
+__device__ __forceinline__ void mel_fetch(f32x16_t& xe, f32x16_t& xo, const float* __restrict__ wsrc, int t, int T, int S, int l) {
+    if (INTERIOR) {
+        const float* p0 = wsrc + t * MEL_HOP - MEL_NFFT / 2 + 2 * l;
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const float2 v = *reinterpret_cast<const float2*>(p0 + 32 * n1);
+            xe[n1] = v.x; xo[n1] = v.y;
         }
         return;
     }
     const int tc = t < T ? t : T - 1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = 2 * (lane + 64 * j);
+    for (int n1 = 0; n1 < 16; ++n1) {
+        const int p = 2 * (16 * n1 + l);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             int i = tc * MEL_HOP + p + e - MEL_NFFT / 2;
             if (i < 0) i = -i;
             if (i >= S) i = 2 * (S - 1) - i;
-            x[j][e] = wsrc[i];
+            if (e == 0) xe[n1] = wsrc[i];
+            else xo[n1] = wsrc[i];
         }
     }
 }
 
-__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wave_in, int S, int T,
+constexpr int MEL_XROW = 18 * 8;                  // exchange tile: 16 rows (k1) of 16 complex, pitch 18 (b128 reads conflict-free)
+constexpr int MEL_XFRAME = 16 * MEL_XROW;         // 2304 B per frame
+constexpr int MEL_PWFRAME = 260;                  // floats: 257 bins + the zero padding clamped reads may touch
+
+// Round 3 form: a wave transforms FOUR frames at a time, 16 lanes per frame and 16 complex points per lane, as 256 = 16 x 16:
+// a 16-point DFT over n1 in registers (twiddles of the 16-point transform are literals), the W256^(n2 k1) factors (per-lane
+// registers), ONE exchange through LDS (lane n2 writes column n2, lane k1 reads row k1), a 16-point DFT over n2 in registers.
+// The real-FFT unpack needs Z[256 - k], which lives in lane 16 - l of the same group: one lane permutation per value.  The
+// mel projection keeps the former mapping (64 lanes x 1.5 bands per frame, filter weights in registers).  Per frame and
+// wave ~240 instructions against ~800 for four radix-4 stages through LDS with one frame per wave.
+__global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict__ wave_in, int S, int T,
                                                      const float* __restrict__ window,
                                                      const float* __restrict__ twiddle,   // [512][2] exp(-2 pi i k / 512)
                                                      const int32_t* __restrict__ fb_start,
@@ -80,112 +120,134 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
                                                      float norm_mean, float norm_2std, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float* tw = reinterpret_cast<float*>(smem);                      // [1024]
-    float* otile = tw + 1024;                                        // [96][65]
-    cplx* z = reinterpret_cast<cplx*>(otile + MEL_BANDS * MEL_OUT_LD) + wv * 256;   // per wave [256]
-    float* pw = reinterpret_cast<float*>(reinterpret_cast<cplx*>(otile + MEL_BANDS * MEL_OUT_LD) + 4 * 256) + wv * 260;
-
+    const int l = lane & 15, grp = lane >> 4;
+    float* wtab = reinterpret_cast<float*>(smem);                     // [512] Hann window
+    float* tw256 = wtab + 512;                                        // [256][2] exp(-2 pi i m / 256)
+    float* fbw = tw256 + 512;                                         // [96][16] leading filter weights of every band
+    float* otile = fbw + MEL_BANDS * 16;                              // [96][65]
+    char* xch = reinterpret_cast<char*>(otile + MEL_BANDS * MEL_OUT_LD) + wv * 4 * MEL_XFRAME;          // per wave: 4 frames
+    // the power spectra of the four frames reuse the exchange tiles (2304 >= 1040 bytes per frame; a wave-level sync apart)
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * MEL_FRAMES_PER_BLOCK;
     const float* wsrc = wave_in + (int64_t)b * S;
-    // the wave works alone on its 16 frames (its own z / pw regions): no block barrier inside the frame loop; the
-    // samples of frame fi + 1 are in flight while frame fi is transformed
-    float x[4][2], win[4][2];
     const bool interior = t0 > 0 && (t0 + MEL_FRAMES_PER_BLOCK) * MEL_HOP + MEL_NFFT / 2 <= S && t0 + MEL_FRAMES_PER_BLOCK <= T &&
                           (reinterpret_cast<uintptr_t>(wsrc) & 7) == 0;      // block-uniform
-    if (interior) mel_fetch<true>(x, wsrc, t0 + wv * 16, T, S, lane);
-    else mel_fetch<false>(x, wsrc, t0 + wv * 16, T, S, lane);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float2 w2 = *reinterpret_cast<const float2*>(window + 2 * (lane + 64 * j));
-        win[j][0] = w2.x; win[j][1] = w2.y;
-    }
-    // this lane's two bands (lane, lane + 64): the first MEL_WREG0 / MEL_WREG1 filter weights live in registers (the
-    // slaney bank's bands are 1..6 and 5..15 bins long), zero beyond the band; longer bands finish in a global-read loop
+    f32x16_t xe, xo;       // even / odd samples = real / imaginary parts of the packed points (vector values: an array would live in scratch)
+    if (interior) mel_fetch<true>(xe, xo, wsrc, t0 + wv * 16 + grp, T, S, l);
+    else mel_fetch<false>(xe, xo, wsrc, t0 + wv * 16 + grp, T, S, l);
+    const cplx w512l = {twiddle[2 * l], twiddle[2 * l + 1]};          // W512^l
+    // this lane's two bands (lane, lane + 64)
     int mb_start[2], mb_len[2];
-    float mw0[MEL_WREG0], mw1[MEL_WREG1];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = lane + 64 * j;
         mb_start[j] = m < MEL_BANDS ? fb_start[m] : 0;
         mb_len[j] = m < MEL_BANDS ? fb_len[m] : 0;
     }
-#pragma unroll
-    for (int i = 0; i < MEL_WREG0; ++i) mw0[i] = i < mb_len[0] ? fb_w[lane * fb_stride + i] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < MEL_WREG1; ++i) mw1[i] = i < mb_len[1] ? fb_w[(lane + 64) * fb_stride + i] : 0.0f;
-    if (lane < 3) pw[MEL_NBINS + lane] = 0.0f;      // the padding the clamped reads below may touch
-    for (int i = threadIdx.x; i < 1024; i += 256) tw[i] = twiddle[i];
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        wtab[i] = window[i];
+        tw256[i] = twiddle[4 * (i >> 1) + (i & 1)];
+    }
+    for (int i = threadIdx.x; i < MEL_BANDS * 16; i += 256) {
+        const int m = i >> 4, k = i & 15;
+        fbw[i] = k < fb_len[m] && k < fb_stride ? fb_w[m * fb_stride + k] : 0.0f;
+    }
     __syncthreads();
 
-    for (int fi = 0; fi < 16; ++fi) {
-        const int tl = wv * 16 + fi;       // frame within the block
-        // ---- framing (center=True, reflect padding of 256 samples) + window + complex packing
+    for (int quad = 0; quad < 4; ++quad) {
+        const int tl0 = wv * 16 + quad * 4;      // first of this wave's four frames within the block
+        // ---- framing (center=True, reflect padding of 256 samples) + window + complex packing: v[n1] = z[16 n1 + l]
+        cplx v[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) z[lane + 64 * j] = {x[j][0] * win[j][0], x[j][1] * win[j][1]};
-        if (fi + 1 < 16) {
-            if (interior) mel_fetch<true>(x, wsrc, t0 + tl + 1, T, S, lane);
-            else mel_fetch<false>(x, wsrc, t0 + tl + 1, T, S, lane);
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const float2 w2 = *reinterpret_cast<const float2*>(wtab + 2 * (16 * n1 + l));
+            v[n1] = {xe[n1] * w2.x, xo[n1] * w2.y};
+        }
+        if (quad + 1 < 4) {                       // the next four frames' samples fly while these are transformed
+            if (interior) mel_fetch<true>(xe, xo, wsrc, t0 + tl0 + 4 + grp, T, S, l);
+            else mel_fetch<false>(xe, xo, wsrc, t0 + tl0 + 4 + grp, T, S, l);
+        }
+        // ---- 256 = 16 x 16: DFT over n1, twiddle, exchange, DFT over n2
+        dft16(v);
+        char* xf = xch + grp * MEL_XFRAME;
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+            cplx y = v[rev16(k1)];
+            if (k1 > 0) {                         // W256^(l k1)
+                const float2 t2 = *reinterpret_cast<const float2*>(tw256 + 2 * ((l * k1) & 255));
+                y = cmul(y, cplx{t2.x, t2.y});
+            }
+            *reinterpret_cast<float2*>(xf + k1 * MEL_XROW + l * 8) = make_float2(y.re, y.im);
         }
         wave_lds_sync();
-        // ---- 256-point complex FFT, radix-4 DIF, 4 stages, one in-place butterfly per lane per stage
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int L = 256 >> (2 * st);
-            const int q = L >> 2;
-            const int blk = lane / q, pos = lane - blk * q;
-            const int base = blk * L + pos;
-            const cplx a0 = z[base], a1 = z[base + q], a2 = z[base + 2 * q], a3 = z[base + 3 * q];
-            const cplx b0 = cadd(a0, a2), b1 = csub(a0, a2), b2 = cadd(a1, a3), b3 = mul_neg_i(csub(a1, a3));
-            cplx y0 = cadd(b0, b2), y1 = cadd(b1, b3), y2 = csub(b0, b2), y3 = csub(b1, b3);
-            const int tstep = (MEL_NFFT / L) * pos;   // exp(-2 pi i pos m / L) = tw[(512 / L) * pos * m]
-            const cplx w1 = {tw[2 * tstep], tw[2 * tstep + 1]};
-            const cplx w2 = {tw[4 * tstep], tw[4 * tstep + 1]};
-            const cplx w3 = {tw[6 * tstep], tw[6 * tstep + 1]};
-            y1 = cmul(y1, w1);
-            y2 = cmul(y2, w2);
-            y3 = cmul(y3, w3);
-            z[base] = y0; z[base + q] = y1; z[base + 2 * q] = y2; z[base + 3 * q] = y3;   // the points this lane read
-            wave_lds_sync();
+        for (int j = 0; j < 8; ++j) {
+            const float4 q = *reinterpret_cast<const float4*>(xf + l * MEL_XROW + j * 16);
+            v[2 * j] = {q.x, q.y};
+            v[2 * j + 1] = {q.z, q.w};
         }
-        // ---- unpack the real FFT: X[k] = E[k] + W^k O[k], power spectrum for k = 0..256
+        dft16(v);                                 // Z[l + 16 k2] at v[rev16(k2)]
+        // ---- unpack the real FFT: X[k] = E[k] + W512^k O[k], power spectrum for k = l + 16 k2 (and bin 256 from lane 0)
+        wave_lds_sync();                          // every lane has read its row: the tiles become the power spectra
+        float* pw = reinterpret_cast<float*>(xf);
+        if (l < 3) pw[MEL_NBINS + l] = 0.0f;      // the padding the clamped reads below may touch
+        const int src = (lane & 48) | ((16 - l) & 15);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int k = lane + 64 * j;
-            if (k <= 256) {
-                const cplx zk = z[rev4_256(k & 255)];
-                cplx zc = z[rev4_256((256 - k) & 255)];
-                zc.im = -zc.im;
-                const cplx e = {0.5f * (zk.re + zc.re), 0.5f * (zk.im + zc.im)};
-                const cplx d = {0.5f * (zk.re - zc.re), 0.5f * (zk.im - zc.im)};
-                const cplx o = mul_neg_i(d);                                 // (Z[k] - conj Z[N-k]) / (2i)
-                const cplx w = {tw[2 * k], tw[2 * k + 1]};                    // exp(-2 pi i k / 512)
-                const cplx xk = cadd(e, cmul(o, w));
-                pw[k] = xk.re * xk.re + xk.im * xk.im;
+        for (int k2 = 0; k2 < 16; ++k2) {
+            constexpr float W32C[16] = {1.0000000000f, 0.9807852804f, 0.9238795325f, 0.8314696123f, 0.7071067812f, 0.5555702330f, 0.3826834324f, 0.1950903220f, 0.0000000000f, -0.1950903220f, -0.3826834324f, -0.5555702330f, -0.7071067812f, -0.8314696123f, -0.9238795325f, -0.9807852804f};
+            constexpr float W32S[16] = {-0.0000000000f, -0.1950903220f, -0.3826834324f, -0.5555702330f, -0.7071067812f, -0.8314696123f, -0.9238795325f, -0.9807852804f, -1.0000000000f, -0.9807852804f, -0.9238795325f, -0.8314696123f, -0.7071067812f, -0.5555702330f, -0.3826834324f, -0.1950903220f};      // exp(-2 pi i k2 / 32)
+            const cplx zk = v[rev16(k2)];
+            // Z[256 - k] sits in lane 16 - l, slot 15 - k2 (lane 0 pairs with itself: slot (16 - k2) mod 16)
+            const cplx za = v[rev16((16 - k2) & 15)], zb = v[rev16(15 - k2)];      // (selected per component: a select between
+            const cplx snd = {l == 0 ? za.re : zb.re, l == 0 ? za.im : zb.im};      //  two array elements would pin v[] to scratch)
+            cplx zc = {__shfl(snd.re, src, 64), __shfl(snd.im, src, 64)};
+            zc.im = -zc.im;
+            const cplx e = {0.5f * (zk.re + zc.re), 0.5f * (zk.im + zc.im)};
+            const cplx d = {0.5f * (zk.re - zc.re), 0.5f * (zk.im - zc.im)};
+            const cplx o = mul_neg_i(d);                                 // (Z[k] - conj Z[N-k]) / (2i)
+            const cplx w32 = {W32C[k2], W32S[k2]};
+            const cplx w = cmul(w512l, w32);                              // exp(-2 pi i (l + 16 k2) / 512)
+            const cplx xk = cadd(e, cmul(o, w));
+            pw[l + 16 * k2] = __builtin_fmaf(xk.re, xk.re, xk.im * xk.im);
+            if (k2 == 0 && l == 0) {
+                const float x256 = zk.re - zk.im;                         // X[256] = Re Z[0] - Im Z[0]
+                pw[256] = x256 * x256;
             }
         }
         wave_lds_sync();
-        // ---- mel projection + logC + z-norm into the block's output tile
+        // ---- mel projection + logC + z-norm into the block's output tile, one frame at a time over all 64 lanes; the
+        // first MEL_WREG0 / MEL_WREG1 filter weights of this lane's two bands in registers for the four frames (the slaney
+        // bank's bands are 1..6 and 5..15 bins long), zero beyond the band; longer bands finish in a global-read loop
+        float mw0[MEL_WREG0], mw1[MEL_WREG1];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = lane + 64 * j;
-            if (m < MEL_BANDS) {
-                const int s0 = mb_start[j], n = mb_len[j];
-                float acc = 0.0f;
-                if (j == 0) {
+        for (int i = 0; i < MEL_WREG0; ++i) mw0[i] = fbw[lane * 16 + i];
 #pragma unroll
-                    for (int i = 0; i < MEL_WREG0; ++i) acc += pw[s0 + i < MEL_NBINS ? s0 + i : MEL_NBINS] * mw0[i];
-                    for (int i = MEL_WREG0; i < n; ++i) acc += pw[s0 + i] * fb_w[m * fb_stride + i];
-                } else {
+        for (int i = 0; i < MEL_WREG1; ++i) mw1[i] = lane + 64 < MEL_BANDS ? fbw[(lane + 64) * 16 + i] : 0.0f;
+#pragma unroll 1
+        for (int f = 0; f < 4; ++f) {
+            const float* pwf = reinterpret_cast<const float*>(xch + f * MEL_XFRAME);
+            const int tl = tl0 + f;
 #pragma unroll
-                    for (int i = 0; i < MEL_WREG1; ++i) acc += pw[s0 + i < MEL_NBINS ? s0 + i : MEL_NBINS] * mw1[i];
-                    for (int i = MEL_WREG1; i < n; ++i) acc += pw[s0 + i] * fb_w[m * fb_stride + i];
+            for (int j = 0; j < 2; ++j) {
+                const int m = lane + 64 * j;
+                if (m < MEL_BANDS) {
+                    const int s0 = mb_start[j], n = mb_len[j];
+                    float acc = 0.0f;
+                    if (j == 0) {
+#pragma unroll
+                        for (int i = 0; i < MEL_WREG0; ++i) acc = __builtin_fmaf(pwf[s0 + i < MEL_NBINS ? s0 + i : MEL_NBINS], mw0[i], acc);
+                        for (int i = MEL_WREG0; i < n; ++i) acc += pwf[s0 + i] * fb_w[m * fb_stride + i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < MEL_WREG1; ++i) acc = __builtin_fmaf(pwf[s0 + i < MEL_NBINS ? s0 + i : MEL_NBINS], mw1[i], acc);
+                        for (int i = MEL_WREG1; i < n; ++i) acc += pwf[s0 + i] * fb_w[m * fb_stride + i];
+                    }
+                    const float lm = log10f(1.0f + acc * log_scale);
+                    otile[m * MEL_OUT_LD + tl] = (lm - norm_mean) / norm_2std;
                 }
-                const float lm = log10f(1.0f + acc * log_scale);
-                otile[m * MEL_OUT_LD + tl] = (lm - norm_mean) / norm_2std;
             }
         }
-        wave_lds_sync();       // pw / z are rewritten by the next frame
+        wave_lds_sync();       // pw / the exchange tile are rewritten by the next four frames
     }
     __syncthreads();
     // ---- coalesced store of the [96][64] tile
@@ -206,7 +268,7 @@ extern "C" int maest_logmel(const float* wave, int B, int S, const float* window
     MAEST_REQUIRE(B > 0 && S > MEL_NFFT / 2, "maest_logmel: bad shape B=%d S=%d (reflect padding needs S > 256)", B, S);
     MAEST_REQUIRE(fb_stride > 0, "maest_logmel: bad fb_stride");
     const int T = 1 + S / MEL_HOP;
-    const int smem_bytes = (1024 + MEL_BANDS * MEL_OUT_LD) * 4 + 4 * 256 * 8 + 4 * 260 * 4;
+    const int smem_bytes = (512 + 512 + MEL_BANDS * 16 + MEL_BANDS * MEL_OUT_LD) * 4 + 4 * 4 * MEL_XFRAME;
     dim3 grid((T + MEL_FRAMES_PER_BLOCK - 1) / MEL_FRAMES_PER_BLOCK, B);
     hipLaunchKernelGGL(logmel_kernel, grid, dim3(256), smem_bytes, (hipStream_t)stream, wave, S, T, window, twiddle,
                        fb_start, fb_len, fb_w, fb_stride, log_scale, norm_mean, norm_2std, out);
