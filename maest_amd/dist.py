@@ -40,10 +40,13 @@ def backward_order(names: List[str]) -> List[str]:
 
 class GradReducer:
     def __init__(self, named_params, bucket_mb: float = 96.0, process_group=None, skip=(),
-                 force_collective: bool = False):
+                 force_collective: bool = False, tail_mb: float = 32.0):
         """force_collective: issue the bucket all-reduces even at world size 1 (needs an initialised process group).
         A one-rank all-reduce changes nothing numerically, but it drives the whole exchange path -- communicator, the
-        asynchronous launch from the side stream, the wait in finish() -- through RCCL on a single-GPU box."""
+        asynchronous launch from the side stream, the wait in finish() -- through RCCL on a single-GPU box.
+        tail_mb: cap of the LAST bucket (the one backward completes last: block 0 and the embeddings).  Its all-reduce
+        cannot overlap with anything -- backward is over when it starts -- so it is kept small (one block, 29 MB, instead of
+        three); the buckets before it stay large (few, long ring transfers: xGMI is per-link bound)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.collective = self.world > 1 or (bool(force_collective) and dist.is_initialized())
@@ -57,11 +60,17 @@ class GradReducer:
         self.bucket_of: Dict[str, int] = {}
         self.buckets: List[dict] = []
         cap = int(bucket_mb * 1024 * 1024 / 4)
+        # the tail bucket: gradients taken from the END of the backward order while they fit under tail_mb
+        tail_cap = int(min(tail_mb, bucket_mb) * 1024 * 1024 / 4)
+        tail_first, acc = len(self.order), 0
+        while tail_first > 1 and acc + params[self.order[tail_first - 1]].numel() <= tail_cap:
+            tail_first -= 1
+            acc += params[self.order[tail_first]].numel()
         off = 0
         cur = {"start": 0, "end": 0, "names": []}
-        for n in self.order:
+        for i, n in enumerate(self.order):
             k = params[n].numel()
-            if cur["names"] and (off + k - cur["start"]) > cap:
+            if cur["names"] and ((off + k - cur["start"]) > cap or (i == tail_first and tail_first < len(self.order))):
                 cur["end"] = off
                 self.buckets.append(cur)
                 cur = {"start": off, "end": off, "names": []}
