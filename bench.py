@@ -46,7 +46,7 @@ def flops_per_clip_fwd_not_executed(N, attn_rows):
     return 2 * (N - 2) * 768 * (768 + 3072 + 3072) + 4 * (N - attn_rows) * N * 768
 
 
-PMC_TRAFFIC_FILE = "profiles/r03a_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r03b_pmc_traffic.json"
 
 
 def pmc_traffic():
