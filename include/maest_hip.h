@@ -75,6 +75,8 @@ const char* maest_last_error(void);
 #define MAEST_OPT_GEMM_TAIL 5 /* env MAEST_GEMM_TAIL, default 1: the last partial round of a large NT GEMM runs in 128-row
                                  tiles (a second launch) when at most half a round of 256-row tiles is left over; 0: off;
                                  2: every tile a 128-row tile (tests) */
+#define MAEST_OPT_ATTN_FWD 6 /* env MAEST_ATTN_FWD, default 0: bf16 attention forward with K / V tiles fed by LDS-DMA into unpadded
+                                bank-swizzled tiles; 1: the register-staged, padded-pitch form every other dtype uses */
 #define MAEST_OPT_LN_BWD_BLOCKS 4 /* env MAEST_LN_BWD_BLOCKS, default 1024: workgroup cap of the LayerNorm backward grid */
 int maest_set_option(int opt, int value, int restore_default);
 int maest_get_option(int opt, int* value);

@@ -899,6 +899,113 @@ __device__ __forceinline__ void mma_transposed_swz(f32x16_t (&acc)[2], const cha
     }
 }
 
+// =================================================================================== forward, DMA-fed tiles (bf16)
+// attn_fwd_kernel with its K / V tiles on the staging path of the fused backward: UNPADDED 128-byte-row tiles filled by LDS-DMA
+// (two instructions of K and two of V per wave and tile, issued right behind the barrier that frees the buffer, for the tile
+// after the one being consumed), bank-swizzled on the DMA source address so that the 16-byte row reads AND the transpose reads
+// are conflict-free -- no staging registers, no ds_write pass, 32 KiB instead of 36.  The removal ablation of the
+// register-staged form (profiles/r03_attn_fwd_ablation.txt) prices its K / V refills at a quarter of the kernel and its
+// LDS bank-conflict cycles at 23 % (padded pitch: the transpose reads cost twice their ideal cycles).  Rows beyond N repeat row
+// N - 1 (the DMA clamps): their scores are masked on the last tile as before, so P = 0 meets a finite V row.
+__global__ __launch_bounds__(256, 4) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                              float* __restrict__ lse, int B, int N, float scale, int q_rows) {
+    using T = bf16_t;
+    using C = AttnCfg<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[64 keys][128 B], V[64 keys][128 B] }
+    constexpr int TILE128 = 64 * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const AttnBlock blk = attn_block((N + 127) / 128, B);
+    const int head = blk.head, b = blk.b;
+    if (blk.rb * 128 >= q_rows) return;   // block-uniform: only the first q_rows queries are wanted (the head's tokens)
+    const int q0 = blk.rb * 128 + wave * 32;
+    const int q = q0 + (lane & 31);
+    const bool wave_active = q0 < N && q0 < q_rows;   // wave-uniform
+    const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
+    const T* kbase = qbase + NHEADS * HD;
+    const T* vbase = qbase + 2 * NHEADS * HD;
+
+    const int ntiles = (N + 63) / 64;
+    auto tile_dma = [&](int kt) {         // this wave's 16 rows of K and of V of key tile kt -> ring buffer kt & 1
+        char* kb = smem + (kt & 1) * 2 * TILE128;
+        dma_rows128(kb, kbase, QKV_LD, kt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
+        dma_rows128(kb + TILE128, vbase, QKV_LD, kt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
+    };
+    tile_dma(0);
+    chunk16 qf[C::STEPS];
+    row_frags_load<T>(qf, qbase, QKV_LD, q, N, h);
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
+    float m_run = NEG_BIG, l_run = 0.0f;
+    const float c2 = scale * LOG2E;
+    MAEST_ATTN_WAIT_VM0();
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const char* k_lds = smem + (kt & 1) * 2 * TILE128;
+        const char* v_lds = k_lds + TILE128;
+        if (kt + 1 < ntiles) tile_dma(kt + 1);   // its buffer was read a tile ago: everybody has passed the barrier since
+        if (wave_active) {
+            f32x16_t s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+                mma_rows_swz(s[kb], k_lds, kb * 32, lane, qf);           // S^T[key][q]
+            }
+            if (kt == ntiles - 1 && (N & 63) != 0) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt * 64 + kb * 32 + frag_row(r, lane) >= N) s[kb][r] = NEG_BIG;
+            }
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx * c2);
+            const float alpha = fast_exp2<T>(m_run - m_new);
+            m_run = m_new;
+            const f32x2_t c2v = {c2, c2}, nm = {-m_new, -m_new};
+            f32x2_t ps = {0.0f, 0.0f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2_t sv = {s[kb][r], s[kb][r + 1]};
+                    const f32x2_t e = __builtin_elementwise_fma(sv, c2v, nm);
+                    const f32x2_t pv = {fast_exp2<T>(e[0]), fast_exp2<T>(e[1])};
+                    s[kb][r] = pv[0];
+                    s[kb][r + 1] = pv[1];
+                    ps += pv;
+                }
+            l_run = l_run * alpha + (ps[0] + ps[1]);  // per half-wave partial; halves are merged at the end
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) mma_transposed_swz(o, v_lds, kb * 32, lane, s[kb]);   // O^T[d][q] += V^T[d][key] P^T[key][q]
+        }
+        // this wave's share of the next tile has landed; behind the barrier everybody's has, and nobody reads this tile any more
+        __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q < N && wave_active) {
+        store_dT<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv);
+        if (lse != nullptr && h == 0) lse[((int64_t)b * NHEADS + head) * N + q] = m_run * LN2 + logf(l_tot);
+    }
+}
+
 // MAEST_ATTN_PROF: timing instrumentation only (scratch/attn_prof.py builds a second library with it; never defined in
 // the product build): shader-clock stamps of every wave of the workgroups with blockIdx % 256 == 5, per query tile.
 #ifdef MAEST_ATTN_PROF
@@ -1505,10 +1612,17 @@ static int attn_bwd_fused_smem(int N) {
 template <typename T, bool X3 = false>
 static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, int q_rows, hipStream_t st) {
     using C = AttnCfg<T>;
+    dim3 grid(((N + 127) / 128) * NHEADS * B);
+    if constexpr (sizeof(T) == 2 && !X3) {
+        if (option(MAEST_OPT_ATTN_FWD) == 0) {      // K / V tiles by LDS-DMA (unpadded, swizzled)
+            hipLaunchKernelGGL(attn_fwd_dma_kernel, grid, dim3(256), 4 * 64 * 128, st, (const bf16_t*)qkv, (bf16_t*)out, lse, B, N,
+                               scale, q_rows);
+            return check_launch("maest_attn_fwd(dma)");
+        }
+    }
     const int smem_bytes = 4 * C::TILE;
     static DeviceOnce once;
     ensure_dynamic_lds(once, &attn_fwd_kernel<T, X3>, smem_bytes);
-    dim3 grid(((N + 127) / 128) * NHEADS * B);
     hipLaunchKernelGGL((attn_fwd_kernel<T, X3>), grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, B, N, scale,
                        q_rows);
     return check_launch("maest_attn_fwd");

@@ -212,6 +212,13 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2):
     rt, at = (2e-5, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2)
     close(out, ref, rt, at, "attention fwd")
     close(lse, ref_lse, 1e-4, 1e-4 if dtype == torch.float32 else 2e-2, "attention lse")
+    if dtype == torch.bfloat16:
+        # the call above took the DMA-fed tiles (bf16 default); the register-staged form every other dtype uses against the
+        # oracle too, and the two bit for bit (the same products in the same order; only the tile staging differs)
+        with ops.options(attn_fwd=1):
+            out1, lse1 = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
+        close(out1, ref, rt, at, "attention fwd (register-staged tiles)")
+        assert torch.equal(out1, out) and torch.equal(lse1, lse), "DMA-fed and register-staged attention forward differ"
     # backward (the oracle's autograd on the same rounded operands)
     dout = rnd((B * N, 768), seed + 1).to(dtype)
     ref.backward(dout.float())
