@@ -907,7 +907,10 @@ __device__ __forceinline__ void mma_transposed_swz(f32x16_t (&acc)[2], const cha
 // register-staged form (profiles/r03_attn_fwd_ablation.txt) prices its K / V refills at a quarter of the kernel and its
 // LDS bank-conflict cycles at 23 % (padded pitch: the transpose reads cost twice their ideal cycles).  Rows beyond N repeat row
 // N - 1 (the DMA clamps): their scores are masked on the last tile as before, so P = 0 meets a finite V row.
-__global__ __launch_bounds__(256, 4) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+#ifndef MAEST_FWD_RING
+#define MAEST_FWD_RING 2      // ring depth of the K / V tiles: 2 = one tile ahead (32 KiB, 4 workgroups per CU); 3 = two ahead (48 KiB, 3 per CU)
+#endif
+__global__ __launch_bounds__(256, MAEST_FWD_RING == 3 ? 3 : 4) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                               float* __restrict__ lse, int B, int N, float scale, int q_rows) {
     using T = bf16_t;
     using C = AttnCfg<T>;
@@ -927,12 +930,14 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_dma_kernel(const bf16_t* __re
     const T* vbase = qbase + 2 * NHEADS * HD;
 
     const int ntiles = (N + 63) / 64;
-    auto tile_dma = [&](int kt) {         // this wave's 16 rows of K and of V of key tile kt -> ring buffer kt & 1
-        char* kb = smem + (kt & 1) * 2 * TILE128;
+    constexpr int RING = MAEST_FWD_RING;      // 2: one tile ahead (32 KiB, 4 workgroups per CU); 3: two ahead (48 KiB, 3 per CU)
+    auto tile_dma = [&](int kt) {         // this wave's 16 rows of K and of V of key tile kt -> ring buffer kt % RING
+        char* kb = smem + (kt % RING) * 2 * TILE128;
         dma_rows128(kb, kbase, QKV_LD, kt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
         dma_rows128(kb + TILE128, vbase, QKV_LD, kt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
     };
     tile_dma(0);
+    if (RING == 3 && ntiles > 1) tile_dma(1);
     chunk16 qf[C::STEPS];
     row_frags_load<T>(qf, qbase, QKV_LD, q, N, h);
 
@@ -943,12 +948,14 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_dma_kernel(const bf16_t* __re
         for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
     float m_run = NEG_BIG, l_run = 0.0f;
     const float c2 = scale * LOG2E;
-    MAEST_ATTN_WAIT_VM0();
+    if (RING == 3 && ntiles > 1) __builtin_amdgcn_s_waitcnt(0x0F74);      // vmcnt(4): tile 0 and the Q fragments landed, tile 1 may fly
+    else MAEST_ATTN_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < ntiles; ++kt) {
-        const char* k_lds = smem + (kt & 1) * 2 * TILE128;
+        const char* k_lds = smem + (kt % RING) * 2 * TILE128;
         const char* v_lds = k_lds + TILE128;
-        if (kt + 1 < ntiles) tile_dma(kt + 1);   // its buffer was read a tile ago: everybody has passed the barrier since
+        const bool issued = kt + RING - 1 < ntiles;
+        if (issued) tile_dma(kt + RING - 1);     // its buffer was read a tile ago: everybody has passed the barrier since
         if (wave_active) {
             f32x16_t s[2];
 #pragma unroll
@@ -995,7 +1002,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_dma_kernel(const bf16_t* __re
             for (int kb = 0; kb < 2; ++kb) mma_transposed_swz(o, v_lds, kb * 32, lane, s[kb]);   // O^T[d][q] += V^T[d][key] P^T[key][q]
         }
         // this wave's share of the next tile has landed; behind the barrier everybody's has, and nobody reads this tile any more
-        __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0)
+        if (RING == 3 && issued) __builtin_amdgcn_s_waitcnt(0x0074);      // vmcnt(4) lgkmcnt(0): only the newest tile may fly
+        else __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -1615,7 +1623,7 @@ static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N,
     dim3 grid(((N + 127) / 128) * NHEADS * B);
     if constexpr (sizeof(T) == 2 && !X3) {
         if (option(MAEST_OPT_ATTN_FWD) == 0) {      // K / V tiles by LDS-DMA (unpadded, swizzled)
-            hipLaunchKernelGGL(attn_fwd_dma_kernel, grid, dim3(256), 4 * 64 * 128, st, (const bf16_t*)qkv, (bf16_t*)out, lse, B, N,
+            hipLaunchKernelGGL(attn_fwd_dma_kernel, grid, dim3(256), MAEST_FWD_RING * 2 * 64 * 128, st, (const bf16_t*)qkv, (bf16_t*)out, lse, B, N,
                                scale, q_rows);
             return check_launch("maest_attn_fwd(dma)");
         }
