@@ -910,7 +910,10 @@ __device__ __forceinline__ void mma_transposed_swz(f32x16_t (&acc)[2], const cha
 #ifndef MAEST_FWD_RING
 #define MAEST_FWD_RING 2      // ring depth of the K / V tiles: 2 = one tile ahead (32 KiB, 4 workgroups per CU); 3 = two ahead (48 KiB, 3 per CU)
 #endif
-__global__ __launch_bounds__(256, MAEST_FWD_RING == 3 ? 3 : 4) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+#ifndef MAEST_FWD_WGS
+#define MAEST_FWD_WGS (MAEST_FWD_RING == 3 ? 3 : 4)      // workgroups per CU the register allocation is bounded for
+#endif
+__global__ __launch_bounds__(256, MAEST_FWD_WGS) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                               float* __restrict__ lse, int B, int N, float scale, int q_rows) {
     using T = bf16_t;
     using C = AttnCfg<T>;
