@@ -65,6 +65,50 @@ def pmc_traffic():
     return None, "no committed PMC summary found"
 
 
+def measure_pmc_traffic(timeout_s=150):
+    """HBM bytes per GEMM call of the dominant kernel, MEASURED by this run: two rocprofv3 passes (--kernel-trace --pmc
+    FETCH_SIZE, then WRITE_SIZE: counters in their own passes, no other trace domain) over a short child run of this same
+    file (2 steps + 1 warm-up, kernels serialized, no side cases), on this GPU.  Per call = sum over every gemm_nt256w
+    launch (256-row tiles and the 128-row-tile launch behind some of them) / number of 256-row-tile launches;
+    traffic = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section: FETCH_SIZE counts half of the wide coalesced
+    reads on gfx950; profiles/r03b_pmc_traffic.json holds the same passes with their calibration on known byte counts:
+    x2.00 / x1.00).  Returns (bytes, source, parts) or (None, reason, None): any failure falls back to the committed figure."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH", None
+    parts = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(prefix="maest_pmc_", dir="/tmp") as d:
+                cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                       sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                       "--no-kernel-timing", "--serial-kernels", "--no-side-cases"]
+                env = dict(os.environ, TMPDIR="/tmp", MAEST_BENCH_PMC="0")
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+                if r.returncode != 0:
+                    return None, f"rocprofv3 --pmc {counter} pass exited with {r.returncode}", None
+                total, calls = 0.0, 0
+                for f in glob.glob(os.path.join(d, "**", "p_counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if "gemm_nt256w_kernel" not in row["Kernel_Name"] or row["Counter_Name"] != counter:
+                            continue
+                        total += float(row["Counter_Value"])
+                        name = row["Kernel_Name"].split("(")[0].replace(" ", "")
+                        if name.endswith(",4>"):          # the 256-row-tile instantiation: one launch per GEMM call
+                            calls += 1
+                if calls == 0:
+                    return None, f"no gemm_nt256w launches in the --pmc {counter} pass", None
+                parts[counter] = (total * 1024.0 / calls, calls)
+    except Exception as e:      # timeout, parse error, ...
+        return None, f"live PMC pass failed: {type(e).__name__}: {e}", None
+    fetch, write = parts["FETCH_SIZE"][0], parts["WRITE_SIZE"][0]
+    src = ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) over a child "
+           "`bench.py --steps 2 --warmup 1 --serial-kernels` of the same binary on this GPU; 2 x FETCH_SIZE + WRITE_SIZE per "
+           f"GEMM call ({parts['FETCH_SIZE'][1]} calls profiled)")
+    return 2.0 * fetch + write, src, {"fetch_size_raw_per_call": round(fetch), "write_size_per_call": round(write)}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU
     (what Lightning does for the reference, ex_maest.py:49,57).  Rank 0 of the child job prints the JSON line."""
@@ -289,7 +333,7 @@ def flop_counts(case, precision):
     return step_flops, skipped, attn_rows, tail_on
 
 
-def kernel_report(case, timer, steps, precision, with_traffic):
+def kernel_report(case, timer, steps, precision, with_traffic, live_traffic=None):
     """roofline / kernel_ms_per_step / attention_set objects from one kernel_pass."""
     out = {}
     B, N, train = case["B"], case["N"], case["train"]
@@ -306,8 +350,13 @@ def kernel_report(case, timer, steps, precision, with_traffic):
                                                        if precision == "bf16x3" else "maest_gemm_nt (fp32 MFMA)")),
                            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
         if with_traffic:
-            traffic, traffic_source = pmc_traffic()
-            out["roofline"].update(traffic=traffic, traffic_source=traffic_source)
+            if live_traffic is not None and live_traffic[0] is not None:
+                out["roofline"].update(traffic=live_traffic[0], traffic_source=live_traffic[1], traffic_parts=live_traffic[2])
+            else:
+                traffic, traffic_source = pmc_traffic()
+                if live_traffic is not None:
+                    traffic_source += f" (live measurement unavailable: {live_traffic[1]})"
+                out["roofline"].update(traffic=traffic, traffic_source=traffic_source)
         out["roofline"].update(launches_per_step=g["launches"] // steps, avg_launch_ms=round(g["ms"] / g["launches"], 4),
                                ms_per_step=round(g["ms"] / steps, 3),
                                note="second pass over the same K steps, kernels serialized (side-stream overlap off) "
@@ -465,7 +514,13 @@ def main():
                                        "(cls, dist) only, forward and backward; logits, features and all gradients equal "
                                        "the complete evaluation's" if tail_on else "complete")
         if timer is not None:
-            out.update(kernel_report(case, timer, args.steps, args.precision, with_traffic=True))
+            # HBM traffic of the dominant kernel from live PMC passes: on the headline configuration of a complete default
+            # line only (N = 1, configs[2], bf16; MAEST_BENCH_PMC=0 or --no-cpu-baseline skip it: +50 s)
+            live = None
+            if (world == 1 and args.mode == "train" and T <= 640 and args.precision == "bf16" and not args.no_cpu_baseline
+                    and B == 256 and os.environ.get("MAEST_BENCH_PMC", "1") != "0"):
+                live = measure_pmc_traffic()
+            out.update(kernel_report(case, timer, args.steps, args.precision, with_traffic=True, live_traffic=live))
         if world == 1 and not args.no_kernel_timing:
             # the HBM-bound front end of the path: the log-mel kernel on a full batch of waveforms
             try:
