@@ -50,10 +50,10 @@ PMC_TRAFFIC_FILE = "profiles/r03b_pmc_traffic.json"
 
 
 def pmc_traffic():
-    """(HBM bytes per launch of the dominant kernel, where that number comes from).  FETCH_SIZE / WRITE_SIZE cannot
-    be collected by bench.py on itself: the figure is read from the committed summary of separate rocprofv3 --pmc
-    passes over THIS command (scratch/profile_round.sh), i.e. a constant from an earlier run of the same binary,
-    and is labelled as such in the JSON line (`traffic_source`).  (None, reason) when the file is absent."""
+    """FALLBACK of measure_pmc_traffic(): (HBM bytes per launch of the dominant kernel, where that number comes from) read
+    from the committed summary of separate rocprofv3 --pmc passes over THIS command (scratch/profile_round.sh), i.e. a
+    constant from an earlier run of the same binary, labelled as such in the JSON line (`traffic_source`).  (None, reason)
+    when the file is absent."""
     for name in (PMC_TRAFFIC_FILE, "profiles/r02c_pmc_traffic.json"):
         try:
             with open(os.path.join(REPO, name)) as f:
