@@ -1510,6 +1510,10 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused3_kernel(const bf1
         }
     } else {
         // =============================================================================== aux waves
+#ifndef MAEST_F3_AUX_PRIO
+#define MAEST_F3_AUX_PRIO 0
+#endif
+        if (MAEST_F3_AUX_PRIO > 0) __builtin_amdgcn_s_setprio(MAEST_F3_AUX_PRIO);   // (the youngest waves of the workgroup lose every arbitration)
         const float* sbase = aux == 0 ? lse : delta;       // per-row statistic this wave carries: lse (scaled) / delta
         auto stat_load = [&](int it, int t) -> float {     // (unconditional, clamped)
             int row = t * 32 + (lane & 31);
