@@ -151,8 +151,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ src, 
     unsafeAtomicAdd(out + c, s);
 }
 
-// ---- BCE with logits (mean), optional label mixup; loss accumulated with one atomic per block
-__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ z, const float* __restrict__ y,
+// ---- BCE with logits (mean), optional label mixup.
+// ONE workgroup of 1024 threads: the loss is a sum in a fixed order (per-thread strided partials, wave butterflies, 16 wave
+// partials added by thread 0), so that the same logits give the same loss bit for bit.  (Rounds 1-3 used up to 256 workgroups with
+// one atomic each: the order of those adds, and with it the last bit of the loss, changed from run to run -- seen once as a
+// 6e-8 difference between two evaluations of the same batch in tests/test_model_gpu.py.)  100 elements per thread at B = 256: ~10 us.
+__global__ __launch_bounds__(1024) void bce_logits_kernel(const float* __restrict__ z, const float* __restrict__ y,
                                                          const int32_t* __restrict__ perm,
                                                          const float* __restrict__ lam, int rows, int cols,
                                                          float weight, float* __restrict__ loss,
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
     const int64_t total = (int64_t)rows * cols;
     const float inv = 1.0f / (float)total;
     float acc = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 1024) {
         const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
         float t = y[i];
         if (lam != nullptr) {
@@ -180,7 +184,11 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(loss, weight * (red[0] + red[1] + red[2] + red[3]) * inv);
+    if (threadIdx.x == 0) {
+        float tot = 0.0f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+        unsafeAtomicAdd(loss, weight * tot * inv);          // (the caller's scalar accumulates the terms of a composite loss)
+    }
 }
 
 __global__ __launch_bounds__(256) void sigmoid_mean_kernel(const float* __restrict__ z, int rows, int cols,
@@ -328,10 +336,7 @@ extern "C" int maest_bce_logits(const float* z, const float* y, const int32_t* p
     MAEST_REQUIRE(z && y && loss, "maest_bce_logits: null pointer");
     MAEST_REQUIRE(rows > 0 && cols > 0, "maest_bce_logits: bad shape");
     MAEST_REQUIRE((perm == nullptr) == (lam == nullptr), "maest_bce_logits: perm and lam go together");
-    const int64_t total = (int64_t)rows * cols;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(bce_logits_kernel, dim3(blocks), dim3(256), 64, (hipStream_t)stream, z, y, perm, lam, rows,
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(1024), 64, (hipStream_t)stream, z, y, perm, lam, rows,
                        cols, weight, loss, dlogits);
     return check_launch("maest_bce_logits");
 }
