@@ -151,43 +151,67 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ src, 
     unsafeAtomicAdd(out + c, s);
 }
 
-// ---- BCE with logits (mean), optional label mixup.
-// ONE workgroup of 1024 threads: the loss is a sum in a fixed order (per-thread strided partials, wave butterflies, 16 wave
-// partials added by thread 0), so that the same logits give the same loss bit for bit.  (Rounds 1-3 used up to 256 workgroups with
-// one atomic each: the order of those adds, and with it the last bit of the loss, changed from run to run -- seen once as a
-// 6e-8 difference between two evaluations of the same batch in tests/test_model_gpu.py.)  100 elements per thread at B = 256: ~10 us.
-__global__ __launch_bounds__(1024) void bce_logits_kernel(const float* __restrict__ z, const float* __restrict__ y,
-                                                         const int32_t* __restrict__ perm,
-                                                         const float* __restrict__ lam, int rows, int cols,
-                                                         float weight, float* __restrict__ loss,
-                                                         float* __restrict__ dlogits) {
+// ---- BCE with logits (mean), optional label mixup.  The loss is a sum in a FIXED order, so that the same logits give the same
+// loss bit for bit: per-workgroup partials (per-thread strided sums, wave butterflies, four wave partials added by thread 0), then
+// one wave adds the partials in index order.  (Rounds 1-3 added the workgroup partials with one atomic each: their order, and with it
+// the last bit of the loss, changed from run to run -- seen as a 6e-8 difference between two evaluations of the same batch in
+// tests/test_model_gpu.py, once in ~10 runs.)  Training (dlogits given): the partials are parked in the head of the dlogits buffer,
+// which the gradient kernel overwrites afterwards -- no workspace, three small launches.  Loss only: one workgroup does it all.
+__device__ __forceinline__ float bce_term(const float* __restrict__ z, const float* __restrict__ y, const int32_t* __restrict__ perm,
+                                          const float* __restrict__ lam, int cols, int64_t i, float& t_out) {
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    float t = y[i];
+    if (lam != nullptr) {
+        const float l = lam[r];
+        t = t * l + y[(int64_t)perm[r] * cols + c] * (1.0f - l);
+    }
+    t_out = t;
+    const float v = z[i];
+    // max(z,0) - z*y + log1p(exp(-|z|))   (ATen's numerically stable form)
+    return fmaxf(v, 0.0f) - v * t + log1pf(expf(-fabsf(v)));
+}
+// partial[blockIdx] = sum of this workgroup's terms (grid-strided); with gridDim == 1 and `loss` given, the whole loss
+__global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restrict__ z, const float* __restrict__ y,
+                                                          const int32_t* __restrict__ perm, const float* __restrict__ lam,
+                                                          int rows, int cols, float weight, float* __restrict__ partial,
+                                                          float* __restrict__ loss) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);
     const int64_t total = (int64_t)rows * cols;
-    const float inv = 1.0f / (float)total;
+    float acc = 0.0f, t;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        acc += bce_term(z, y, perm, lam, cols, i, t);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = ((red[0] + red[1]) + red[2]) + red[3];
+        if (loss != nullptr) unsafeAtomicAdd(loss, weight * tot / (float)total);     // (gridDim == 1: nothing else adds concurrently)
+        else partial[blockIdx.x] = tot;
+    }
+}
+// one wave: loss += weight * (partial[0] + partial[1] + ... in a fixed order) / total   (the caller's scalar accumulates the
+// terms of a composite loss: launches of one stream are ordered)
+__global__ __launch_bounds__(64) void bce_sum_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ loss) {
     float acc = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 1024) {
+    for (int i = threadIdx.x; i < n; i += 64) acc += partial[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, scale * acc);
+}
+__global__ __launch_bounds__(256) void bce_grad_kernel(const float* __restrict__ z, const float* __restrict__ y,
+                                                       const int32_t* __restrict__ perm, const float* __restrict__ lam,
+                                                       int rows, int cols, float weight, float* __restrict__ dlogits) {
+    const int64_t total = (int64_t)rows * cols;
+    const float inv = 1.0f / (float)total;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
         float t = y[i];
         if (lam != nullptr) {
             const float l = lam[r];
             t = t * l + y[(int64_t)perm[r] * cols + c] * (1.0f - l);
         }
-        const float v = z[i];
-        // max(z,0) - z*y + log1p(exp(-|z|))   (ATen's numerically stable form)
-        acc += fmaxf(v, 0.0f) - v * t + log1pf(expf(-fabsf(v)));
-        if (dlogits != nullptr) {
-            const float sg = 1.0f / (1.0f + expf(-v));
-            dlogits[i] = weight * (sg - t) * inv;
-        }
-    }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float tot = 0.0f;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
-        unsafeAtomicAdd(loss, weight * tot * inv);          // (the caller's scalar accumulates the terms of a composite loss)
+        const float sg = 1.0f / (1.0f + expf(-z[i]));
+        dlogits[i] = weight * (sg - t) * inv;
     }
 }
 
@@ -336,8 +360,23 @@ extern "C" int maest_bce_logits(const float* z, const float* y, const int32_t* p
     MAEST_REQUIRE(z && y && loss, "maest_bce_logits: null pointer");
     MAEST_REQUIRE(rows > 0 && cols > 0, "maest_bce_logits: bad shape");
     MAEST_REQUIRE((perm == nullptr) == (lam == nullptr), "maest_bce_logits: perm and lam go together");
-    hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(1024), 64, (hipStream_t)stream, z, y, perm, lam, rows,
-                       cols, weight, loss, dlogits);
+    const int64_t total = (int64_t)rows * cols;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    if (dlogits == nullptr || total < blocks) {        // loss only (evaluation): one workgroup, fixed order
+        hipLaunchKernelGGL(bce_partial_kernel, dim3(1), dim3(256), 64, (hipStream_t)stream, z, y, perm, lam, rows, cols, weight,
+                           (float*)nullptr, loss);
+        if (dlogits != nullptr)
+            hipLaunchKernelGGL(bce_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, y, perm, lam, rows, cols, weight,
+                               dlogits);
+    } else {
+        hipLaunchKernelGGL(bce_partial_kernel, dim3(blocks), dim3(256), 64, (hipStream_t)stream, z, y, perm, lam, rows, cols, weight,
+                           dlogits, (float*)nullptr);
+        hipLaunchKernelGGL(bce_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)dlogits, blocks,
+                           weight / (float)total, loss);
+        hipLaunchKernelGGL(bce_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, y, perm, lam, rows, cols, weight,
+                           dlogits);
+    }
     return check_launch("maest_bce_logits");
 }
 
