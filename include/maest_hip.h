@@ -77,6 +77,8 @@ const char* maest_last_error(void);
                                  2: every tile a 128-row tile (tests) */
 #define MAEST_OPT_ATTN_FWD 6 /* env MAEST_ATTN_FWD, default 0: bf16 attention forward with K / V tiles fed by LDS-DMA into unpadded
                                 bank-swizzled tiles; 1: the register-staged, padded-pitch form every other dtype uses */
+#define MAEST_OPT_ATTN_FWD_WAVES 7 /* env MAEST_ATTN_FWD_WAVES, default 0: waves (32-query blocks) per workgroup of the DMA-fed bf16
+                                      attention forward chosen by shape; 4 / 5 / 6 / 8 force one (tests, A/B) */
 #define MAEST_OPT_LN_BWD_BLOCKS 4 /* env MAEST_LN_BWD_BLOCKS, default 1024: workgroup cap of the LayerNorm backward grid */
 int maest_set_option(int opt, int value, int restore_default);
 int maest_get_option(int opt, int* value);

@@ -910,10 +910,16 @@ __device__ __forceinline__ void mma_transposed_swz(f32x16_t (&acc)[2], const cha
 #ifndef MAEST_FWD_RING
 #define MAEST_FWD_RING 2      // ring depth of the K / V tiles: 2 = one tile ahead (32 KiB, 4 workgroups per CU); 3 = two ahead (48 KiB, 3 per CU)
 #endif
-#ifndef MAEST_FWD_WGS
-#define MAEST_FWD_WGS (MAEST_FWD_RING == 3 ? 3 : 4)      // workgroups per CU the register allocation is bounded for
-#endif
-__global__ __launch_bounds__(256, MAEST_FWD_WGS) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+// NW = waves per workgroup = 32-query blocks per workgroup (round 3, last part).  Every workgroup of a (batch, head) streams
+// ALL of its K / V tiles from L2 into its own LDS, so the refill traffic (a quarter of the kernel in the removal ablation)
+// scales with the number of workgroups per item, and the rows a partly filled last workgroup pads are computed for nothing:
+// N = 290 is 3 x 128 rows (24 % padding, K / V streamed three times) but 2 x 160 (9 %, twice); N = 560 is 5 x 128 or 3 x 192
+// (3 % instead of 13 %, three times instead of five).  The price is occupancy (16 / 15 / 12 waves per CU at NW = 4 / 5 / 6) and a
+// barrier over more waves; attn_fwd_waves() picks per N from the measurements in profiles/r03_attn_fwd_waves.txt.
+template <int NW>
+struct FwdWgs { static constexpr int value = MAEST_FWD_RING == 3 ? (NW <= 5 ? 3 : 2) : (16 / NW); };
+template <int NW>
+__global__ __launch_bounds__(NW * 64, FwdWgs<NW>::value) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                               float* __restrict__ lse, int B, int N, float scale, int q_rows) {
     using T = bf16_t;
     using C = AttnCfg<T>;
@@ -922,10 +928,11 @@ __global__ __launch_bounds__(256, MAEST_FWD_WGS) void attn_fwd_dma_kernel(const 
 
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const AttnBlock blk = attn_block((N + 127) / 128, B);
+    constexpr int QB = NW * 32;           // query rows per workgroup
+    const AttnBlock blk = attn_block((N + QB - 1) / QB, B);
     const int head = blk.head, b = blk.b;
-    if (blk.rb * 128 >= q_rows) return;   // block-uniform: only the first q_rows queries are wanted (the head's tokens)
-    const int q0 = blk.rb * 128 + wave * 32;
+    if (blk.rb * QB >= q_rows) return;    // block-uniform: only the first q_rows queries are wanted (the head's tokens)
+    const int q0 = blk.rb * QB + wave * 32;
     const int q = q0 + (lane & 31);
     const bool wave_active = q0 < N && q0 < q_rows;   // wave-uniform
     const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
@@ -934,10 +941,22 @@ __global__ __launch_bounds__(256, MAEST_FWD_WGS) void attn_fwd_dma_kernel(const 
 
     const int ntiles = (N + 63) / 64;
     constexpr int RING = MAEST_FWD_RING;      // 2: one tile ahead (32 KiB, 4 workgroups per CU); 3: two ahead (48 KiB, 3 per CU)
-    auto tile_dma = [&](int kt) {         // this wave's 16 rows of K and of V of key tile kt -> ring buffer kt % RING
+    static_assert(RING == 2 || NW == 4, "the counted waits of the three-deep ring assume four pieces per wave and tile");
+    // this wave's share of the 16 one-KiB pieces (8 of K, 8 of V) of key tile kt -> ring buffer kt % RING.  Pieces 2w, 2w + 1 of
+    // K and of V at NW = 4; dealt round-robin otherwise (the waits below are vmcnt(0): the count per wave does not matter)
+    auto tile_dma = [&](int kt) {
         char* kb = smem + (kt % RING) * 2 * TILE128;
-        dma_rows128(kb, kbase, QKV_LD, kt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
-        dma_rows128(kb + TILE128, vbase, QKV_LD, kt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
+        if constexpr (NW == 4) {
+            dma_rows128(kb, kbase, QKV_LD, kt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
+            dma_rows128(kb + TILE128, vbase, QKV_LD, kt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
+        } else {
+#pragma unroll
+            for (int p0 = 0; p0 < 16; p0 += NW) {
+                const int p = p0 + wave;
+                if (p < 8) dma_rows128(kb, kbase, QKV_LD, kt * 64, p, p + 1, 1, N, lane);
+                else if (p < 16) dma_rows128(kb + TILE128, vbase, QKV_LD, kt * 64, p - 8, p - 7, 1, N, lane);
+            }
+        }
     };
     tile_dma(0);
     if (RING == 3 && ntiles > 1) tile_dma(1);
@@ -1624,17 +1643,33 @@ static int attn_bwd_fused_smem(int N) {
     return nkw * 32 * AttnCfg<bf16_t>::PITCH + 2 * (2 * 32 * AttnCfg<bf16_t>::PITCH + 256) + 2 * nkw * 32 * FB_DS_PITCH;
 }
 
+// Waves (= 32-query blocks) per workgroup of attn_fwd_dma_kernel.  MAEST_OPT_ATTN_FWD_WAVES forces 4 / 5 / 6 / 8; 0 = by shape.
+static int attn_fwd_waves(int N, int q_rows) {
+    const int forced = option(MAEST_OPT_ATTN_FWD_WAVES);
+    if (forced == 4 || forced == 5 || forced == 6 || forced == 8) return forced;
+    if (q_rows < N) return 4;                     // head-token passes: one active wave in one workgroup per item anyway
+    return 4;
+}
+
 template <typename T, bool X3 = false>
 static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, int q_rows, hipStream_t st) {
     using C = AttnCfg<T>;
-    dim3 grid(((N + 127) / 128) * NHEADS * B);
     if constexpr (sizeof(T) == 2 && !X3) {
         if (option(MAEST_OPT_ATTN_FWD) == 0) {      // K / V tiles by LDS-DMA (unpadded, swizzled)
-            hipLaunchKernelGGL(attn_fwd_dma_kernel, grid, dim3(256), MAEST_FWD_RING * 2 * 64 * 128, st, (const bf16_t*)qkv, (bf16_t*)out, lse, B, N,
-                               scale, q_rows);
+            const int nw = attn_fwd_waves(N, q_rows);
+            const dim3 g(((N + nw * 32 - 1) / (nw * 32)) * NHEADS * B);
+            const int lds = MAEST_FWD_RING * 2 * 64 * 128;
+#define MAEST_FWD_LAUNCH(NW_) hipLaunchKernelGGL(attn_fwd_dma_kernel<NW_>, g, dim3(NW_ * 64), lds, st, (const bf16_t*)qkv, \
+                                                 (bf16_t*)out, lse, B, N, scale, q_rows)
+            if (nw == 5) MAEST_FWD_LAUNCH(5);
+            else if (nw == 6) MAEST_FWD_LAUNCH(6);
+            else if (nw == 8) MAEST_FWD_LAUNCH(8);
+            else MAEST_FWD_LAUNCH(4);
+#undef MAEST_FWD_LAUNCH
             return check_launch("maest_attn_fwd(dma)");
         }
     }
+    dim3 grid(((N + 127) / 128) * NHEADS * B);
     const int smem_bytes = 4 * C::TILE;
     static DeviceOnce once;
     ensure_dynamic_lds(once, &attn_fwd_kernel<T, X3>, smem_bytes);
