@@ -911,11 +911,13 @@ __device__ __forceinline__ void mma_transposed_swz(f32x16_t (&acc)[2], const cha
 #define MAEST_FWD_RING 2      // ring depth of the K / V tiles: 2 = one tile ahead (32 KiB, 4 workgroups per CU); 3 = two ahead (48 KiB, 3 per CU)
 #endif
 // NW = waves per workgroup = 32-query blocks per workgroup (round 3, last part).  Every workgroup of a (batch, head) streams
-// ALL of its K / V tiles from L2 into its own LDS, so the refill traffic (a quarter of the kernel in the removal ablation)
-// scales with the number of workgroups per item, and the rows a partly filled last workgroup pads are computed for nothing:
-// N = 290 is 3 x 128 rows (24 % padding, K / V streamed three times) but 2 x 160 (9 %, twice); N = 560 is 5 x 128 or 3 x 192
-// (3 % instead of 13 %, three times instead of five).  The price is occupancy (16 / 15 / 12 waves per CU at NW = 4 / 5 / 6) and a
-// barrier over more waves; attn_fwd_waves() picks per N from the measurements in profiles/r03_attn_fwd_waves.txt.
+// ALL of its K / V tiles from L2 into its own LDS, so fewer, larger workgroups move fewer bytes (N = 560: 3 x 192 or 3 x 256
+// rows instead of 5 x 128).  Measured (scratch/attn_fwd_waves.py, profiles/r03_attn_fwd_waves.txt; bit-equal at every NW):
+// it does not pay at the production shapes -- NW = 5 / 6 leave one SIMD with two waves of a workgroup whose per-tile barrier
+// then waits for that SIMD (N = 290: 193 / 187 us against 147), NW = 8 pays its padding (N = 560: 429 against 407 us) and
+// breaks even where the padding is equal (N = 1685: 756 against 767 us).  The refills are latency the four co-resident
+// workgroups already hide, not bandwidth.  Only N <= 256 with more than 128 rows gains (N = 129: 56 against 65 us).
+// attn_fwd_waves() therefore keeps NW = 4; MAEST_OPT_ATTN_FWD_WAVES forces another for tests and A/B.
 template <int NW>
 struct FwdWgs { static constexpr int value = MAEST_FWD_RING == 3 ? (NW <= 5 ? 3 : 2) : (16 / NW); };
 template <int NW>
@@ -1647,8 +1649,8 @@ static int attn_bwd_fused_smem(int N) {
 static int attn_fwd_waves(int N, int q_rows) {
     const int forced = option(MAEST_OPT_ATTN_FWD_WAVES);
     if (forced == 4 || forced == 5 || forced == 6 || forced == 8) return forced;
-    if (q_rows < N) return 4;                     // head-token passes: one active wave in one workgroup per item anyway
-    return 4;
+    (void)N; (void)q_rows;
+    return 4;                                     // measured best at every production shape (see attn_fwd_dma_kernel)
 }
 
 template <typename T, bool X3 = false>
