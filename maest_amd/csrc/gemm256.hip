@@ -642,6 +642,22 @@ __device__ __forceinline__ void epilogueW(char* smem, const f32x16_t (&acc)[2][4
 
 // MAEST_ABLATE_* : timing experiments only (scratch/probe/ablate_w.sh builds the kernel with parts of the main loop
 // removed; results are wrong on purpose).  Never defined in the product build.
+// MAEST_NT_PRIO (timing experiment; the product build leaves it undefined = 0): wave priority in the main loop of
+// gemm_nt256w_kernel.  0: raised for every COMPUTE phase (the shipped form); 1: never; 2: static -- the second-dispatched
+// half (waves 4-7) at priority 1 for the whole loop, no per-phase flips; 3: COMPUTE phases at priority 3.
+#ifndef MAEST_NT_PRIO
+#define MAEST_NT_PRIO 0
+#endif
+#if MAEST_NT_PRIO == 0
+#define MAEST_NT_PRIO_RAISE() __builtin_amdgcn_s_setprio(1)
+#define MAEST_NT_PRIO_DROP() __builtin_amdgcn_s_setprio(0)
+#elif MAEST_NT_PRIO == 3
+#define MAEST_NT_PRIO_RAISE() __builtin_amdgcn_s_setprio(3)
+#define MAEST_NT_PRIO_DROP() __builtin_amdgcn_s_setprio(0)
+#else
+#define MAEST_NT_PRIO_RAISE() ((void)0)
+#define MAEST_NT_PRIO_DROP() ((void)0)
+#endif
 #ifdef MAEST_ABLATE_NO_BARRIER
 #define MAEST_LOOP_BARRIER() ((void)0)
 #else
@@ -810,7 +826,7 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
 #endif
     auto compute = [&](bool dma, int stage, bool is_b, int buf) {
         const int ndma = is_b ? 4 : NA;
-        __builtin_amdgcn_s_setprio(1);
+        MAEST_NT_PRIO_RAISE();
         if constexpr (X3) {
             // split-bf16: the two k chunks of a fragment pair feed ONE K = 16 MFMA triple (common.h: mma_chunk2)
 #pragma unroll
@@ -861,7 +877,7 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
         }
         ++roll_q;
 #endif
-        __builtin_amdgcn_s_setprio(0);
+        MAEST_NT_PRIO_DROP();
     };
     auto next = [](int b, int by) { b += by; return b >= W2_NBUF ? b - W2_NBUF : b; };
 
@@ -873,6 +889,9 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     issue_unit(2, false, 4);
     MAEST_WAIT_VMCNT(2 * NA + 4);    // stage 0 landed (this wave's share): A_1 B_1 A_2 may still fly
     __builtin_amdgcn_s_barrier();
+#if MAEST_NT_PRIO == 2
+    if (wm == 1) __builtin_amdgcn_s_setprio(1);
+#endif
     if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger (wave-uniform)
     // Per stage j, group A (wm == 0) passes barriers  b1 b2 b3 b4  as
     //   LOAD(j,0) b1 COMPUTE(j,0) b2 LOAD(j,1) b3 COMPUTE(j,1) [vmcnt] b4
