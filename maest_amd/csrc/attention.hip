@@ -225,6 +225,44 @@ __device__ __forceinline__ void store_dT(const f32x16_t (&acc)[2], T* row_ptr, i
                       acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
 }
 
+// The same accumulator pair as 16-byte pieces (bf16): [64 d][32 rows] (lane = row, registers = d: d = 32 db + 8 g + 4 h + j) -> 16-byte
+// pieces of the row -- half the store instructions of store_dT at the same bytes and addresses (a row-per-lane store tail is bound by
+// store ISSUE, not bandwidth: cdna_hip_programming.md T21).  Call it from converged code (the exchange is a wave operation); `ok`
+// predicates the store per lane: the two half-waves exchange one 8-byte quarter so that lane (key, h) owns d = 32 db + 8 (pair + 2 h) .. + 7
+__device__ __forceinline__ void store_32d_rows16(const f32x16_t& acc, bf16_t* row_ptr, int lane, float mul, bool ok) {
+    const int h = lane >> 5;
+    uint32_t pk[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        pk[g][0] = pack_bf2(acc[4 * g] * mul, acc[4 * g + 1] * mul);
+        pk[g][1] = pack_bf2(acc[4 * g + 2] * mul, acc[4 * g + 3] * mul);
+    }
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) {
+        // v_permlane32_swap(vdst, src): lanes 32-63 of vdst <-> lanes 0-31 of src.  vdst = group `pair`, src = group `pair + 2`:
+        // afterwards the lower lane holds [own | upper's] quarter of group `pair`, the upper lane [lower's | own] of `pair + 2`
+        const auto x = __builtin_amdgcn_permlane32_swap(pk[pair][0], pk[pair + 2][0], false, false);
+        const auto y = __builtin_amdgcn_permlane32_swap(pk[pair][1], pk[pair + 2][1], false, false);
+        chunk16 c;
+        c[0] = x[0];
+        c[1] = y[0];
+        c[2] = x[1];
+        c[3] = y[1];
+        if (ok) *reinterpret_cast<chunk16*>(row_ptr + 8 * (pair + 2 * h)) = c;
+    }
+}
+__device__ __forceinline__ void store_dT_rows16(const f32x16_t (&acc)[2], bf16_t* row_ptr, int lane, float mul, bool ok) {
+    store_32d_rows16(acc[0], row_ptr, lane, mul, ok);
+    store_32d_rows16(acc[1], row_ptr + 32, lane, mul, ok);
+}
+
+// store_dT for any T; for bf16 the 16-byte-piece form (the caller's row predicate goes in as `ok`)
+template <typename T>
+__device__ __forceinline__ void store_dT_ok(const f32x16_t (&acc)[2], T* row_ptr, int lane, float mul, bool ok) {
+    if constexpr (sizeof(T) == 2) store_dT_rows16(acc, row_ptr, lane, mul, ok);
+    else if (ok) store_dT<T>(acc, row_ptr, lane, mul);
+}
+
 // =================================================================================== forward
 template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(const T* __restrict__ qkv,
@@ -340,11 +378,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(c
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q < N && wave_active && (!(MAEST_ABLATE_FWD & 16) || l_tot == 12345.0f)) {
-        // (staging O through LDS for whole-row stores was measured: no gain at N = 290, -16 % at N = 560 -- the O write costs
-        // its HBM bytes, not its access pattern; profiles/r03_attn_fwd_ablation.txt)
-        store_dT<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv);
-        if (lse != nullptr && h == 0) lse[((int64_t)b * NHEADS + head) * N + q] = m_run * LN2 + logf(l_tot);
+    if (wave_active) {      // (wave-uniform)
+        // (staging O through LDS for whole-row stores was measured: no gain at N = 290, -16 % at N = 560;
+        // profiles/r03_attn_fwd_ablation.txt.  The 16-byte pieces of store_dT_ok need no LDS and no barrier.)
+        const bool ok = q < N && (!(MAEST_ABLATE_FWD & 16) || l_tot == 12345.0f);
+        store_dT_ok<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv, ok);
+        if (ok && lse != nullptr && h == 0) lse[((int64_t)b * NHEADS + head) * N + q] = m_run * LN2 + logf(l_tot);
     }
 }
 
@@ -478,10 +517,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
         if (more) store_tile((qt + 1) & 1);
         __syncthreads();
     }
-    if (key_ok) {
+    {
         T* row = dqkv + ((int64_t)b * N + key) * QKV_LD + head * HD;
-        store_dT<T>(dk, row + NHEADS * HD, lane, scale);
-        store_dT<T>(dv, row + 2 * NHEADS * HD, lane, 1.0f);
+        store_dT_ok<T>(dk, row + NHEADS * HD, lane, scale, key_ok);
+        store_dT_ok<T>(dv, row + 2 * NHEADS * HD, lane, 1.0f, key_ok);
     }
 }
 
@@ -567,7 +606,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
         }
         __syncthreads();
     }
-    if (q_ok) store_dT<T>(dq, dqkv + ((int64_t)b * N + q) * QKV_LD + head * HD, lane, scale);
+    store_dT_ok<T>(dq, dqkv + ((int64_t)b * N + q) * QKV_LD + head * HD, lane, scale, q_ok);
 }
 
 // =================================================================================== fused backward (bf16, N <= 320)
@@ -1032,9 +1071,9 @@ __global__ __launch_bounds__(NW * 64, FwdWgs<NW>::value) void attn_fwd_dma_kerne
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q < N && wave_active) {
-        store_dT<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv);
-        if (lse != nullptr && h == 0) lse[((int64_t)b * NHEADS + head) * N + q] = m_run * LN2 + logf(l_tot);
+    if (wave_active) {      // (wave-uniform)
+        store_dT_ok<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv, q < N);
+        if (q < N && lse != nullptr && h == 0) lse[((int64_t)b * NHEADS + head) * N + q] = m_run * LN2 + logf(l_tot);
     }
 }
 
@@ -1251,13 +1290,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
         auto dq_store = [&](const f32x16_t& acc, int t) {
             if (t < 0 || aux > 1) return;
             const int q = t * 32 + (lane & 31);
-            if (q < N) {
-                T* row = dq_out + (uint32_t)(q * QKV_LD + aux * 32);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    store4<T>(row + 8 * g + 4 * h, acc[4 * g] * scale, acc[4 * g + 1] * scale, acc[4 * g + 2] * scale,
-                              acc[4 * g + 3] * scale);
-            }
+            store_32d_rows16(acc, dq_out + (uint32_t)(q * QKV_LD + aux * 32), lane, scale, q < N);     // (wave-uniform t, aux: converged)
         };
         // prologue: tiles 0 and 1 by DMA; statistics of tile 0 stored, of tile 1 in flight
         tile_dma(0);
@@ -1343,32 +1376,6 @@ __device__ __forceinline__ void row_frags_lds_swz(chunk16 (&f)[4], const char* t
 #pragma unroll
     for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const chunk16*>(rp + (((2 * s + h) ^ fz) << 4));
 }
-// dK^T / dV^T accumulator pair [64 d][32 keys] (lane = key, registers = d: d = 32 db + 8 g + 4 h + j) -> 16-byte pieces of
-// the key's row: the two half-waves exchange one 8-byte quarter so that lane (key, h) owns d = 32 db + 8 (pair + 2 h) .. + 7
-__device__ __forceinline__ void store_dT_rows16(const f32x16_t (&acc)[2], bf16_t* row_ptr, int lane, float mul, bool ok) {
-    const int h = lane >> 5;
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        uint32_t pk[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            pk[g][0] = pack_bf2(acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul);
-            pk[g][1] = pack_bf2(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
-        }
-#pragma unroll
-        for (int pair = 0; pair < 2; ++pair) {
-            const uint32_t s0 = h ? pk[pair][0] : pk[pair + 2][0], s1 = h ? pk[pair][1] : pk[pair + 2][1];
-            const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 32, 64), r1 = (uint32_t)__shfl_xor((int)s1, 32, 64);
-            chunk16 c;
-            c[0] = h ? r0 : pk[pair][0];
-            c[1] = h ? r1 : pk[pair][1];
-            c[2] = h ? pk[pair + 2][0] : r0;
-            c[3] = h ? pk[pair + 2][1] : r1;
-            if (ok) *reinterpret_cast<chunk16*>(row_ptr + db * 32 + 8 * (pair + 2 * h)) = c;
-        }
-    }
-}
-
 __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused3_kernel(const bf16_t* __restrict__ qkv,
                                                                         const bf16_t* __restrict__ dout,
                                                                         const float* __restrict__ lse,
@@ -1580,13 +1587,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused3_kernel(const bf1
         };
         auto dq_store = [&](const f32x16_t& acc, T* out_item, int t) {
             const int q = t * 32 + (lane & 31);
-            if (q < N) {
-                T* row = out_item + (uint32_t)(q * QKV_LD + aux * 32);
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq)
-                    store4<T>(row + 8 * gq + 4 * h, acc[4 * gq] * scale, acc[4 * gq + 1] * scale, acc[4 * gq + 2] * scale,
-                              acc[4 * gq + 3] * scale);
-            }
+            store_32d_rows16(acc, out_item + (uint32_t)(q * QKV_LD + aux * 32), lane, scale, q < N);
         };
         // prologue: statistics of tile 0 stored, of tile 1 in flight
         stat_store(stat_load(it0, 0), 0, 0);

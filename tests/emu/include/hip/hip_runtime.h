@@ -217,6 +217,28 @@ static inline T __shfl(T v, int src, int width = 64) {
     return out;
 }
 
+// v_permlane32_swap_b32 vdst, src: lanes 32-63 of vdst swap with lanes 0-31 of src; returns {new vdst, new src}
+struct emu_u32x2 {
+    uint32_t v[2];
+    uint32_t operator[](int i) const { return v[i]; }
+};
+static inline emu_u32x2 __builtin_amdgcn_permlane32_swap(uint32_t vdst, uint32_t src, bool, bool) {
+    emu::Wave& W = emu::wave();
+    const int l = emu::lane();
+    W.X[l] = vdst;
+    emu::wave_sync();
+    const uint32_t upper_vdst = W.X[(l & 31) + 32];
+    emu::wave_sync();
+    W.X[l] = src;
+    emu::wave_sync();
+    const uint32_t lower_src = W.X[l & 31];
+    emu::wave_sync();
+    emu_u32x2 r;
+    if (l < 32) { r.v[0] = vdst; r.v[1] = upper_vdst; }
+    else { r.v[0] = lower_src; r.v[1] = src; }
+    return r;
+}
+
 static inline float atomicAdd(float* p, float v) {
     std::atomic_ref<float> a(*p);
     float old = a.load();
