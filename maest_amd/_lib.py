@@ -27,6 +27,8 @@ SIGNATURES = {
     "maest_gemm_nt": [_P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _I, _P, _P, _L, _I, _P],
     "maest_gemm_nt_rowdot": [_P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _P, _L, _P, _I, _P],
     "maest_gemm_tn": [_P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _P, _I, _P],
+    "maest_gemm_tn_workspace_bytes": [_I, _I, _I, _I, _I, _P],
+    "maest_gemm_tn_ws": [_P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _P, _I, _P, _L, _P],
     "maest_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
     "maest_cast_weights": [_P, _P, _P, _I, _I, _I, _P],
     "maest_cast_weights_multi": [_I, _P, _P, _P, _P, _P, _I, _P],
@@ -62,8 +64,9 @@ SIGNATURES = {
     "maest_get_option": [_I, _P],
 }
 
-ABI_VERSION = 4
-OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "ln_bwd_blocks": 4, "gemm_tail": 5, "attn_fwd": 6, "attn_fwd_waves": 7}
+ABI_VERSION = 5
+OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "ln_bwd_blocks": 4, "gemm_tail": 5, "attn_fwd": 6, "attn_fwd_waves": 7,
+           "tn_reduce": 8}
 
 _lib = None
 _host_emulation = False  # set only by tests/emu

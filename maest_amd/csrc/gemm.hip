@@ -520,7 +520,8 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
                    int64_t ld_aux, hipStream_t stream, float* rowdot = nullptr, int ntok = 0);   // gemm256.hip
 
 int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C, int64_t ldc, int M,
-                   int N, int K, float* colsum, int split_k, hipStream_t stream);   // gemm256.hip
+                   int N, int K, float* colsum, int split_k, hipStream_t stream, void* ws, int64_t ws_bytes);   // gemm256.hip
+int64_t gemm_tn256_workspace_bytes(int dtype, int M, int N, int K, int split_k);                              // gemm256.hip
 
 // rowdot[item, g, q] = sum_{c < 64} c_mat[m, 64 g + c] * other[m, 64 g + c], m = item * ntok + q: four lanes per (row, group).
 // The stand-alone form of the MAEST_EPI_ROWDOT epilogue (shapes the 256-row-tile kernels do not take).
@@ -660,9 +661,24 @@ extern "C" int maest_gemm_nt_rowdot(const void* A, int64_t lda, const void* B, i
     return check_launch("maest_gemm_nt_rowdot");
 }
 
+extern "C" int maest_gemm_tn_workspace_bytes(int dtype, int M, int N, int K, int split_k, int64_t* bytes) {
+    MAEST_REQUIRE(bytes != nullptr, "maest_gemm_tn_workspace_bytes: null result pointer");
+    MAEST_REQUIRE(M > 0 && N > 0 && K > 0 && split_k >= 0, "maest_gemm_tn_workspace_bytes: bad shape M=%d N=%d K=%d", M, N, K);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3, "maest_gemm_tn_workspace_bytes: bad dtype %d", dtype);
+    *bytes = gemm_tn256_workspace_bytes(dtype, M, N, K, split_k);
+    return MAEST_OK;
+}
+
 extern "C" int maest_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C,
                              int64_t ldc, int M, int N, int K, float* colsum, int split_k, void* stream) {
+    return maest_gemm_tn_ws(A, lda, B, ldb, dtype, C, ldc, M, N, K, colsum, split_k, nullptr, 0, stream);
+}
+
+extern "C" int maest_gemm_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C,
+                                int64_t ldc, int M, int N, int K, float* colsum, int split_k, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
     MAEST_REQUIRE(A && B && C, "maest_gemm_tn: null operand");
+    MAEST_REQUIRE(workspace_bytes >= 0, "maest_gemm_tn_ws: negative workspace size");
     MAEST_REQUIRE(M > 0 && N > 0 && K > 0, "maest_gemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
     MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3, "maest_gemm_tn: bad dtype %d", dtype);
     const bool x3 = dtype == MAEST_F32X3;        // split-bf16 products exist in the 256-tile kernel; other shapes: exact fp32
@@ -674,7 +690,7 @@ extern "C" int maest_gemm_tn(const void* A, int64_t lda, const void* B, int64_t 
     MAEST_REQUIRE(split_k >= 0, "maest_gemm_tn: split_k must be >= 0 (0 = automatic)");
     {   // large aligned problems go to the 256x256 LDS-DMA kernel
         const int rc = gemm_tn256_try(A, lda, B, ldb, x3 ? MAEST_F32X3 : dtype, C, ldc, M, N, K, colsum, split_k,
-                                      (hipStream_t)stream);
+                                      (hipStream_t)stream, workspace, workspace_bytes);
         if (rc >= 0) return rc;
     }
     if (split_k == 0) {

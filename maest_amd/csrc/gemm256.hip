@@ -1280,6 +1280,7 @@ struct GemmTn256Params {
     int M, N, K;
     int tiles_m, tiles_n;
     int k_slices_per_split, split_k;
+    float* ws;      // NULL: the split-K partials are added to C with fp32 atomics; else [split][tile][wave][32 chunks][64 lanes][4] fp32
 };
 
 template <typename T, bool X3 = false>
@@ -1430,6 +1431,23 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
 #ifdef MAEST_ABLATE_NO_EPI
     if (acc[0][0][0] != 123.456f) return;
 #endif
+    if (p.ws != nullptr) {
+        // Workspace form of the split-K combine (end of round 3).  The atomic form below issues 1024 global_atomic_add_f32 per
+        // workgroup, 256 B each: the store path takes an instruction per ~64 clk and CU whatever its width, so the 256 KiB tile
+        // leaves at ~4 B/clk (the 40-50 us of a 0.3 ms launch).  Here the accumulators leave as they sit in the registers, four at
+        // a time: 256 dwordx4 stores of 1 KiB, lane-linear (the layout is private to this kernel and tn256_reduce_kernel, which
+        // sums the partials of a tile in split order -- deterministic -- and adds them to C).
+        float* base = p.ws + ((int64_t)(split * ntiles + tile) * 8 + wave) * 8192 + lane * 4;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4_t v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(base + ((a * 2 + b) * 4 + q) * 256));
+                }
+    } else {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int col = j0 + wn * 64 + b * 32 + (lane & 31);
@@ -1441,10 +1459,81 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
                 unsafeAtomicAdd(p.C + (int64_t)row * p.ldc + col, acc[a][b][r]);
             }
     }
+    }
     if (do_colsum) {
         const float tot = cs + __shfl_xor(cs, 32, 64);     // merge the two k halves
         if (lane < 32) unsafeAtomicAdd(p.colsum + i0 + wm * 128 + wn * 32 + lane, tot);
     }
+}
+
+// C[tile] += sum over the splits, in split order, of the partial tiles gemm_tn256_kernel left in the workspace.  One wave per
+// (tile, GEMM wave, i-block a): it re-reads what that wave's lanes stored (16 bytes per lane and chunk: 1 KiB per instruction),
+// turns each 32 x 32 block around through LDS (a lane holds 4 consecutive ROWS of one column) and adds 16-byte row pieces to C.
+__global__ __launch_bounds__(64) void tn256_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc, int ntiles,
+                                                          int tiles_n, int split_k) {
+    __shared__ float blk[32 * 33];
+    const int lane = threadIdx.x;
+    const int a = blockIdx.x & 3, wave = (blockIdx.x >> 2) & 7, tile = blockIdx.x >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tile_i = tile / tiles_n, tile_j = tile - tile_i * tiles_n;
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        f32x4_t s[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        const float* src = ws + ((int64_t)tile * 8 + wave) * 8192 + ((a * 2 + b) * 4) * 256 + lane * 4;
+        for (int sp = 0; sp < split_k; ++sp) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                s[q] += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + q * 256));
+            src += (int64_t)ntiles * 8 * 8192;
+        }
+        __syncthreads();                     // (one wave: orders the LDS reads of the previous block before these writes)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) blk[(8 * q + 4 * h + j) * 33 + c] = s[q][j];      // row = frag_row(4 q + j, lane)
+        __syncthreads();
+        const int64_t row0 = (int64_t)tile_i * 256 + wm * 128 + a * 32;
+        const int col0 = tile_j * 256 + wn * 64 + b * 32 + (lane & 7) * 4;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + (lane >> 3);
+            const float* bp = blk + r * 33 + (lane & 7) * 4;
+            f32x4_t* dst = reinterpret_cast<f32x4_t*>(C + (row0 + r) * ldc + col0);
+            f32x4_t v = *dst;
+            v[0] += bp[0]; v[1] += bp[1]; v[2] += bp[2]; v[3] += bp[3];
+            *dst = v;
+        }
+    }
+}
+
+// split_k, K slices per split and workgroup count of the 256-tile TN kernel for a shape; false when it does not take the shape
+static bool tn256_plan(int dtype, int M, int N, int K, int split_k, int* splits, int* per_split) {
+    if (dtype == MAEST_F32X3) dtype = MAEST_F32;
+    const int ks = dtype == MAEST_BF16 ? Tn256<bf16_t>::KS : Tn256<float>::KS;
+    if ((M % 256) != 0 || (N % 256) != 0 || (K % ks) != 0 || K < 8 * ks) return false;
+    // variant 4: take any qualifying shape (emulator tests)
+    if ((int64_t)M * N < (int64_t)8 * 65536 && option(MAEST_OPT_GEMM_VARIANT) != 4)
+        return false;                                      // few output tiles: the 128x128 kernel splits K finer
+    const int total = K / ks;
+    const int tiles = (M / 256) * (N / 256);
+    // one workgroup per CU and ONE round: never more workgroups than the 256 CUs (rounding up gave 288 for the
+    // 36-tile fc1/fc2 wgrads, i.e. a second round for 32 stragglers: 0.49 ms instead of 0.33 ms)
+    if (split_k <= 0) split_k = tiles >= 256 ? 1 : 256 / tiles;
+    if (split_k > total / 4) split_k = total / 4 > 0 ? total / 4 : 1;
+    *per_split = (total + split_k - 1) / split_k;
+    *splits = (total + *per_split - 1) / *per_split;
+    return true;
+}
+
+// Bytes of workspace with which maest_gemm_tn_ws combines the split-K partials without atomics; 0: the shape takes a path
+// that has no workspace form (or a single split)
+int64_t gemm_tn256_workspace_bytes(int dtype, int M, int N, int K, int split_k) {
+    int splits = 1, per = 0;
+    if (option(MAEST_OPT_TN_REDUCE) == 0 || !tn256_plan(dtype, M, N, K, split_k, &splits, &per) || splits < 2) return 0;
+    return (int64_t)splits * (M / 256) * (N / 256) * 65536 * (int64_t)sizeof(float);
 }
 
 template <typename T, bool X3 = false>
@@ -1452,34 +1541,34 @@ static int launch_tn256(GemmTn256Params& p, int split_k, hipStream_t stream) {
     static DeviceOnce once;
     ensure_dynamic_lds(once, &gemm_tn256_kernel<T, X3>, G2_SMEM);
     p.split_k = split_k;
-    hipLaunchKernelGGL((gemm_tn256_kernel<T, X3>), dim3(p.tiles_m * p.tiles_n * split_k), dim3(512), G2_SMEM, stream, p);
-    return check_launch("maest_gemm_tn(256)");
+    const int ntiles = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((gemm_tn256_kernel<T, X3>), dim3(ntiles * split_k), dim3(512), G2_SMEM, stream, p);
+    const int rc = check_launch("maest_gemm_tn(256)");
+    if (rc != MAEST_OK || p.ws == nullptr) return rc;
+    hipLaunchKernelGGL(tn256_reduce_kernel, dim3(ntiles * 32), dim3(64), 0, stream, (const float*)p.ws, p.C, p.ldc, ntiles, p.tiles_n,
+                       split_k);
+    return check_launch("maest_gemm_tn(256, reduce)");
 }
 
-// Called by maest_gemm_tn; returns -1 when the shape does not qualify.  split_k <= 0 = automatic.
+// Called by maest_gemm_tn; returns -1 when the shape does not qualify.  split_k <= 0 = automatic.  ws / ws_bytes: optional
+// workspace (gemm_tn256_workspace_bytes); too small or NULL = atomics.
 int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C, int64_t ldc, int M,
-                   int N, int K, float* colsum, int split_k, hipStream_t stream) {
+                   int N, int K, float* colsum, int split_k, hipStream_t stream, void* ws, int64_t ws_bytes) {
     const bool x3 = dtype == MAEST_F32X3;        // fp32 tensors, split-bf16 products
+    int per = 0;
+    if (!tn256_plan(dtype, M, N, K, split_k, &split_k, &per)) return -1;
     if (x3) dtype = MAEST_F32;
-    const int ks = dtype == MAEST_BF16 ? Tn256<bf16_t>::KS : Tn256<float>::KS;
-    if ((M % 256) != 0 || (N % 256) != 0 || (K % ks) != 0 || K < 8 * ks) return -1;
-    // variant 4: take any qualifying shape (emulator tests)
-    if ((int64_t)M * N < (int64_t)8 * 65536 && option(MAEST_OPT_GEMM_VARIANT) != 4)
-        return -1;                                         // few output tiles: the 128x128 kernel splits K finer
     GemmTn256Params p;
     p.A = (const char*)A; p.B = (const char*)B; p.C = C; p.colsum = colsum;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K;
     p.tiles_m = M / 256;
     p.tiles_n = N / 256;
-    const int total = K / ks;
-    const int tiles = p.tiles_m * p.tiles_n;
-    // one workgroup per CU and ONE round: never more workgroups than the 256 CUs (rounding up gave 288 for the
-    // 36-tile fc1/fc2 wgrads, i.e. a second round for 32 stragglers: 0.49 ms instead of 0.33 ms)
-    if (split_k <= 0) split_k = tiles >= 256 ? 1 : 256 / tiles;
-    if (split_k > total / 4) split_k = total / 4 > 0 ? total / 4 : 1;
-    p.k_slices_per_split = (total + split_k - 1) / split_k;
-    split_k = (total + p.k_slices_per_split - 1) / p.k_slices_per_split;
+    p.k_slices_per_split = per;
+    const int64_t need = (int64_t)split_k * p.tiles_m * p.tiles_n * 65536 * (int64_t)sizeof(float);
+    const bool use_ws = ws != nullptr && split_k >= 2 && ws_bytes >= need && option(MAEST_OPT_TN_REDUCE) != 0 &&
+                        ((uintptr_t)ws % 16) == 0 && ((uintptr_t)C % 16) == 0 && (ldc % 4) == 0;
+    p.ws = use_ws ? (float*)ws : nullptr;
     if (x3) return launch_tn256<float, true>(p, split_k, stream);
     return dtype == MAEST_BF16 ? launch_tn256<bf16_t>(p, split_k, stream) : launch_tn256<float>(p, split_k, stream);
 }

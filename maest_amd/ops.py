@@ -161,8 +161,14 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, colsum: Optiona
     for t in (a, b, out, colsum):
         if t is not None and not (t.is_cuda or _lib.host_emulation()):
             raise _lib.MaestHipError("maest_amd kernels need tensors on a HIP device; there is no CPU fallback")
-    _timed_call("maest_gemm_tn", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), _mm_code(a.dtype, x3), _p(out2),
-                out2.stride(0), M, N, K, _p(colsum), split_k, _s(a))
+    # split-K partials through a scratch buffer where the kernel has that form (deterministic, no atomics on `out`): the buffer
+    # comes from torch's caching allocator on the CURRENT stream -- the stream the call runs on -- so its reuse is stream-ordered
+    code = _mm_code(a.dtype, x3)
+    nbytes = ctypes.c_int64(0)
+    call("maest_gemm_tn_workspace_bytes", code, M, N, K, split_k, ctypes.byref(nbytes))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=a.device) if nbytes.value > 0 else None
+    _timed_call("maest_gemm_tn", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), code, _p(out2),
+                out2.stride(0), M, N, K, _p(colsum), split_k, _p(ws), nbytes.value, _s(a), _entry="maest_gemm_tn_ws")
     return out
 
 
