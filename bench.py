@@ -46,7 +46,7 @@ def flops_per_clip_fwd_not_executed(N, attn_rows):
     return 2 * (N - 2) * 768 * (768 + 3072 + 3072) + 4 * (N - attn_rows) * N * 768
 
 
-PMC_TRAFFIC_FILE = "profiles/r03b_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r03c_pmc_traffic.json"
 
 
 def pmc_traffic():
@@ -71,7 +71,7 @@ def measure_pmc_traffic(timeout_s=150):
     file (2 steps + 1 warm-up, kernels serialized, no side cases), on this GPU.  Per call = sum over every gemm_nt256w
     launch (256-row tiles and the 128-row-tile launch behind some of them) / number of 256-row-tile launches;
     traffic = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section: FETCH_SIZE counts half of the wide coalesced
-    reads on gfx950; profiles/r03b_pmc_traffic.json holds the same passes with their calibration on known byte counts:
+    reads on gfx950; profiles/r03c_pmc_traffic.json holds the same passes with their calibration on known byte counts:
     x2.00 / x1.00).  Returns (bytes, source, parts) or (None, reason, None): any failure falls back to the committed figure."""
     import csv, glob, shutil, subprocess, tempfile
     exe = shutil.which("rocprofv3")

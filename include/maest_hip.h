@@ -79,8 +79,9 @@ const char* maest_last_error(void);
                                 bank-swizzled tiles; 1: the register-staged, padded-pitch form every other dtype uses */
 #define MAEST_OPT_ATTN_FWD_WAVES 7 /* env MAEST_ATTN_FWD_WAVES, default 0: waves (32-query blocks) per workgroup of the DMA-fed bf16
                                       attention forward chosen by shape; 4 / 5 / 6 / 8 force one (tests, A/B) */
-#define MAEST_OPT_TN_REDUCE 8 /* env MAEST_TN_REDUCE, default 1: maest_gemm_tn_ws uses a workspace it is given (partial tiles stored
-                                 plainly, summed in split order by a second kernel); 0: always fp32 atomics (A/B) */
+#define MAEST_OPT_TN_REDUCE 8 /* env MAEST_TN_REDUCE, default 0: split-K partials of the wgrad GEMM are combined with fp32 atomics; 1:
+                                 maest_gemm_tn_ws uses the workspace it is given (partial tiles stored plainly, summed in split
+                                 order by a second kernel: bit-reproducible dW; +0.3 % on the training step, measured) */
 #define MAEST_OPT_LN_BWD_BLOCKS 4 /* env MAEST_LN_BWD_BLOCKS, default 1024: workgroup cap of the LayerNorm backward grid */
 int maest_set_option(int opt, int value, int restore_default);
 int maest_get_option(int opt, int* value);
@@ -117,12 +118,15 @@ int maest_gemm_nt_rowdot(const void* A, int64_t lda, const void* B, int64_t ldb,
  * than M / N.  split_k partials are combined with fp32 atomics; split_k = 0 picks it automatically. */
 int maest_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C,
                   int64_t ldc, int M, int N, int K, float* colsum, int split_k, void* stream);
-/* The same with a caller-owned scratch buffer (ABI 5).  Given `workspace_bytes` >= maest_gemm_tn_workspace_bytes(...) of 16-byte
- * aligned device memory (and C 16-byte aligned, ldc % 4 == 0), the K-split partial tiles are written to it with plain 16-byte
- * stores and a second kernel adds them to C in split order: no atomics on C, so dW is bit-reproducible from run to run (colsum
- * still uses atomics), and the 1024 narrow atomic instructions per workgroup of the epilogue (40-50 us of a 0.3 ms launch) become
- * 256 wide stores.  workspace = NULL, a smaller buffer, or a shape for which maest_gemm_tn_workspace_bytes reports 0 = exactly
- * maest_gemm_tn.  The workspace is dead when the call's work on `stream` has completed. */
+/* The same with a caller-owned scratch buffer (ABI 5): the DETERMINISTIC form of the split-K combine, selected by
+ * MAEST_OPT_TN_REDUCE = 1.  Given `workspace_bytes` >= the figure maest_gemm_tn_workspace_bytes reports, of 16-byte aligned device
+ * memory (and C 16-byte aligned, ldc % 4 == 0), the K-split partial tiles are written to it with plain 16-byte stores and a second
+ * kernel adds them to C in split order: no atomics on C, so dW is bit-reproducible from run to run (colsum still uses atomics).
+ * Measured against the atomics: the GEMM + reduce pair is 1-3 % faster than the GEMM with its atomic epilogue when timed alone
+ * (the 1024 narrow atomic instructions per workgroup become 256 wide stores) but the training step is 0.3 % slower with it
+ * (profiles/r03_ab_tn_workspace_combine.txt) -- hence opt-in.  workspace = NULL, a smaller buffer, the option at 0, or a shape
+ * for which maest_gemm_tn_workspace_bytes reports 0 = exactly maest_gemm_tn.  The workspace is dead when the call's work on
+ * `stream` has completed. */
 int maest_gemm_tn_workspace_bytes(int dtype, int M, int N, int K, int split_k, int64_t* bytes);
 int maest_gemm_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C, int64_t ldc, int M, int N,
                      int K, float* colsum, int split_k, void* workspace, int64_t workspace_bytes, void* stream);

@@ -1437,6 +1437,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
         // leaves at ~4 B/clk (the 40-50 us of a 0.3 ms launch).  Here the accumulators leave as they sit in the registers, four at
         // a time: 256 dwordx4 stores of 1 KiB, lane-linear (the layout is private to this kernel and tn256_reduce_kernel, which
         // sums the partials of a tile in split order -- deterministic -- and adds them to C).
+        // Measured (profiles/r03_ab_tn_workspace_combine.txt): the GEMM + reduce pair is 1-3 % faster than the atomic form alone, the
+        // training step 0.3 % slower (the reduce kernel re-reads 64 MB beside the other stream's GEMMs): opt-in, for reproducible dW.
         float* base = p.ws + ((int64_t)(split * ntiles + tile) * 8 + wave) * 8192 + lane * 4;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -1471,7 +1473,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
 // turns each 32 x 32 block around through LDS (a lane holds 4 consecutive ROWS of one column) and adds 16-byte row pieces to C.
 __global__ __launch_bounds__(64) void tn256_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc, int ntiles,
                                                           int tiles_n, int split_k) {
-    __shared__ float blk[32 * 33];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* blk = reinterpret_cast<float*>(smem);      // [32][33]
     const int lane = threadIdx.x;
     const int a = blockIdx.x & 3, wave = (blockIdx.x >> 2) & 7, tile = blockIdx.x >> 5;
     const int wm = wave >> 2, wn = wave & 3;
@@ -1545,7 +1548,7 @@ static int launch_tn256(GemmTn256Params& p, int split_k, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_tn256_kernel<T, X3>), dim3(ntiles * split_k), dim3(512), G2_SMEM, stream, p);
     const int rc = check_launch("maest_gemm_tn(256)");
     if (rc != MAEST_OK || p.ws == nullptr) return rc;
-    hipLaunchKernelGGL(tn256_reduce_kernel, dim3(ntiles * 32), dim3(64), 0, stream, (const float*)p.ws, p.C, p.ldc, ntiles, p.tiles_n,
+    hipLaunchKernelGGL(tn256_reduce_kernel, dim3(ntiles * 32), dim3(64), 32 * 33 * sizeof(float), stream, (const float*)p.ws, p.C, p.ldc, ntiles, p.tiles_n,
                        split_k);
     return check_launch("maest_gemm_tn(256, reduce)");
 }

@@ -172,6 +172,13 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, colsum: Optiona
     return out
 
 
+def gemm_tn_workspace_bytes(dtype, M: int, N: int, K: int, split_k: int = 0, x3: bool = False) -> int:
+    """Scratch bytes with which gemm_tn combines its split-K partials without atomics (0: this shape has no such form)."""
+    nbytes = ctypes.c_int64(0)
+    call("maest_gemm_tn_workspace_bytes", _mm_code(dtype, x3), M, N, K, split_k, ctypes.byref(nbytes))
+    return nbytes.value
+
+
 def transpose(src: torch.Tensor, ld_dst: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[c, r] = src[r, c]; out has shape [cols, ld_dst] with the pad columns zeroed."""
     assert src.dim() == 2 and src.stride(1) == 1

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from maest_amd import ops
+from maest_amd import _lib, ops
 from oracle import maest_oracle as O
 
 
@@ -107,6 +107,20 @@ def case_gemm_tn(dev, dtype, K, M, N, seed=3, lda_pad=0):
         ops.gemm_tn(a_dev, b.to(dev), out, colsum=cs, split_k=sk, M=M, N=N)
         close(out, ref, 1e-5, at, f"gemm_tn split_k={sk}")
         close(cs, ref_cs, 1e-5, at, f"gemm_tn colsum split_k={sk}")
+    # the deterministic split-K combine of the 256-tile kernel (tn_reduce=1; where the shape takes it): partial tiles through a
+    # workspace, summed in split order by a second kernel -- bit-reproducible, and ACCUMULATING into `out` like the atomics
+    a_dev, b_dev = a_full.to(dev)[:, :M], b.to(dev)
+    with ops.options(tn_reduce=1):
+        outs = []
+        for _ in range(1 if _lib.host_emulation() else 2):
+            out = torch.zeros((M, N), dtype=torch.float32, device=dev)
+            ops.gemm_tn(a_dev, b_dev, out, split_k=0, M=M, N=N)
+            outs.append(out)
+        close(outs[0], ref, 1e-5, at, "gemm_tn (workspace combine)")
+        if ops.gemm_tn_workspace_bytes(dtype, M, N, K) > 0 and len(outs) == 2:
+            assert torch.equal(outs[0], outs[1]), "gemm_tn through the workspace must be bit-reproducible"
+            ops.gemm_tn(a_dev, b_dev, outs[1], split_k=0, M=M, N=N)            # second call accumulates
+            close(outs[1], 2 * ref, 1e-5, 2 * at, "gemm_tn accumulates into a non-zero C")
     # transpose-detecting: A = [I | 0] picks rows of B
     if dtype == torch.float32 and K >= M:
         eye = torch.zeros(K, M)
@@ -219,7 +233,9 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2):
             out1, lse1 = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
         close(out1, ref, rt, at, "attention fwd (register-staged tiles)")
         assert torch.equal(out1, out) and torch.equal(lse1, lse), "DMA-fed and register-staged attention forward differ"
-        for nw in (5, 6, 8):     # other workgroup sizes of the DMA-fed form: the same per-wave arithmetic, other tile dealing
+        # other workgroup sizes of the DMA-fed form: the same per-wave arithmetic, other tile dealing (one of them under the
+        # host emulator, which runs a launch in seconds)
+        for nw in ((5,) if _lib.host_emulation() else (5, 6, 8)):
             with ops.options(attn_fwd_waves=nw):
                 outw, lsew = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
             assert torch.equal(outw, out) and torch.equal(lsew, lse), f"attention forward with {nw} waves per workgroup differs"

@@ -43,6 +43,24 @@ def test_argument_validation_returns_status_and_message():
     assert rc == 1 and b"768" in lib.maest_last_error()
 
 
+def test_wgrad_workspace_size_is_host_logic():
+    """maest_gemm_tn_workspace_bytes (the opt-in deterministic split-K combine): one 256 KiB partial tile per workgroup of the
+    split-K launch (at most one round of 256), 0 for shapes the 256-tile kernel does not take or that need no split; no device work."""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    from maest_amd import ops
+    tile = 256 * 256 * 4
+    assert ops.gemm_tn_workspace_bytes(torch.bfloat16, 2304, 768, 74240) == 0                       # default: fp32 atomics
+    with ops.options(tn_reduce=1):
+        assert ops.gemm_tn_workspace_bytes(torch.bfloat16, 2304, 768, 74240) == 9 * 27 * tile       # qkv wgrad: 27 tiles x 9 splits
+        assert ops.gemm_tn_workspace_bytes(torch.bfloat16, 768, 768, 74240) == 28 * 9 * tile        # proj: 9 tiles x 28 splits
+        assert ops.gemm_tn_workspace_bytes(torch.bfloat16, 3072, 768, 74240) == 7 * 36 * tile
+        assert ops.gemm_tn_workspace_bytes(torch.bfloat16, 400, 768, 74240) == 0                    # ragged M: the 128-tile kernel
+        assert ops.gemm_tn_workspace_bytes(torch.bfloat16, 768, 768, 74240, split_k=1) == 0         # a single split: nothing to combine
+    lib = _lib.load()
+    assert lib.maest_gemm_tn_workspace_bytes(1, 2304, 768, 74240, 0, None) == 1 and b"null result" in lib.maest_last_error()
+
+
 def test_numpy_input(model):
     with pytest.raises(Exception):
         model(np.random.rand(128, 128))
