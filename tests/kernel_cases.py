@@ -233,9 +233,9 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2):
             out1, lse1 = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
         close(out1, ref, rt, at, "attention fwd (register-staged tiles)")
         assert torch.equal(out1, out) and torch.equal(lse1, lse), "DMA-fed and register-staged attention forward differ"
-        # other workgroup sizes of the DMA-fed form: the same per-wave arithmetic, other tile dealing (one of them under the
-        # host emulator, which runs a launch in seconds)
-        for nw in ((5,) if _lib.host_emulation() else (5, 6, 8)):
+        # other workgroup sizes of the DMA-fed form: the same per-wave arithmetic, other tile dealing (GPU only: the host emulator
+        # takes seconds per launch and the CPU suite has to stay short)
+        for nw in (() if _lib.host_emulation() else (5, 6, 8)):
             with ops.options(attn_fwd_waves=nw):
                 outw, lsew = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
             assert torch.equal(outw, out) and torch.equal(lsew, lse), f"attention forward with {nw} waves per workgroup differs"
