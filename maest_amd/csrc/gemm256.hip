@@ -1433,10 +1433,10 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
 #endif
     if (p.ws != nullptr) {
         // Workspace form of the split-K combine (end of round 3).  The atomic form below issues 1024 global_atomic_add_f32 per
-        // workgroup, 256 B each: the store path takes an instruction per ~64 clk and CU whatever its width, so the 256 KiB tile
-        // leaves at ~4 B/clk (the 40-50 us of a 0.3 ms launch).  Here the accumulators leave as they sit in the registers, four at
-        // a time: 256 dwordx4 stores of 1 KiB, lane-linear (the layout is private to this kernel and tn256_reduce_kernel, which
-        // sums the partials of a tile in split order -- deterministic -- and adds them to C).
+        // workgroup, 256 B each, and an fp32 atomic instruction takes ~50 ns of a CU's store path (scratch/probe/store_issue.hip):
+        // the 40-50 us of a 0.3 ms launch.  Here the accumulators leave as they sit in the registers, four at a time: 256 dwordx4
+        // stores of 1 KiB (~38 ns each when streaming), lane-linear -- the layout is private to this kernel and
+        // tn256_reduce_kernel, which sums the partials of a tile in split order (deterministic) and adds them to C.
         // Measured (profiles/r03_ab_tn_workspace_combine.txt): the GEMM + reduce pair is 1-3 % faster than the atomic form alone, the
         // training step 0.3 % slower (the reduce kernel re-reads 64 MB beside the other stream's GEMMs): opt-in, for reproducible dW.
         float* base = p.ws + ((int64_t)(split * ntiles + tile) * 8 + wave) * 8192 + lane * 4;
