@@ -81,7 +81,7 @@ const char* maest_last_error(void);
                                       attention forward chosen by shape; 4 / 5 / 6 / 8 force one (tests, A/B) */
 #define MAEST_OPT_TN_REDUCE 8 /* env MAEST_TN_REDUCE, default 0: split-K partials of the wgrad GEMM are combined with fp32 atomics; 1:
                                  maest_gemm_tn_ws uses the workspace it is given (partial tiles stored plainly, summed in split
-                                 order by a second kernel: bit-reproducible dW; +0.3 % on the training step, measured) */
+                                 order by a second kernel: bit-reproducible dW; no measurable cost on the training step) */
 #define MAEST_OPT_LN_BWD_BLOCKS 4 /* env MAEST_LN_BWD_BLOCKS, default 1024: workgroup cap of the LayerNorm backward grid */
 int maest_set_option(int opt, int value, int restore_default);
 int maest_get_option(int opt, int* value);
@@ -122,9 +122,9 @@ int maest_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int dt
  * MAEST_OPT_TN_REDUCE = 1.  Given `workspace_bytes` >= the figure maest_gemm_tn_workspace_bytes reports, of 16-byte aligned device
  * memory (and C 16-byte aligned, ldc % 4 == 0), the K-split partial tiles are written to it with plain 16-byte stores and a second
  * kernel adds them to C in split order: no atomics on C, so dW is bit-reproducible from run to run (colsum still uses atomics).
- * Measured against the atomics: the GEMM + reduce pair is 1-3 % faster than the GEMM with its atomic epilogue when timed alone
- * (the 1024 narrow atomic instructions per workgroup become 256 wide stores) but the training step is 0.3 % slower with it
- * (profiles/r03_ab_tn_workspace_combine.txt) -- hence opt-in.  workspace = NULL, a smaller buffer, the option at 0, or a shape
+ * Measured against the atomics (profiles/r03_ab_tn_workspace_combine.txt): the GEMM + reduce pair timed alone is 21 % faster at the
+ * proj shape (28 splits), 6 % at qkv, equal at fc1 / fc2; the training step is equal within the pairs' spread -- opt-in because
+ * there is no gain to claim, not because it costs.  workspace = NULL, a smaller buffer, the option at 0, or a shape
  * for which maest_gemm_tn_workspace_bytes reports 0 = exactly maest_gemm_tn.  The workspace is dead when the call's work on
  * `stream` has completed. */
 int maest_gemm_tn_workspace_bytes(int dtype, int M, int N, int K, int split_k, int64_t* bytes);

@@ -1437,8 +1437,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
         // the 40-50 us of a 0.3 ms launch.  Here the accumulators leave as they sit in the registers, four at a time: 256 dwordx4
         // stores of 1 KiB (~38 ns each when streaming), lane-linear -- the layout is private to this kernel and
         // tn256_reduce_kernel, which sums the partials of a tile in split order (deterministic) and adds them to C.
-        // Measured (profiles/r03_ab_tn_workspace_combine.txt): the GEMM + reduce pair is 1-3 % faster than the atomic form alone, the
-        // training step 0.3 % slower (the reduce kernel re-reads 64 MB beside the other stream's GEMMs): opt-in, for reproducible dW.
+        // Measured (profiles/r03_ab_tn_workspace_combine.txt): GEMM + reduce against the atomic form alone -21 % (proj, 28 splits) ...
+        // +-0 (fc1 / fc2, 7 splits); the training step equal within the pairs' spread: opt-in, for reproducible dW.
         float* base = p.ws + ((int64_t)(split * ntiles + tile) * 8 + wave) * 8192 + lane * 4;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -1469,47 +1469,47 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
 }
 
 // C[tile] += sum over the splits, in split order, of the partial tiles gemm_tn256_kernel left in the workspace.  One wave per
-// (tile, GEMM wave, i-block a): it re-reads what that wave's lanes stored (16 bytes per lane and chunk: 1 KiB per instruction),
-// turns each 32 x 32 block around through LDS (a lane holds 4 consecutive ROWS of one column) and adds 16-byte row pieces to C.
+// (tile, GEMM wave, 32 x 32 block): it re-reads what that wave's lanes stored for the block (16 bytes per lane and chunk: 1 KiB per
+// instruction, four splits in flight) and adds the sums to C as the accumulator layout has them -- for a fixed register the lanes of
+// a half-wave hold 32 consecutive columns of one row, i.e. lane-linear 128-byte runs, which cost their bytes
+// (scratch/probe/store_issue.hip).  No LDS, 40 registers: it fits beside any other kernel's workgroups.
 __global__ __launch_bounds__(64) void tn256_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc, int ntiles,
                                                           int tiles_n, int split_k) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* blk = reinterpret_cast<float*>(smem);      // [32][33]
     const int lane = threadIdx.x;
-    const int a = blockIdx.x & 3, wave = (blockIdx.x >> 2) & 7, tile = blockIdx.x >> 5;
+    const int ab = blockIdx.x & 7, wave = (blockIdx.x >> 3) & 7, tile = blockIdx.x >> 6;
+    const int a = ab >> 1, b = ab & 1;
     const int wm = wave >> 2, wn = wave & 3;
     const int tile_i = tile / tiles_n, tile_j = tile - tile_i * tiles_n;
-    const int h = lane >> 5, c = lane & 31;
+    f32x4_t s[4];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        f32x4_t s[4];
+    for (int q = 0; q < 4; ++q) s[q] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    const float* src = ws + ((int64_t)tile * 8 + wave) * 8192 + (ab * 4) * 256 + lane * 4;
+    const int64_t step = (int64_t)ntiles * 8 * 8192;
+    int sp = 0;
+    for (; sp + 4 <= split_k; sp += 4) {          // four splits' loads in flight, added in split order
+        f32x4_t v[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s[q] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-        const float* src = ws + ((int64_t)tile * 8 + wave) * 8192 + ((a * 2 + b) * 4) * 256 + lane * 4;
-        for (int sp = 0; sp < split_k; ++sp) {
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                s[q] += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + q * 256));
-            src += (int64_t)ntiles * 8 * 8192;
-        }
-        __syncthreads();                     // (one wave: orders the LDS reads of the previous block before these writes)
+                v[u][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + u * step + q * 256));
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) blk[(8 * q + 4 * h + j) * 33 + c] = s[q][j];      // row = frag_row(4 q + j, lane)
-        __syncthreads();
-        const int64_t row0 = (int64_t)tile_i * 256 + wm * 128 + a * 32;
-        const int col0 = tile_j * 256 + wn * 64 + b * 32 + (lane & 7) * 4;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int r = it * 8 + (lane >> 3);
-            const float* bp = blk + r * 33 + (lane & 7) * 4;
-            f32x4_t* dst = reinterpret_cast<f32x4_t*>(C + (row0 + r) * ldc + col0);
-            f32x4_t v = *dst;
-            v[0] += bp[0]; v[1] += bp[1]; v[2] += bp[2]; v[3] += bp[3];
-            *dst = v;
-        }
+            for (int q = 0; q < 4; ++q) s[q] += v[u][q];
+        src += 4 * step;
     }
+    for (; sp < split_k; ++sp) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + q * 256));
+        src += step;
+    }
+    float* cp = C + ((int64_t)tile_i * 256 + wm * 128 + a * 32) * ldc + tile_j * 256 + wn * 64 + b * 32 + (lane & 31);
+    float old[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) old[r] = cp[(int64_t)frag_row(r, lane) * ldc];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cp[(int64_t)frag_row(r, lane) * ldc] = old[r] + s[r >> 2][r & 3];
 }
 
 // split_k, K slices per split and workgroup count of the 256-tile TN kernel for a shape; false when it does not take the shape
@@ -1548,7 +1548,7 @@ static int launch_tn256(GemmTn256Params& p, int split_k, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_tn256_kernel<T, X3>), dim3(ntiles * split_k), dim3(512), G2_SMEM, stream, p);
     const int rc = check_launch("maest_gemm_tn(256)");
     if (rc != MAEST_OK || p.ws == nullptr) return rc;
-    hipLaunchKernelGGL(tn256_reduce_kernel, dim3(ntiles * 32), dim3(64), 32 * 33 * sizeof(float), stream, (const float*)p.ws, p.C, p.ldc, ntiles, p.tiles_n,
+    hipLaunchKernelGGL(tn256_reduce_kernel, dim3(ntiles * 64), dim3(64), 0, stream, (const float*)p.ws, p.C, p.ldc, ntiles, p.tiles_n,
                        split_k);
     return check_launch("maest_gemm_tn(256, reduce)");
 }

@@ -23,4 +23,4 @@ for K in (74240, 112000):
                     t[v].append(bench(lambda: ops.gemm_tn(a, b, out, colsum=cs, split_k=0)))
         m = lambda v: sorted(v)[1]
         print(f"tokens {K:6d} {name:5s} [{M:4d} x {N:4d}]  atomics {m(t[0]):7.1f} us   workspace + reduce {m(t[1]):7.1f} us  ({(m(t[1])/m(t[0])-1)*100:+5.1f} %)   "
-              f"workspace {ops.gemm_tn_workspace_bytes(dt, M, N, K) / 2**20:.0f} MiB", flush=True)
+              f"workspace {256 * 256 * 4 * 256 // ((M // 256) * (N // 256)) * ((M // 256) * (N // 256)) / 2**20:.0f} MiB at most", flush=True)
