@@ -75,8 +75,11 @@ const char* maest_last_error(void);
 #define MAEST_OPT_GEMM_TAIL 5 /* env MAEST_GEMM_TAIL, default 1: the last partial round of a large NT GEMM runs in 128-row
                                  tiles (a second launch) when at most half a round of 256-row tiles is left over; 0: off;
                                  2: every tile a 128-row tile (tests) */
-#define MAEST_OPT_ATTN_FWD 6 /* env MAEST_ATTN_FWD, default 0: bf16 attention forward with K / V tiles fed by LDS-DMA into unpadded
-                                bank-swizzled tiles; 1: the register-staged, padded-pitch form every other dtype uses */
+#define MAEST_OPT_ATTN_FWD 6 /* env MAEST_ATTN_FWD, default 0: bf16 attention forward by shape -- N > 320 (complete passes): the
+                                persistent one-wave-per-SIMD kernel (attn_fwd_pw.hip: 96 query rows per wave, K / V tiles streamed
+                                by LDS-DMA across work items); otherwise four-wave workgroups with K / V tiles fed by LDS-DMA into
+                                unpadded bank-swizzled tiles; 1: the register-staged, padded-pitch form every other dtype uses;
+                                2: the four-wave LDS-DMA form at every N; 3: the persistent form at every N (tests) */
 #define MAEST_OPT_ATTN_FWD_WAVES 7 /* env MAEST_ATTN_FWD_WAVES, default 0: waves (32-query blocks) per workgroup of the DMA-fed bf16
                                       attention forward chosen by shape; 4 / 5 / 6 / 8 force one (tests, A/B) */
 #define MAEST_OPT_TN_REDUCE 8 /* env MAEST_TN_REDUCE, default 0: split-K partials of the wgrad GEMM are combined with fp32 atomics; 1:

@@ -4,9 +4,15 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+if os.path.dirname(HERE) not in sys.path:
+    sys.path.insert(0, os.path.dirname(HERE))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmaest_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "norm.hip", "attention.hip", "embed.hip", "misc.hip", "mel.hip", "mel2.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "norm.hip", "attention.hip", "attn_fwd_pw.hip", "embed.hip", "misc.hip", "mel.hip", "mel2.hip"]
+
+
+# sources whose inline asm owns fixed registers: {file: (first, last owned arch VGPR)}; all accumulator registers are owned too
+AUDITED = {"attn_fwd_pw.hip": (96, 245)}
 
 
 def _hipcc():
@@ -37,6 +43,8 @@ def build(force=False, verbose=True):
         objs.append(o)
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-Wno-unused-result", "-c", s, "-o", o]
+        if os.path.basename(s) in AUDITED:
+            cmd.insert(-4, "-save-temps=obj")       # keeps the device assembly next to the object for the audit below
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()
@@ -45,6 +53,17 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
         if verbose and out.strip():
             sys.stderr.write(out.decode())
+    # kernels that own registers by hand: the compiler must have stayed out of them (maest_amd/pw_audit.py)
+    from maest_amd import pw_audit
+    for name, (lo, hi) in AUDITED.items():
+        asm = os.path.join(HERE, "build", os.path.splitext(name)[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        bad, maxv, meta = pw_audit.audit(asm, lo, hi)
+        if bad:
+            for n, why, st in bad[:20]:
+                sys.stderr.write(f"{name}: line {n}: {why}: {st}\n")
+            raise RuntimeError(f"{name}: the code object touches registers the kernel owns by hand (or spills)")
+        if verbose:
+            print(f"audit {name}: compiler's highest arch VGPR v{maxv}, owned v{lo}..v{hi} and the accumulator half untouched; {meta}")
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
     if verbose:

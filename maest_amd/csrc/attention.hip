@@ -26,19 +26,9 @@
 // fp32 softmax) and T = float (v_mfma_f32_32x32x2_f32, exact fp32 -- parity mode).
 #include <type_traits>
 
-#include "common.h"
+#include "attn_common.h"
 
 namespace maest {
-
-constexpr int HD = 64;         // head dim
-constexpr int NHEADS = 12;
-constexpr int QKV_LD = 3 * NHEADS * HD;  // 2304
-constexpr int OUT_LD = NHEADS * HD;      // 768
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
-constexpr float NEG_BIG = -1.0e30f;
-// drain this wave's vector-memory queue (LDS-DMA included) without touching the LDS / scalar counters
-#define MAEST_ATTN_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 template <typename T>
 struct AttnCfg {
@@ -154,7 +144,6 @@ __device__ __forceinline__ void mma_rows(f32x16_t& acc, const char* lds, int row
 // gathered from the ROW-MAJOR tile with the row permutation of acc_to_chunk:
 //   bf16: rows 16s + 4h + (0..3) and 16s + 8 + 4h + (0..3)  -> two ds_read_b64_tr_b16
 //   fp32: rows  8s + 4h + (0..3)                            -> four ds_read_b32
-typedef short v4i16a_t __attribute__((ext_vector_type(4)));
 template <typename T>
 __device__ __forceinline__ chunk16 frag_from_rows(const char* tile, int rho0, int s, int dblk, int lane);
 // the same gather from a row-major bf16 tile of ANY row pitch (bytes, multiple of 8)
@@ -225,32 +214,6 @@ __device__ __forceinline__ void store_dT(const f32x16_t (&acc)[2], T* row_ptr, i
                       acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
 }
 
-// The same accumulator pair as 16-byte pieces (bf16): [64 d][32 rows] (lane = row, registers = d: d = 32 db + 8 g + 4 h + j) -> 16-byte
-// pieces of the row -- half the store instructions of store_dT at the same bytes and addresses (a row-per-lane store tail is bound by
-// store ISSUE, not bandwidth: cdna_hip_programming.md T21).  Call it from converged code (the exchange is a wave operation); `ok`
-// predicates the store per lane: the two half-waves exchange one 8-byte quarter so that lane (key, h) owns d = 32 db + 8 (pair + 2 h) .. + 7
-__device__ __forceinline__ void store_32d_rows16(const f32x16_t& acc, bf16_t* row_ptr, int lane, float mul, bool ok) {
-    const int h = lane >> 5;
-    uint32_t pk[4][2];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        pk[g][0] = pack_bf2(acc[4 * g] * mul, acc[4 * g + 1] * mul);
-        pk[g][1] = pack_bf2(acc[4 * g + 2] * mul, acc[4 * g + 3] * mul);
-    }
-#pragma unroll
-    for (int pair = 0; pair < 2; ++pair) {
-        // v_permlane32_swap(vdst, src): lanes 32-63 of vdst <-> lanes 0-31 of src.  vdst = group `pair`, src = group `pair + 2`:
-        // afterwards the lower lane holds [own | upper's] quarter of group `pair`, the upper lane [lower's | own] of `pair + 2`
-        const auto x = __builtin_amdgcn_permlane32_swap(pk[pair][0], pk[pair + 2][0], false, false);
-        const auto y = __builtin_amdgcn_permlane32_swap(pk[pair][1], pk[pair + 2][1], false, false);
-        chunk16 c;
-        c[0] = x[0];
-        c[1] = y[0];
-        c[2] = x[1];
-        c[3] = y[1];
-        if (ok) *reinterpret_cast<chunk16*>(row_ptr + 8 * (pair + 2 * h)) = c;
-    }
-}
 __device__ __forceinline__ void store_dT_rows16(const f32x16_t (&acc)[2], bf16_t* row_ptr, int lane, float mul, bool ok) {
     store_32d_rows16(acc[0], row_ptr, lane, mul, ok);
     store_32d_rows16(acc[1], row_ptr + 32, lane, mul, ok);
@@ -875,25 +838,6 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
 // the transpose reads 2x).  delta = rowsum(dO * O) comes from attn_delta_kernel again (the DMA cannot compute it).
 // DMA'd rows beyond N repeat row N - 1: padded queries carry lse = +BIG (P = 0 exactly), padded keys write dS = 0.
 constexpr int F2_QBUF = 2 * 32 * 128 + 256;       // Q tile | dO tile | lse[32] | delta[32]
-__device__ __forceinline__ int swz128(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
-// One LDS-DMA instruction (global_load_lds_dwordx4: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS address `dst`),
-// issued as inline asm so that hipcc does not know about it: through the builtin the compiler treats the DMA as a
-// store to LDS that may alias every later LDS read and puts `s_waitcnt vmcnt(0)` in front of the next ds_read (here:
-// inside the dQ loop), i.e. it waits for the tile it has just requested.  The waits are placed by hand
-// (MAEST_ATTN_WAIT_VM0 one step later); a hidden DMA can only make the compiler's own counted waits longer, never
-// shorter.  M0 (the DMA's LDS base) is saved and restored inside the statement.  (The host emulator build takes
-// the builtin, which it executes synchronously.)
-__device__ __forceinline__ void dma16(const void* gsrc, char* dst) {
-#if defined(__AMDGCN__)
-    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst);
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
-#else
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-#endif
-}
 // LDS-DMA of 8-row groups [j0, j1) of an unpadded 128-byte-row tile (instruction j = rows 8j .. 8j + 7 = 1 KiB)
 __device__ __forceinline__ void dma_rows128(char* tile, const bf16_t* base, int ld, int row0, int j0, int j1, int jstep,
                                             int nvalid, int lane) {
@@ -1654,11 +1598,16 @@ static int attn_fwd_waves(int N, int q_rows) {
     return 4;                                     // measured best at every production shape (see attn_fwd_dma_kernel)
 }
 
+int attn_fwd_pw_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, hipStream_t st);   // attn_fwd_pw.hip
+
 template <typename T, bool X3 = false>
 static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, int q_rows, hipStream_t st) {
     using C = AttnCfg<T>;
     if constexpr (sizeof(T) == 2 && !X3) {
-        if (option(MAEST_OPT_ATTN_FWD) == 0) {      // K / V tiles by LDS-DMA (unpadded, swizzled)
+        const int afw = option(MAEST_OPT_ATTN_FWD);
+        // the long token rows (10 s inference, 30 s shapes): the persistent one-wave-per-SIMD form; 3 forces it at any N (tests)
+        if (q_rows == N && ((afw == 0 && N > 320) || afw == 3)) return attn_fwd_pw_launch(qkv, out, lse, B, N, scale, st);
+        if (afw == 0 || afw == 2 || afw == 3) {     // K / V tiles by LDS-DMA (unpadded, swizzled); 2 forces this form at any N
             const int nw = attn_fwd_waves(N, q_rows);
             const dim3 g(((N + nw * 32 - 1) / (nw * 32)) * NHEADS * B);
             const int lds = MAEST_FWD_RING * 2 * 64 * 128;

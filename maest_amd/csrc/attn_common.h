@@ -1,0 +1,67 @@
+// Definitions shared by the attention kernels (attention.hip: every numeric mode, forward and backward;
+// attn_fwd_pw.hip: the persistent one-wave-per-SIMD bf16 forward).  Layout contract and MFMA scheme: attention.hip.
+#pragma once
+#include "common.h"
+
+namespace maest {
+
+constexpr int HD = 64;         // head dim
+constexpr int NHEADS = 12;
+constexpr int QKV_LD = 3 * NHEADS * HD;  // 2304
+constexpr int OUT_LD = NHEADS * HD;      // 768
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float NEG_BIG = -1.0e30f;
+// drain this wave's vector-memory queue (LDS-DMA included) without touching the LDS / scalar counters
+#define MAEST_ATTN_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
+
+typedef short v4i16a_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int swz128(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+// One LDS-DMA instruction (global_load_lds_dwordx4: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS address `dst`),
+// issued as inline asm so that hipcc does not know about it: through the builtin the compiler treats the DMA as a
+// store to LDS that may alias every later LDS read and puts `s_waitcnt vmcnt(0)` in front of the next ds_read (here:
+// inside the dQ loop), i.e. it waits for the tile it has just requested.  The waits are placed by hand
+// (MAEST_ATTN_WAIT_VM0 one step later); a hidden DMA can only make the compiler's own counted waits longer, never
+// shorter.  M0 (the DMA's LDS base) is saved and restored inside the statement.  (The host emulator build takes
+// the builtin, which it executes synchronously.)
+__device__ __forceinline__ void dma16(const void* gsrc, char* dst) {
+#if defined(__AMDGCN__)
+    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#endif
+}
+
+// The same accumulator pair as 16-byte pieces (bf16): [64 d][32 rows] (lane = row, registers = d: d = 32 db + 8 g + 4 h + j) -> 16-byte
+// pieces of the row -- half the store instructions of store_dT at the same bytes and addresses (a row-per-lane store tail is bound by
+// store ISSUE, not bandwidth: cdna_hip_programming.md T21).  Call it from converged code (the exchange is a wave operation); `ok`
+// predicates the store per lane: the two half-waves exchange one 8-byte quarter so that lane (key, h) owns d = 32 db + 8 (pair + 2 h) .. + 7
+__device__ __forceinline__ void store_32d_rows16(const f32x16_t& acc, bf16_t* row_ptr, int lane, float mul, bool ok) {
+    const int h = lane >> 5;
+    uint32_t pk[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        pk[g][0] = pack_bf2(acc[4 * g] * mul, acc[4 * g + 1] * mul);
+        pk[g][1] = pack_bf2(acc[4 * g + 2] * mul, acc[4 * g + 3] * mul);
+    }
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) {
+        // v_permlane32_swap(vdst, src): lanes 32-63 of vdst <-> lanes 0-31 of src.  vdst = group `pair`, src = group `pair + 2`:
+        // afterwards the lower lane holds [own | upper's] quarter of group `pair`, the upper lane [lower's | own] of `pair + 2`
+        const auto x = __builtin_amdgcn_permlane32_swap(pk[pair][0], pk[pair + 2][0], false, false);
+        const auto y = __builtin_amdgcn_permlane32_swap(pk[pair][1], pk[pair + 2][1], false, false);
+        chunk16 c;
+        c[0] = x[0];
+        c[1] = y[0];
+        c[2] = x[1];
+        c[3] = y[1];
+        if (ok) *reinterpret_cast<chunk16*>(row_ptr + 8 * (pair + 2 * h)) = c;
+    }
+}
+
+}  // namespace maest

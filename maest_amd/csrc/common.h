@@ -187,6 +187,14 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
     return v;
 }
+// true on every lane when the predicate holds on any lane of the wave (one v_cmp into an SGPR pair; the branch on it is wave-uniform)
+__device__ __forceinline__ bool wave_any(bool p) {
+#if defined(__AMDGCN__)
+    return __builtin_amdgcn_ballot_w64(p) != 0;
+#else
+    return wave_max(p ? 1.0f : 0.0f) > 0.0f;       // host emulator (tests/emu)
+#endif
+}
 
 // GELU value and derivative together (one erf, one exp).  EXACT = true: libm erff (fp32 parity mode);
 // EXACT = false: Abramowitz-Stegun 7.1.26 erf (|err| <= 1.5e-7, far below bf16 resolution; bf16 perf mode).

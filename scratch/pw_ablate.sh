@@ -1,0 +1,22 @@
+#!/bin/bash
+# attn_fwd_pw_kernel timing variants: every argument is "name" or "name:-DFLAG=.. -DFLAG2=.." ; a bare number is PW_ABLATE bits
+# (attn_fwd_pw.hip; results wrong on purpose).  Builds scratch/pw_abl/libmaest_<name>.so locally; scratch/pw_ablate_run.py times
+# them on the GPU box.
+set -e
+cd "$(dirname "$0")/.."
+python maest_amd/build.py >/dev/null
+rm -rf scratch/pw_abl; mkdir -p scratch/pw_abl
+for a in "$@"; do
+  name=${a%%:*}; flags=""; [[ "$a" == *:* ]] && flags=${a#*:}
+  [[ "$name" =~ ^[0-9]+$ ]] && flags="$flags -DPW_ABLATE=$name"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $flags \
+      -c maest_amd/csrc/attn_fwd_pw.hip -o scratch/pw_abl/pw_$name.o &
+done
+wait
+for a in "$@"; do
+  name=${a%%:*}
+  objs=$(ls maest_amd/build/*.o | grep -v attn_fwd_pw)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/pw_abl/libmaest_$name.so $objs scratch/pw_abl/pw_$name.o
+  rm scratch/pw_abl/pw_$name.o
+done
+ls scratch/pw_abl | tr '\n' ' '

@@ -93,6 +93,21 @@ def test_emu_attention_multi_tile_spike(emu):
     KC.case_attention(emu, torch.float32, 1, 100, spike=True)
 
 
+def test_emu_attention_persistent_forward(emu):
+    """attn_fwd_pw_kernel's host twin (the C++ form of every owned-register primitive): 3 key tiles with both fragment-set parities, a
+    ragged last tile, the rescale path (spike) -- one item; the multi-item walk is a GPU test."""
+    from maest_amd import ops
+    import tests.kernel_cases as K
+    qkv = K.rnd((130, 2304), 20, 1.0)
+    qkv[70, 768:768 + 64] = qkv[3, 0:64] * 6.0
+    qkv = qkv.to(torch.bfloat16)
+    with ops.options(attn_fwd=3):
+        out, lse = ops.attn_fwd(qkv, 1, 130, 0.125, save_lse=True)
+    ref, ref_lse = K._attn_ref(qkv.float(), 1, 130, 0.125)
+    K.close(out, ref, 2e-2, 2e-2, "persistent attention forward (emulated)")
+    K.close(lse, ref_lse, 1e-4, 2e-2, "persistent attention forward lse (emulated)")
+
+
 def test_emu_split_bf16_products(emu):
     """precision="bf16x3": fp32 tensors, three bf16 MFMAs per product on hi/lo operand splits (GEMM + attention fwd)."""
     KC.case_split_precision(emu, M=512, N=256, K=192, B=1, Ntok=40)
