@@ -51,15 +51,18 @@ constexpr int PW_Q0 = 2 * PW_RING * PW_TILE;  // swizzled like a K tile): 72 KiB
 constexpr int PW_LDS = PW_Q0 + PW_ROWS * 128;
 constexpr float PW_HOT = 4096.0f;             // a tile's (half-)row sum above this sends the wave to the rescale path
 constexpr float PW_COLD = 1.0e-30f;           // ... and, on an item's first tile (scores taken against m = 0), one below this
-#ifndef PW_PKADD
-#define PW_PKADD 0        // row-sum pair by one v_pk_add_f32 (1) or two v_add_f32 (0): measured 351 against 335 us (B = 256, N = 560)
+#ifndef PW_SUM
+#define PW_SUM 0          // row sums: 0 = two v_add_f32 per slice, 1 = one v_dot2c_f32_bf16 on the packed word (timing variants)
+#endif
+#ifndef PW_CHAIN
+#define PW_CHAIN 0        // MFMA order inside a group: 0 = the two accumulators alternate, 1 = one accumulator's four MFMAs back to back
 #endif
 #ifndef PW_DMAPOS
 #define PW_DMAPOS 0       // where a tile's eight LDS-DMA requests ride (timing variants)
 #endif
 #ifndef PW_ABLATE
 #define PW_ABLATE 0       // timing experiments only (scratch/pw_ablate.sh; results wrong on purpose): bit 0 no LDS-DMA requests, 1 no
-#endif                    // barrier / vmcnt wait, 2 no softmax slices, 3 no MFMAs, 4 no fragment reads, 5 no stores, 6 no Q take
+#endif                    // barrier / vmcnt wait, 2 no softmax slices, 3 no MFMAs, 4 no fragment reads, 5 no stores, 6 no Q take, 8 v_mov for v_exp
 
 // register map (device build)
 constexpr int PW_A_O = 0;                     // O^T[i][db]       16 registers each: a0   .. a95
@@ -84,6 +87,11 @@ struct PwCtx {
     uint32_t kaddr[4];           // LDS byte addresses (ring slot included) of this lane's K row chunks
     uint32_t vaddr[2][2];        // ... of its transpose-read pieces: [d block][row / row + 8]
     int kslot, vslot;            // ring slot those addresses point into (wave-uniform)
+#ifdef PW_PROF
+    unsigned long long* pp;      // (timing build: stamp buffer in LDS, next index, this workgroup is the profiled one, lane)
+    int pidx, plane;
+    bool pon;
+#endif
 #if !PW_DEV
     f32x16_t o[PW_QB][2];        // (host emulator: the state the device keeps in owned registers)
     chunk16 qf[PW_QB][4];
@@ -102,9 +110,15 @@ struct PwCtx {
 // the kernel's own 72 KiB (no vector-memory operation: the counted vmcnt waits stay exact) and copied out at the end.
 #ifdef PW_PROF
 __device__ unsigned long long* g_pw_prof = nullptr;
-#define PW_STAMP() do { if (pon && pidx < 512) { if (lane == 0) pp[pidx] = __builtin_amdgcn_s_memtime(); ++pidx; } } while (0)
+#define PW_STAMP() do { if (c.pon && c.pidx < 512) { if (c.plane == 0) c.pp[c.pidx] = __builtin_amdgcn_s_memtime(); ++c.pidx; } } while (0)
+#ifdef PW_PROF_SLOTS
+#define PW_STAMP_SLOT() PW_STAMP()
+#else
+#define PW_STAMP_SLOT() ((void)0)
+#endif
 #else
 #define PW_STAMP() ((void)0)
+#define PW_STAMP_SLOT() ((void)0)
 #endif
 
 // One LDS-DMA piece (1 KiB): lane l's 16 bytes come from (char*)sbase + voff + IMM (sbase wave-uniform, in SGPRs) and land at
@@ -314,7 +328,7 @@ __device__ __forceinline__ void pw_read_v(PwCtx& c) { pw_read_v_all(c, std::make
 // pipeline region away in program order; the nops make that a guarantee).
 template <int I, int BUF, int SET, int K, bool TILE0>
 __device__ __forceinline__ void pw_s_mfma(PwCtx& c) {
-    constexpr int KB = K & 1, J = K >> 1;
+    constexpr int KB = PW_CHAIN ? K >> 2 : K & 1, J = PW_CHAIN ? K & 3 : K >> 1;
 #if PW_DEV
     if (PW_ABLATE & 8) return;
     constexpr int KF = (SET ? PW_A_K2 : PW_A_K) + (4 * KB + J) * 4, Q = PW_A_Q + (4 * I + J) * 4, S = PW_V_S + (2 * BUF + KB) * 16, NM = PW_V_NM + 16 * I;
@@ -350,13 +364,14 @@ __device__ __forceinline__ void pw_s_mfma(PwCtx& c) {
 // K & 1) into the O registers, B = a chunk of P buffer BUF.  TILE0: the first two take C = 0 (O[I] needs no clearing).
 template <int I, int BUF, int K, bool TILE0>
 __device__ __forceinline__ void pw_pv_mfma(PwCtx& c) {
-    constexpr int KB = K >> 2, S2 = (K >> 1) & 1, DB = K & 1;
+    constexpr int KB = PW_CHAIN ? (K >> 1) & 1 : K >> 2, S2 = PW_CHAIN ? K & 1 : (K >> 1) & 1, DB = PW_CHAIN ? K >> 2 : K & 1;
+    constexpr bool FIRSTOF = KB == 0 && S2 == 0;       // this accumulator's first MFMA of the group
 #if PW_DEV
     if (PW_ABLATE & 8) return;
     constexpr int O = PW_A_O + (2 * I + DB) * 16, V = PW_A_V + ((2 * KB + DB) * 2 + S2) * 4, P = PW_V_PK + ((2 * BUF + KB) * 2 + S2) * 4;
-    if constexpr (TILE0 && K == 0)
+    if constexpr (TILE0 && FIRSTOF && K == 0)
         asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], 0" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
-    else if constexpr (TILE0 && K == 1)
+    else if constexpr (TILE0 && FIRSTOF)
         asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], 0" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
     else if constexpr (K == 0)
         asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
@@ -364,7 +379,7 @@ __device__ __forceinline__ void pw_pv_mfma(PwCtx& c) {
         asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
 #else
     f32x16_t cin = c.o[I][DB];
-    if (TILE0 && K < 2) {
+    if (TILE0 && FIRSTOF) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) cin[r] = 0.0f;
     }
@@ -392,7 +407,8 @@ __device__ __forceinline__ void pw_pv_products(PwCtx& c) { pw_pv_all<I, BUF, TIL
 // ones: one instruction per slice instead of two adds.
 __device__ __forceinline__ void pw_sum_begin(PwCtx& c) {
 #if PW_DEV
-    asm volatile("v_mov_b32 v%c0, 0\n\tv_mov_b32 v%c1, 0x3f803f80" : : "i"(PW_V_T + 2), "i"(PW_V_T + 3));
+    if constexpr (PW_SUM == 1) asm volatile("v_mov_b32 v%c0, 0\n\tv_mov_b32 v%c1, 0x3f803f80" : : "i"(PW_V_T + 2), "i"(PW_V_T + 3));
+    else asm volatile("v_mov_b32 v%c0, 0\n\tv_mov_b32 v%c1, 0" : : "i"(PW_V_T + 2), "i"(PW_V_T + 3));
 #else
     c.a0 = 0.0f;
 #endif
@@ -400,7 +416,8 @@ __device__ __forceinline__ void pw_sum_begin(PwCtx& c) {
 __device__ __forceinline__ float pw_sum_end(PwCtx& c) {
 #if PW_DEV
     float r;
-    asm volatile("s_nop 2\n\tv_mov_b32 %0, v%c1" : "=v"(r) : "i"(PW_V_T + 2));     // (a dot result read by another VALU: 3 wait states)
+    if constexpr (PW_SUM == 1) asm volatile("s_nop 2\n\tv_mov_b32 %0, v%c1" : "=v"(r) : "i"(PW_V_T + 2));     // (a dot result read by another VALU: 3 wait states)
+    else asm volatile("v_add_f32 %0, v%c1, v%c2" : "=v"(r) : "i"(PW_V_T + 2), "i"(PW_V_T + 3));
     return r;
 #else
     return c.a0;
@@ -421,7 +438,8 @@ __device__ __forceinline__ void pw_sm_exp(PwCtx& c, int klim, float d) {
         asm volatile("v_sub_f32 v%c1, v%c3, %0\n\tv_sub_f32 v%c2, v%c4, %0\n\tv_exp_f32 v%c1, v%c1\n\tv_exp_f32 v%c2, v%c2"
                      : : "v"(d), "i"(T0), "i"(T0 + 1), "i"(S), "i"(S + 1));
     else
-        asm volatile("v_exp_f32 v%c0, v%c2\n\tv_exp_f32 v%c1, v%c3" : : "i"(T0), "i"(T0 + 1), "i"(S), "i"(S + 1));
+        if constexpr ((PW_ABLATE & 256) != 0) asm volatile("v_mov_b32 v%c0, v%c2\n\tv_mov_b32 v%c1, v%c3" : : "i"(T0), "i"(T0 + 1), "i"(S), "i"(S + 1));
+        else asm volatile("v_exp_f32 v%c0, v%c2\n\tv_exp_f32 v%c1, v%c3" : : "i"(T0), "i"(T0 + 1), "i"(S), "i"(S + 1));
 #else
     if (MASK) {
         if (KB * 32 + (R & 3) + 8 * (R >> 2) >= klim) c.s[BUF][KB][R] = NEG_BIG;
@@ -435,14 +453,18 @@ template <int BUF, int K>
 __device__ __forceinline__ void pw_sm_fin(PwCtx& c) {
     constexpr int KB = K >> 3, R = 2 * (K & 7);
 #if PW_DEV
-    if (PW_ABLATE & 4) return;
+    if (PW_ABLATE & (4 | 512)) return;
     constexpr int P = PW_V_PK + ((2 * BUF + KB) * 2 + (R >> 3)) * 4 + ((R & 7) >> 1), T0 = PW_V_T + 4 * (K & 1), A0 = PW_V_T + 2;
-    asm volatile("v_cvt_pk_bf16_f32 v%c4, v%c0, v%c1\n\tv_dot2c_f32_bf16 v%c2, v%c4, v%c3"
-                 : : "i"(T0), "i"(T0 + 1), "i"(A0), "i"(A0 + 1), "i"(P));
+    if constexpr (PW_SUM == 1)
+        asm volatile("v_cvt_pk_bf16_f32 v%c4, v%c0, v%c1\n\tv_dot2c_f32_bf16 v%c2, v%c4, v%c3"
+                     : : "i"(T0), "i"(T0 + 1), "i"(A0), "i"(A0 + 1), "i"(P));
+    else
+        asm volatile("v_add_f32 v%c2, v%c2, v%c0\n\tv_add_f32 v%c3, v%c3, v%c1\n\tv_cvt_pk_bf16_f32 v%c4, v%c0, v%c1"
+                     : : "i"(T0), "i"(T0 + 1), "i"(A0), "i"(A0 + 1), "i"(P));
 #else
     const uint32_t w = pack_bf2(c.t[K & 1][0], c.t[K & 1][1]);
     c.pk[BUF][KB][R >> 3][(R & 7) >> 1] = w;
-    c.a0 += u2f(w << 16) + u2f(w & 0xffff0000u);
+    c.a0 += PW_SUM == 1 ? u2f(w << 16) + u2f(w & 0xffff0000u) : c.t[K & 1][0] + c.t[K & 1][1];
 #endif
 }
 // a whole unit, outside the pipeline (the rescale path): exp(0) | exp(1) fin(0) | ... | fin(15)
@@ -531,6 +553,7 @@ __device__ __forceinline__ void pw_slot(PwCtx& c, int klim, const PwDma& dm, cha
         if constexpr (I == 2 && K < 8 && (K & 1)) pw_dma_piece<2 + K / 4, (K / 2) & 1>(dm, smem, wave);
     }
     if constexpr (K > 0) pw_sm_fin<BUF, (K > 0 ? K - 1 : 0)>(c);
+    if constexpr (PAR == 1) PW_STAMP_SLOT();
 }
 // T0: the item's first key tile: the scores were taken against m = 0 (C = 0), so the row sum is checked on both sides, and the
 // rescale path SETS the maximum (O[I] and l[I] are still untouched: nothing to bring along).
@@ -571,12 +594,13 @@ __global__ __launch_bounds__(PW_NW * 64, 1) void attn_fwd_pw_kernel(const bf16_t
     const int first = xcd * per + slot0;
     if (first >= lim) return;
 
-#ifdef PW_PROF
-    unsigned long long* pp = reinterpret_cast<unsigned long long*>(smem + PW_LDS) + wave * 512;
-    int pidx = 0;
-    const bool pon = blockIdx.x == 5 && g_pw_prof != nullptr;
-#endif
     PwCtx c;
+#ifdef PW_PROF
+    c.pp = reinterpret_cast<unsigned long long*>(smem + PW_LDS) + wave * 512;
+    c.pidx = 0;
+    c.plane = lane;
+    c.pon = blockIdx.x == 5 && g_pw_prof != nullptr;
+#endif
     {
 #if PW_DEV
         const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -785,9 +809,14 @@ __global__ __launch_bounds__(PW_NW * 64, 1) void attn_fwd_pw_kernel(const bf16_t
         PW_STAMP();
     }
 #ifdef PW_PROF
-    if (pon) {
+    if (g_pw_prof != nullptr && blockIdx.x < 64 && tid == 0) {       // where the dispatcher put this workgroup
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_pw_prof[1024 + blockIdx.x] = xcc;
+    }
+    if (c.pon) {
         __syncthreads();
-        for (int i = lane; i < 512; i += 64) g_pw_prof[wave * 512 + i] = i < pidx ? pp[i] : 0ull;
+        for (int i = lane; i < 512; i += 64) g_pw_prof[wave * 512 + i] = i < c.pidx ? c.pp[i] : 0ull;
     }
 #endif
 }

@@ -7,7 +7,7 @@ lib = ctypes.CDLL("scratch/pw_abl/libmaest_%s.so" % (sys.argv[3] if len(sys.argv
 _lib._lib = _lib._bind(lib)
 B, N = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 560)
 qkv = torch.randn(B * N, 2304, device="cuda").to(torch.bfloat16)
-buf = torch.zeros(2 * 512, dtype=torch.int64, device="cuda")
+buf = torch.zeros(2 * 512 + 64, dtype=torch.int64, device="cuda")
 with ops.options(attn_fwd=3):
     for _ in range(3): ops.attn_fwd(qkv, B, N, 0.125)
     torch.cuda.synchronize()
@@ -16,7 +16,7 @@ with ops.options(attn_fwd=3):
     ops.attn_fwd(qkv, B, N, 0.125)
     torch.cuda.synchronize()
     lib.maest_debug_pw_prof(None)
-t = buf.cpu().reshape(2, 512)
+print("XCC_ID register of workgroups 0..63:", [int(x) & 0xf for x in buf.cpu()[1024:]]); t = buf.cpu()[:1024].reshape(2, 512)
 T = (N + 63) // 64
 per_item = 2 + 4 * T + 4          # stamps per item: start, prologue, 4 per tile, drain/wait/take/store
 for w in range(2):
