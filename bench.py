@@ -275,6 +275,36 @@ def build_case(args, dev, rank, world, mode, T, B, patchout, reducer_kw=None):
                 Tk=Tk, N=2 + 9 * Tk)
 
 
+def check_ranks(net, world, dev):
+    """--check-ranks: every rank's weights as (sum, sum of squares, xor of the bit patterns) gathered on all ranks and
+    compared exactly -- data-parallel replicas that saw the same averaged gradients hold bit-identical weights --, and the
+    bucket all-reduces the last step launched."""
+    import torch.distributed as dist
+    flat = torch.cat([p.detach().reshape(-1).float() for p in net.parameters()])
+    bits = flat.view(torch.int32)
+    x = bits[0].clone()
+    # xor-fold of all bit patterns (exact, order-independent)
+    n = 1 << (bits.numel() - 1).bit_length()
+    pad = torch.zeros(n, dtype=torch.int32, device=dev)
+    pad[:bits.numel()] = bits
+    while pad.numel() > 1:
+        half = pad.numel() // 2
+        pad = pad[:half] ^ pad[half:]
+    sig = torch.stack([flat.double().sum(), (flat.double() ** 2).sum(), pad[0].double()])
+    red = getattr(net, "_grad_sink", None)
+    res = {"buckets": None if red is None else len(red.buckets),
+           "all_reduces_last_step": None if red is None else int(red.reduced_this_step)}
+    if world > 1:
+        sigs = [torch.zeros_like(sig) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        res["weights_identical_across_ranks"] = bool(all(torch.equal(s, sigs[0]) for s in sigs))
+        res["ranks_compared"] = world
+    else:
+        res["weights_identical_across_ranks"] = True
+        res["ranks_compared"] = 1
+    return res
+
+
 def timed_steps(step, steps, warmup, world, dev):
     """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks."""
     import torch.distributed as dist
@@ -432,15 +462,24 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: create the one-rank RCCL communicator and push every gradient bucket through its "
                          "all-reduce anyway (the data-parallel exchange path on a single GPU)")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="debug / test switch: every rank of a --gpus N job runs on device 0 and gloo carries the device tensors of "
+                         "the gradient exchange -- the whole N-rank launch, bootstrap, bucket and timing path on a one-GPU box "
+                         "(tests/test_model_gpu.py); the clips/s of such a run measure nothing")
+    ap.add_argument("--check-ranks", action="store_true",
+                    help="after the timed steps: compare the weights of all ranks (they must be bit-identical) and report the "
+                         "bucket all-reduces launched per step as `dp_check` on the line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
 
     from maest_amd.dist import init_from_env
 
-    rank, local, world = init_from_env(force=args.force_collective)
+    rank, local, world = init_from_env(backend="gloo" if args.ranks_share_gpu else None, force=args.force_collective)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.ranks_share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -470,6 +509,10 @@ def main():
     timer = None
     if not args.no_kernel_timing and world == 1:
         timer = kernel_pass(case, args.steps)
+
+    dp_check = None
+    if args.check_ranks:
+        dp_check = check_ranks(net, world, dev)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -506,6 +549,10 @@ def main():
             "model_mfma_frac": round((step_flops - skipped) / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "executed_flop_fraction": round(1.0 - skipped / step_flops, 4),
         }
+        if dp_check is not None:
+            out["dp_check"] = dp_check
+        if args.ranks_share_gpu:
+            out["config"]["parallelism"] += " -- ALL RANKS ON ONE GPU over gloo (--ranks-share-gpu: a path test, not a measurement)"
         if complete is not None:
             out["complete_last_block"] = {"value": round(B * args.steps / complete, 2), "unit": "clips/s",
                                           "ms_per_step": round(complete / args.steps * 1e3, 3),

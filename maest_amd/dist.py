@@ -81,6 +81,7 @@ class GradReducer:
         cur["end"] = off
         self.buckets.append(cur)
         self._pending = [0] * len(self.buckets)
+        self.reduced_this_step = 0
         self._works = []
         self.reset()
 
@@ -89,6 +90,7 @@ class GradReducer:
         self.flat.zero_()
         self._pending = [len(b["names"]) for b in self.buckets]
         self._works = []
+        self.reduced_this_step = 0          # bucket all-reduces launched since this reset (bench.py --check-ranks, tests)
 
     def grad_buffer(self, name) -> Optional[torch.Tensor]:
         """Destination the engine should write `name`'s gradient into (a view of the flat buffer)."""
@@ -110,6 +112,7 @@ class GradReducer:
         bk = self.buckets[b]
         w = dist.all_reduce(self.flat[bk["start"]:bk["end"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._works.append(w)
+        self.reduced_this_step += 1
 
     def on_grad(self, name):
         """note_grad + reduce_bucket on the current stream (callers with a single stream: the host-logic tests)."""

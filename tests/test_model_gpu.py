@@ -797,6 +797,46 @@ def test_data_parallel_rccl_one_rank_forced_collective():
     assert "weights and gradients identical" in r.stdout
 
 
+def _bench_line(extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    r = subprocess.run([sys.executable, bench, "--steps", "3", "--warmup", "1", "--batch", "16", "--no-cpu-baseline",
+                        "--no-kernel-timing", "--no-side-cases", "--check-ranks"] + extra,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert lines, r.stderr[-2000:]
+    out = json.loads(lines[-1])                      # the JSON line is the LAST thing on stdout ...
+    assert sum(1 for ln in lines if ln.lstrip().startswith('{"metric"')) == 1, "... and only rank 0 prints one"
+    return out
+
+
+def test_bench_gpus_8_self_launch_on_one_gpu():
+    """`python bench.py --gpus 8` exactly as the driver calls it (no launcher: bench.py re-executes itself under
+    torch.distributed.run with 8 ranks, 127.0.0.1 rendezvous), with the one debug switch that a one-GPU box needs: every rank on
+    device 0, gloo carrying the device tensors (--ranks-share-gpu).  The whole N-rank path runs: bootstrap from the torchrun
+    environment, weight broadcast, per-rank data, the five gradient buckets all-reduced in every step from the communication
+    stream, barriers + max-over-ranks timing, rank 0's JSON line.  Replicas must end with bit-identical weights."""
+    out = _bench_line(["--gpus", "8", "--ranks-share-gpu"], timeout=1500)
+    assert out["n_gpus"] == 8 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["per_gpu_batch"] == 16 and out["config"]["global_batch"] == 8 * 16
+    assert out["config"]["parallelism"].startswith("dp8")
+    chk = out["dp_check"]
+    assert chk["ranks_compared"] == 8 and chk["weights_identical_across_ranks"] is True
+    assert chk["buckets"] == 5 and chk["all_reduces_last_step"] == 5
+    assert out["value"] > 0 and abs(out["value"] - 8 * 16 * 3 / (out["ms_per_step"] * 3e-3)) < 0.01 * out["value"]
+
+
+def test_bench_one_rank_rccl_forced_collective_line():
+    """The same bench path at --gpus 1 with the one-rank RCCL communicator (backend nccl through init_from_env, every bucket
+    pushed through librccl's all-reduce): the nccl branch of the bootstrap and the bench share one code path."""
+    out = _bench_line(["--gpus", "1", "--force-collective"])
+    assert out["n_gpus"] == 1 and "one-rank communicator, forced" in out["config"]["parallelism"]
+    assert out["dp_check"]["buckets"] == 5 and out["dp_check"]["all_reduces_last_step"] == 5
+
+
 def test_validation_loop_matches_the_oracle_and_scikit_learn():
     """The evaluation side of the Lightning module (models/module.py:104-212): predict_step, validation_step for the
     live and the SWA net, epoch-end macro AP / ROC-AUC -- losses and scores against the oracle forward (fp32, 1e-3 /
