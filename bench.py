@@ -272,7 +272,32 @@ def build_case(args, dev, rank, world, mode, T, B, patchout, reducer_kw=None):
     Tp = (T - 16) // 10 + 1
     Tk = Tp - patchout
     return dict(net=net, step=step, mode=mode, ts=ts, train=train, T=T, B=B, patchout=patchout, C=C, arch=arch,
-                Tk=Tk, N=2 + 9 * Tk)
+                Tk=Tk, N=2 + 9 * Tk, x=x)
+
+
+def deviation_vs_fp32(case, precision, clips=4):
+    """How far the timed numeric mode is from the exact-fp32 mode of the SAME weights on clips of the SAME batch: relative
+    error of the logits (max |a - b| / max |b|), one forward each under no_grad, with the patchout draw of a training
+    configuration pinned so that both forwards see the same tokens.  (The reference computes in fp32 on the CPU; the fp32
+    mode matches it to ~1e-6, tests/test_model_gpu.py G1 -- no oracle in this path.)"""
+    net, x = case["net"], case["x"][:clips]
+    po = None
+    if case["train"] and case["patchout"] > 0:
+        Tp = (case["T"] - 16) // 10 + 1
+        keep = torch.sort(torch.randperm(Tp, generator=torch.Generator().manual_seed(11))[:Tp - case["patchout"]]).values
+        po = (0, keep)
+    prev = net.precision
+    try:
+        with torch.no_grad():
+            net.precision = precision
+            a = net(x.clone(), _patchout=po)[0].float()
+            net.precision = "fp32"
+            b = net(x.clone(), _patchout=po)[0].float()
+    finally:
+        net.precision = prev
+    torch.cuda.synchronize()
+    return {"logits_rel_err": float(((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()), "clips": int(x.shape[0]),
+            "against": "precision=\"fp32\" (exact fp32 MFMAs) of the same weights on the same clips, same tokens"}
 
 
 def check_ranks(net, world, dev):
@@ -415,9 +440,11 @@ def kernel_report(case, timer, steps, precision, with_traffic, live_traffic=None
     return out
 
 
-def side_case(args, dev, mode, T, B, patchout, steps, warmup, workload):
+def side_case(args, dev, mode, T, B, patchout, steps, warmup, workload, precision=None):
     """A further BASELINE configuration measured on the same line (N = 1 only): its own K timed steps between two
     synchronizes, then its own serialized kernel pass."""
+    if precision is not None:
+        args = argparse.Namespace(**{**vars(args), "precision": precision})
     case = build_case(args, dev, 0, 1, mode, T, B, patchout)
     elapsed = timed_steps(case["step"], steps, warmup, 1, dev)
     step_flops, skipped, _, _ = flop_counts(case, args.precision)
@@ -429,6 +456,11 @@ def side_case(args, dev, mode, T, B, patchout, steps, warmup, workload):
            "executed_flop_fraction": round(1.0 - skipped / step_flops, 4)}
     if not args.no_kernel_timing:
         out.update(kernel_report(case, kernel_pass(case, steps), steps, args.precision, with_traffic=False))
+    if args.precision != "fp32":
+        try:
+            out["deviation_vs_fp32"] = deviation_vs_fp32(case, args.precision)
+        except Exception as e:  # pragma: no cover
+            out["deviation_vs_fp32"] = {"error": repr(e)}
     del case
     torch.cuda.empty_cache()
     return out
@@ -452,7 +484,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=None, help="clips per oracle step of the CPU baseline (SURVEY 8d: B = 8)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-side-cases", action="store_true",
-                    help="skip the `infer` (configs[1]) and `train30s` (configs[3] per-GPU shape) sub-objects of the default line")
+                    help="skip the `infer` / `infer_parity` (configs[1]), `train30s` (configs[3] per-GPU shape) and `ts` (configs[4]) "
+                         "sub-objects of the default line")
     ap.add_argument("--complete-last-block", action="store_true",
                     help="evaluate the last block on every token (A/B reference for the head-token restriction)")
     ap.add_argument("--serial-kernels", action="store_true",
@@ -574,6 +607,11 @@ def main():
                 out["mel"] = time_mel_kernel(dev, B, (T - 1) * 256)
             except Exception as e:  # pragma: no cover
                 out["mel"] = {"error": repr(e)}
+        if world == 1 and args.precision != "fp32":
+            try:
+                out["deviation_vs_fp32"] = deviation_vs_fp32(case, args.precision)
+            except Exception as e:  # pragma: no cover
+                out["deviation_vs_fp32"] = {"error": repr(e)}
         # ---- the other single-GPU BASELINE configurations, driver-visible on the same line (default run only)
         default_line = (world == 1 and args.mode == "train" and args.frames is None and args.batch is None
                         and args.patchout is None and not args.hip_graph and not args.no_side_cases
@@ -589,7 +627,21 @@ def main():
             except Exception as e:  # pragma: no cover
                 out["infer"] = {"error": repr(e)}
             try:
-                out["train30s"] = side_case(args, dev, "train", 1876, 128, 90, max(3, min(args.steps, 5)), 2,
+                out["infer_parity"] = side_case(args, dev, "infer", 626, 256, 0, 10, 2,
+                                                "configs[1] in the mode that meets north_star's 1e-3 logits gate: precision "
+                                                "\"bf16x3\" (fp32 tensors, three bf16 MFMAs per product; what a plain "
+                                                "model.eval()(x) takes by default)", precision="bf16x3")
+            except Exception as e:  # pragma: no cover
+                out["infer_parity"] = {"error": repr(e)}
+            try:
+                out["ts"] = side_case(args, dev, "ts", 1876, 128, 90, 10, 2,
+                                      "discogs-maest-30s-pw-73e-ts teacher-student training step (BASELINE configs[4], per-GPU "
+                                      "shape): batch 128 x 30 s waveforms -> HIP log-mel on the fly -> mixup -> fwd (519-way "
+                                      "separated heads) -> (BCE + BCE)/2 -> bwd -> AdamW")
+            except Exception as e:  # pragma: no cover
+                out["ts"] = {"error": repr(e)}
+            try:
+                out["train30s"] = side_case(args, dev, "train", 1876, 128, 90, 10, 2,
                                             "maest_30s_from_passt_pretrain-shaped training step (BASELINE configs[3], the "
                                             "per-GPU shape of global batch 1024 over 8 GPUs): batch 128 x (96 x 1876), "
                                             "s_patchout_t 90, N = 875 tokens")
