@@ -250,10 +250,10 @@ def build_case(args, dev, rank, world, mode, T, B, patchout, reducer_kw=None):
             net._grad_sink = reducer
         batch = (x, None, y, y_teacher) if ts else (x, None, y)
 
-        def step():
+        def step(xin=None):
             if reducer is not None:
                 reducer.reset()
-            loss = mod.training_step(batch, 0)
+            loss = mod.training_step(batch if xin is None else (xin,) + tuple(batch[1:]), 0)
             loss.backward()
             if reducer is not None:
                 reducer.finish()
@@ -440,6 +440,88 @@ def kernel_report(case, timer, steps, precision, with_traffic, live_traffic=None
     return out
 
 
+def loader_case(args, dev, steps=10, B=256):
+    """SURVEY 8f row 1 on the line: the on-disk mel reader (raw float16 [frames, 96] files, random offsets, one pinned staging
+    buffer + one H2D copy + melfile_assemble_kernel: maest_amd/melfile.py; reference: discogs/dataset.py:69-140 + the norm of
+    discogs/datamodule.py:126-152, 16 host workers per GPU there) feeding the configs[2] training step: B files of 60 s
+    (3750 frames) on tmpfs, 625-frame clips.  Timed alone, and double-buffered -- a producer thread assembling batch i + 1 on
+    a second stream while the step consumes batch i."""
+    import queue
+    import shutil
+    import tempfile
+    import threading
+    from maest_amd.melfile import MelFileReader
+    root = tempfile.mkdtemp(prefix="maest_loader_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        rng = np.random.Generator(np.random.PCG64(99))
+        names = []
+        for i in range(B):
+            (rng.standard_normal((3750, 96), dtype=np.float32) * 0.4 + 2.0).astype(np.float16).tofile(os.path.join(root, f"{i}.mmap"))
+            names.append(f"{i}.mmap")
+        reader = MelFileReader(root, clip_length=10)
+        case = build_case(args, dev, 0, 1, "train", 625, B, 30)
+        step = case["step"]
+        for _ in range(2):
+            reader.load_batch(names, dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            xb = reader.load_batch(names, dev)
+        torch.cuda.synchronize()
+        t_load = (time.perf_counter() - t0) / 5
+        t_res = timed_steps(step, steps, 2, 1, dev) / steps                   # the step on a resident batch
+        side = torch.cuda.Stream(device=dev)
+        q = queue.Queue(maxsize=2)
+        stop = threading.Event()
+
+        def produce():
+            torch.cuda.set_device(dev)
+            while not stop.is_set():
+                with torch.cuda.stream(side):
+                    xb = reader.load_batch(names, dev)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                while not stop.is_set():
+                    try:
+                        q.put((xb, ev), timeout=0.05)
+                        break
+                    except queue.Full:
+                        pass
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+
+        def fed_step():
+            xb, ev = q.get()
+            torch.cuda.current_stream().wait_event(ev)
+            xb.record_stream(torch.cuda.current_stream())
+            return step(xb)
+
+        for _ in range(2):
+            fed_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fed_step()
+        torch.cuda.synchronize()
+        t_fed = (time.perf_counter() - t0) / steps
+        stop.set()
+        th.join(timeout=5)
+        hidden = max(0.0, min(1.0, 1.0 - (t_fed - t_res) / t_load))
+        return {"what": "MelFileReader.load_batch (B float16 files on tmpfs -> pinned staging -> H2D -> melfile_assemble_kernel) "
+                        "alone, and double-buffered on a second stream against the configs[2]-shaped training step (625 frames)",
+                "per_gpu_batch": B, "files": "60 s raw float16 [3750, 96] on " + ("tmpfs (/dev/shm)" if root.startswith("/dev/shm") else "the temp dir"),
+                "loader_alone_clips_per_s": round(B / t_load, 1), "loader_alone_ms_per_batch": round(t_load * 1e3, 2),
+                "step_resident_ms": round(t_res * 1e3, 2), "step_resident_clips_per_s": round(B / t_res, 1),
+                "step_fed_by_loader_ms": round(t_fed * 1e3, 2), "step_fed_by_loader_clips_per_s": round(B / t_fed, 1),
+                "loader_over_step": round(t_res / t_load, 2),
+                "loader_time_hidden_under_the_step": round(hidden, 3),
+                "host_threads": 1}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+        torch.cuda.empty_cache()
+
+
 def side_case(args, dev, mode, T, B, patchout, steps, warmup, workload, precision=None):
     """A further BASELINE configuration measured on the same line (N = 1 only): its own K timed steps between two
     synchronizes, then its own serialized kernel pass."""
@@ -495,6 +577,9 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: create the one-rank RCCL communicator and push every gradient bucket through its "
                          "all-reduce anyway (the data-parallel exchange path on a single GPU)")
+    ap.add_argument("--with-loader", action="store_true",
+                    help="add the `loader` sub-object (the on-disk mel reader alone and double-buffered against the training step) "
+                         "to a non-default line; the default line carries it anyway")
     ap.add_argument("--ranks-share-gpu", action="store_true",
                     help="debug / test switch: every rank of a --gpus N job runs on device 0 and gloo carries the device tensors of "
                          "the gradient exchange -- the whole N-rank launch, bootstrap, bucket and timing path on a one-GPU box "
@@ -647,6 +732,11 @@ def main():
                                             "s_patchout_t 90, N = 875 tokens")
             except Exception as e:  # pragma: no cover
                 out["train30s"] = {"error": repr(e)}
+        if world == 1 and train and (default_line or args.with_loader):
+            try:
+                out["loader"] = loader_case(args, dev)
+            except Exception as e:  # pragma: no cover
+                out["loader"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 cb = args.cpu_batch if args.cpu_batch is not None else (8 if T <= 640 else 2)
