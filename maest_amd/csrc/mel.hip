@@ -270,6 +270,8 @@ extern "C" int maest_logmel(const float* wave, int B, int S, const float* window
     const int T = 1 + S / MEL_HOP;
     const int smem_bytes = (512 + 512 + MEL_BANDS * 16 + MEL_BANDS * MEL_OUT_LD) * 4 + 4 * 4 * MEL_XFRAME;
     dim3 grid((T + MEL_FRAMES_PER_BLOCK - 1) / MEL_FRAMES_PER_BLOCK, B);
+    static DeviceOnce once;                       // 70 KiB of dynamic LDS: above the 64 KiB a kernel gets without the attribute
+    ensure_dynamic_lds(once, &logmel_kernel, smem_bytes);
     hipLaunchKernelGGL(logmel_kernel, grid, dim3(256), smem_bytes, (hipStream_t)stream, wave, S, T, window, twiddle,
                        fb_start, fb_len, fb_w, fb_stride, log_scale, norm_mean, norm_2std, out);
     return check_launch("maest_logmel");

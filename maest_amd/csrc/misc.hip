@@ -170,22 +170,26 @@ __device__ __forceinline__ float bce_term(const float* __restrict__ z, const flo
     // max(z,0) - z*y + log1p(exp(-|z|))   (ATen's numerically stable form)
     return fmaxf(v, 0.0f) - v * t + log1pf(expf(-fabsf(v)));
 }
-// partial[blockIdx] = sum of this workgroup's terms (grid-strided); with gridDim == 1 and `loss` given, the whole loss
-__global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restrict__ z, const float* __restrict__ y,
-                                                          const int32_t* __restrict__ perm, const float* __restrict__ lam,
-                                                          int rows, int cols, float weight, float* __restrict__ partial,
-                                                          float* __restrict__ loss) {
+// partial[blockIdx] = sum of this workgroup's terms (grid-strided); with gridDim == 1 and `loss` given, the whole loss.
+// Any workgroup size that is a multiple of 64 (the loss-only path takes 1024 threads: the one workgroup that keeps the
+// summation order fixed without a scratch buffer then walks a 1024 x 519 validation batch in ~500 terms per thread).
+__global__ __launch_bounds__(1024) void bce_partial_kernel(const float* __restrict__ z, const float* __restrict__ y,
+                                                           const int32_t* __restrict__ perm, const float* __restrict__ lam,
+                                                           int rows, int cols, float weight, float* __restrict__ partial,
+                                                           float* __restrict__ loss) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);
     const int64_t total = (int64_t)rows * cols;
+    const int nthr = (int)blockDim.x;
     float acc = 0.0f, t;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    for (int64_t i = (int64_t)blockIdx.x * nthr + threadIdx.x; i < total; i += (int64_t)gridDim.x * nthr)
         acc += bce_term(z, y, perm, lam, cols, i, t);
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float tot = ((red[0] + red[1]) + red[2]) + red[3];
+        float tot = 0.0f;
+        for (int w = 0; w < nthr / 64; ++w) tot += red[w];                             // fixed order
         if (loss != nullptr) unsafeAtomicAdd(loss, weight * tot / (float)total);     // (gridDim == 1: nothing else adds concurrently)
         else partial[blockIdx.x] = tot;
     }
@@ -363,12 +367,9 @@ extern "C" int maest_bce_logits(const float* z, const float* y, const int32_t* p
     const int64_t total = (int64_t)rows * cols;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256) blocks = 256;
-    if (dlogits == nullptr || total < blocks) {        // loss only (evaluation): one workgroup, fixed order
-        hipLaunchKernelGGL(bce_partial_kernel, dim3(1), dim3(256), 64, (hipStream_t)stream, z, y, perm, lam, rows, cols, weight,
+    if (dlogits == nullptr) {                          // loss only (evaluation): one workgroup of 16 waves, fixed order
+        hipLaunchKernelGGL(bce_partial_kernel, dim3(1), dim3(1024), 64, (hipStream_t)stream, z, y, perm, lam, rows, cols, weight,
                            (float*)nullptr, loss);
-        if (dlogits != nullptr)
-            hipLaunchKernelGGL(bce_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, y, perm, lam, rows, cols, weight,
-                               dlogits);
     } else {
         hipLaunchKernelGGL(bce_partial_kernel, dim3(blocks), dim3(256), 64, (hipStream_t)stream, z, y, perm, lam, rows, cols, weight,
                            dlogits, (float*)nullptr);

@@ -54,7 +54,11 @@ class GradReducer:
         self.order = backward_order(list(params))
         self.params = params
         dev = next(iter(params.values())).device
-        total = sum(p.numel() for p in params.values())
+        # every view starts on a 16-byte boundary (offsets padded to a multiple of 4 floats): the kernels that write gradients in
+        # 16-byte pieces -- the deterministic split-K combine of the wgrad GEMM, MAEST_TN_REDUCE=1 -- then never have to fall
+        # back because a 519-way head bias shifted what follows it; the pad floats stay zero and ride along in the all-reduce
+        pad4 = lambda k: (k + 3) & ~3
+        total = sum(pad4(p.numel()) for p in params.values())
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.views: Dict[str, torch.Tensor] = {}
         self.bucket_of: Dict[str, int] = {}
@@ -63,21 +67,22 @@ class GradReducer:
         # the tail bucket: gradients taken from the END of the backward order while they fit under tail_mb
         tail_cap = int(min(tail_mb, bucket_mb) * 1024 * 1024 / 4)
         tail_first, acc = len(self.order), 0
-        while tail_first > 1 and acc + params[self.order[tail_first - 1]].numel() <= tail_cap:
+        while tail_first > 1 and acc + pad4(params[self.order[tail_first - 1]].numel()) <= tail_cap:
             tail_first -= 1
-            acc += params[self.order[tail_first]].numel()
+            acc += pad4(params[self.order[tail_first]].numel())
         off = 0
         cur = {"start": 0, "end": 0, "names": []}
         for i, n in enumerate(self.order):
             k = params[n].numel()
-            if cur["names"] and ((off + k - cur["start"]) > cap or (i == tail_first and tail_first < len(self.order))):
+            kp = pad4(k)
+            if cur["names"] and ((off + kp - cur["start"]) > cap or (i == tail_first and tail_first < len(self.order))):
                 cur["end"] = off
                 self.buckets.append(cur)
                 cur = {"start": off, "end": off, "names": []}
             self.views[n] = self.flat[off:off + k].view(params[n].shape)
             self.bucket_of[n] = len(self.buckets)
             cur["names"].append(n)
-            off += k
+            off += kp
         cur["end"] = off
         self.buckets.append(cur)
         self._pending = [0] * len(self.buckets)

@@ -579,8 +579,9 @@ class MAEST(nn.Module):
                  s_patchout_f_interleaved=0, s_patchout_t_indices=(), s_patchout_t_interleaved=0,
                  img_size=(96, 625), patch_size=16, stride=10, in_chans=1, num_classes=400, embed_dim=768,
                  depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True, distilled=True, distilled_type="mean",
-                 precision="auto"):
+                 precision="auto", _skip_init: bool = False):
         super().__init__()
+        self._skip_init = bool(_skip_init)      # clone_weights(): the twin's parameters are copies, not draws
         self._init_kwargs = dict(u_patchout=u_patchout, s_patchout_t=s_patchout_t, s_patchout_f=s_patchout_f,
                                  s_patchout_f_indices=s_patchout_f_indices,
                                  s_patchout_f_interleaved=s_patchout_f_interleaved,
@@ -646,15 +647,12 @@ class MAEST(nn.Module):
         """A fresh model of the same architecture, on the same device and in the same mode, holding copies of the
         parameters -- and NOTHING of the engine's run-time state (operand-copy caches keyed on the old parameters,
         side streams, captured HIP graphs, the data-parallel gradient sink with its flat buffer)."""
-        MAEST._skip_random_init = True          # every parameter is overwritten below
-        try:
-            twin = type(self)(**self._init_kwargs)
-        finally:
-            MAEST._skip_random_init = False
-        # configuration changed after construction travels too (patchout switched off for evaluation, numeric mode,
-        # graph replay, engine switches) -- run-time state does not
+        twin = type(self)(**self._init_kwargs, _skip_init=True)     # every parameter is overwritten below
+        # configuration changed after construction travels too (patchout switched off for evaluation, numeric mode, engine
+        # switches) -- run-time state does not, and neither does graph replay: a twin (SWA average, teacher) captures graphs,
+        # with their private memory pools, only when its owner calls enable_hip_graph() on it
         for k in ("precision", "u_patchout", "s_patchout_t", "s_patchout_f", "s_patchout_f_indices",
-                  "s_patchout_f_interleaved", "s_patchout_t_indices", "s_patchout_t_interleaved", "hip_graph"):
+                  "s_patchout_f_interleaved", "s_patchout_t_indices", "s_patchout_t_interleaved"):
             setattr(twin, k, getattr(self, k))
         twin._engine.head_tail = self._engine.head_tail
         twin._engine.overlap_wgrad = self._engine.overlap_wgrad
@@ -675,11 +673,9 @@ class MAEST(nn.Module):
         return twin
 
     # ---- reference API odds and ends --------------------------------------------------------
-    _skip_random_init = False     # clone_weights(): the twin's parameters are copies, not draws
-
     def init_weights(self, mode=""):
         assert mode in ("jax", "jax_nlhb", "nlhb", "")
-        if MAEST._skip_random_init:
+        if self._skip_init:
             return
         for p in (self.new_pos_embed, self.freq_new_pos_embed, self.time_new_pos_embed, self.dist_token,
                   self.cls_token):

@@ -165,7 +165,8 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, colsum: Optiona
     # comes from torch's caching allocator on the CURRENT stream -- the stream the call runs on -- so its reuse is stream-ordered
     code = _mm_code(a.dtype, x3)
     nbytes = ctypes.c_int64(0)
-    call("maest_gemm_tn_workspace_bytes", code, M, N, K, split_k, ctypes.byref(nbytes))
+    if get_option("tn_reduce") != 0:         # (the default combines split-K partials with atomics: no scratch, no query)
+        call("maest_gemm_tn_workspace_bytes", code, M, N, K, split_k, ctypes.byref(nbytes))
     ws = torch.empty(nbytes.value, dtype=torch.uint8, device=a.device) if nbytes.value > 0 else None
     _timed_call("maest_gemm_tn", 2.0 * M * N * K, _p(a), a.stride(0), _p(b), b.stride(0), code, _p(out2),
                 out2.stride(0), M, N, K, _p(colsum), split_k, _p(ws), nbytes.value, _s(a), _entry="maest_gemm_tn_ws")
@@ -536,12 +537,22 @@ def set_option(name: str, value: Optional[int]):
     """maest_set_option: `value` None restores the default (environment, read once at first use)."""
     opt = _lib.OPTIONS[name]
     call("maest_set_option", opt, 0 if value is None else int(value), 1 if value is None else 0)
+    _option_cache.pop((id(_lib.load()), name), None)
+
+
+# library switches change only through set_option (their environment defaults are read once by the library): the hot path
+# (one query per wgrad GEMM and per block of a backward pass) reads them from here instead of crossing the C ABI each time
+_option_cache = {}
 
 
 def get_option(name: str) -> int:
-    v = ctypes.c_int(0)
-    call("maest_get_option", _lib.OPTIONS[name], ctypes.byref(v))
-    return v.value
+    key = (id(_lib.load()), name)
+    v = _option_cache.get(key)
+    if v is None:
+        c = ctypes.c_int(0)
+        call("maest_get_option", _lib.OPTIONS[name], ctypes.byref(c))
+        v = _option_cache[key] = c.value
+    return v
 
 
 class options:
