@@ -600,10 +600,8 @@ __device__ __forceinline__ void epilogueW_run(char* smem, const f32x16_t (&acc)[
             if (PAIR) drain256<OSZ, 0, 32>(src + REGION, p.aux_out, p.ld_aux, nullptr, mbase, n0, p.M, p.N, tid);
         }
     };
-    // (pass 0's aux operand is requested BEHIND the staging of pass 0: in front of it all 128 accumulators are still live and
-    // the 16 .. 32 registers of the request pushed the fp32 / bf16x3 instantiations into scratch; it still flies under the barrier)
-    stage(0, smem);
     if (MODE != 0) prefetch(0);
+    stage(0, smem);
     __syncthreads();
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
