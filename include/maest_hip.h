@@ -69,6 +69,8 @@ const char* maest_last_error(void);
                                 (bf16, N <= 320), query tiles fed by LDS-DMA; 1 = always the two-kernel dK/dV + dQ
                                 form; 2 = the fused form with register-fed tiles and the delta computed in flight;
                                 3 = as 0 without the persistent form (one workgroup per (batch, head) at every shape).
+                                4 = as 1 with the register-staged padded tiles (the bf16 two-kernel form otherwise streams its
+                                tiles by LDS-DMA, bit-equal; A/B and tests).
                                 Under 0, complete backward passes with 257 <= N <= 320 run the persistent form (one
                                 workgroup per CU walks its (batch, head) items, the next item's K / V / query tiles
                                 arriving while the current one computes) */

@@ -1021,6 +1021,195 @@ __global__ __launch_bounds__(NW * 64, FwdWgs<NW>::value) void attn_fwd_dma_kerne
     }
 }
 
+// =================================================================================== two-kernel backward, DMA-fed tiles (bf16)
+// attn_bwd_dkdv_kernel / attn_bwd_dq_kernel (the forms that serve N > 320: the 30 s shapes) with their streamed tiles on the
+// staging path of attn_fwd_dma_kernel: UNPADDED 128-byte-row tiles filled by LDS-DMA (two pieces of each of the two tiles per
+// wave and step, requested right behind the barrier that frees the buffer), bank-swizzled on the DMA source address so that
+// the row reads AND the transpose reads are conflict-free (the padded pitch costs the transpose reads -- half of these kernels'
+// LDS traffic, and they are LDS-bandwidth bound -- twice their ideal cycles); no staging registers, no ds_write pass.  The same
+// products in the same order: bit-equal to the register-staged forms (rows beyond N repeat row N - 1 instead of being zero:
+// padded queries carry lse = +BIG and padded keys a masked score, so P = dS = 0 exactly against a finite operand).
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                   bf16_t* __restrict__ dqkv, int B, int N, float scale) {
+    using T = bf16_t;
+    using C = AttnCfg<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE128 = 64 * 128;
+    constexpr int BUF = 2 * TILE128 + 512;      // { Q[q][d], dO[q][d], lse[64] (pre-multiplied by log2e), delta[64] }
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const AttnBlock blk = attn_block((N + 127) / 128, B);
+    const int head = blk.head, b = blk.b;
+    const int key = blk.rb * 128 + wave * 32 + (lane & 31);
+    const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
+    const T* kbase = qbase + NHEADS * HD;
+    const T* vbase = qbase + 2 * NHEADS * HD;
+    const T* dobase = dout + (int64_t)b * N * OUT_LD + head * HD;
+    const float* lse_b = lse + ((int64_t)b * NHEADS + head) * N;
+    const float* dl_b = delta + ((int64_t)b * NHEADS + head) * N;
+
+    const int ntiles = (N + 63) / 64;
+    auto tile_dma = [&](int qt) {
+        char* base = smem + (qt & 1) * BUF;
+        dma_rows128(base, qbase, QKV_LD, qt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
+        dma_rows128(base + TILE128, dobase, OUT_LD, qt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
+    };
+    float lse_r = 0.0f, dl_r = 0.0f;
+    auto stat_load = [&](int qt) {
+        if (tid < 64) {
+            const int qq = qt * 64 + tid;
+            lse_r = qq < N ? lse_b[qq] * LOG2E : -NEG_BIG;   // padded rows: P = 2^(-BIG) = 0
+            dl_r = qq < N ? dl_b[qq] : 0.0f;
+        }
+    };
+    auto stat_store = [&](int qt) {
+        if (tid < 64) {
+            float* st = reinterpret_cast<float*>(smem + (qt & 1) * BUF + 2 * TILE128);
+            st[tid] = lse_r;
+            st[64 + tid] = dl_r;
+        }
+    };
+    tile_dma(0);
+    stat_load(0);
+    chunk16 kf[C::STEPS], vf[C::STEPS];
+    row_frags_load<T>(kf, kbase, QKV_LD, key, N, h);
+    row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
+    const bool key_ok = key < N;
+    const bool wave_active = blk.rb * 128 + wave * 32 < N;   // wave-uniform
+    const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.0f; dv[db][r] = 0.0f; }
+    stat_store(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0): this wave's pieces, fragments and statistics
+    __builtin_amdgcn_s_barrier();
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const char* q_lds = smem + (qt & 1) * BUF;
+        const char* do_lds = q_lds + TILE128;
+        const float* lse_lds = reinterpret_cast<const float*>(q_lds + 2 * TILE128);
+        const float* dl_lds = lse_lds + 64;
+        const bool more = qt + 1 < ntiles;
+        if (more) {                                 // the other buffer was read a tile ago: everybody has passed the barrier since
+            tile_dma(qt + 1);
+            stat_load(qt + 1);
+        }
+        if (wave_active) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16_t sc, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[r] = 0.0f; dp[r] = 0.0f; }
+                mma_rows_swz(sc, q_lds, qb * 32, lane, kf);      // S[q][key]
+                mma_rows_swz(dp, do_lds, qb * 32, lane, vf);     // dP[q][key]
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ql = qb * 32 + 8 * g + 4 * h;
+                    const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_lds + ql);
+                    const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dl_lds + ql);
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const int r = 4 * g + e;
+                        const f32x2_t sv = {sc[r], sc[r + 1]}, nl = {-l4[e], -l4[e + 1]};
+                        const f32x2_t dpv = {dp[r], dp[r + 1]}, dl = {d4[e], d4[e + 1]};
+                        const f32x2_t ev = __builtin_elementwise_fma(sv, c2v, nl);
+                        const f32x2_t pv = {fast_exp2<T>(ev[0]), fast_exp2<T>(ev[1])};
+                        const f32x2_t ds = pv * (dpv - dl);
+                        sc[r] = pv[0]; sc[r + 1] = pv[1];       // P
+                        dp[r] = ds[0]; dp[r + 1] = ds[1];       // dS (unscaled)
+                    }
+                }
+                mma_transposed_swz(dv, do_lds, qb * 32, lane, sc);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+                mma_transposed_swz(dk, q_lds, qb * 32, lane, dp);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            }
+        }
+        if (more) stat_store(qt + 1);
+        __builtin_amdgcn_s_waitcnt(0x0070);        // this wave's share of the next tile has landed; behind the barrier everybody's
+        __builtin_amdgcn_s_barrier();
+    }
+    T* row = dqkv + ((int64_t)b * N + (key_ok ? key : 0)) * QKV_LD + head * HD;
+    store_dT_ok<T>(dk, row + NHEADS * HD, lane, scale, key_ok);
+    store_dT_ok<T>(dv, row + 2 * NHEADS * HD, lane, 1.0f, key_ok);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                 bf16_t* __restrict__ dqkv, int B, int N, float scale) {
+    using T = bf16_t;
+    using C = AttnCfg<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[key][128 B], V[key][128 B] }
+    constexpr int TILE128 = 64 * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const AttnBlock blk = attn_block((N + 127) / 128, B);
+    const int head = blk.head, b = blk.b;
+    const int q = blk.rb * 128 + wave * 32 + (lane & 31);
+    const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
+    const T* kbase = qbase + NHEADS * HD;
+    const T* vbase = qbase + 2 * NHEADS * HD;
+    const T* dobase = dout + (int64_t)b * N * OUT_LD + head * HD;
+
+    const int ntiles = (N + 63) / 64;
+    auto tile_dma = [&](int kt) {
+        char* kb = smem + (kt & 1) * 2 * TILE128;
+        dma_rows128(kb, kbase, QKV_LD, kt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
+        dma_rows128(kb + TILE128, vbase, QKV_LD, kt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
+    };
+    tile_dma(0);
+    chunk16 qf[C::STEPS], dof[C::STEPS];
+    row_frags_load<T>(qf, qbase, QKV_LD, q, N, h);
+    row_frags_load<T>(dof, dobase, OUT_LD, q, N, h);
+    const bool q_ok = q < N;
+    const bool wave_active = blk.rb * 128 + wave * 32 < N;   // wave-uniform
+    const int qc = q_ok ? q : N - 1;
+    const float lse_q = lse[((int64_t)b * NHEADS + head) * N + qc] * LOG2E;
+    const float dl_q = delta[((int64_t)b * NHEADS + head) * N + qc];
+    const f32x2_t nlse = {-lse_q, -lse_q}, dlv = {dl_q, dl_q}, c2v = {scale * LOG2E, scale * LOG2E};
+    f32x16_t dq[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[db][r] = 0.0f;
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const char* k_lds = smem + (kt & 1) * 2 * TILE128;
+        const char* v_lds = k_lds + TILE128;
+        if (kt + 1 < ntiles) tile_dma(kt + 1);
+        if (wave_active) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16_t sc, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[r] = 0.0f; dp[r] = 0.0f; }
+                mma_rows_swz(sc, k_lds, kb * 32, lane, qf);      // S^T[key][q]
+                mma_rows_swz(dp, v_lds, kb * 32, lane, dof);     // dP^T[key][q]
+                if (kt == ntiles - 1 && (N & 63) != 0) {         // padded keys: P = 0, hence dS = 0
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt * 64 + kb * 32 + frag_row(r, lane) >= N) sc[r] = NEG_BIG;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2_t sv = {sc[r], sc[r + 1]}, dpv = {dp[r], dp[r + 1]};
+                    const f32x2_t ev = __builtin_elementwise_fma(sv, c2v, nlse);
+                    const f32x2_t pv = {fast_exp2<T>(ev[0]), fast_exp2<T>(ev[1])};
+                    const f32x2_t ds = pv * (dpv - dlv);
+                    dp[r] = ds[0]; dp[r + 1] = ds[1];            // dS^T (unscaled)
+                }
+                mma_transposed_swz(dq, k_lds, kb * 32, lane, dp);    // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
+    }
+    store_dT_ok<T>(dq, dqkv + ((int64_t)b * N + (q_ok ? q : 0)) * QKV_LD + head * HD, lane, scale, q_ok);
+}
+
 // MAEST_ATTN_PROF: timing instrumentation only (scratch/attn_prof.py builds a second library with it; never defined in
 // the product build): shader-clock stamps of every wave of the workgroups with blockIdx % 256 == 5, per query tile.
 #ifdef MAEST_ATTN_PROF
@@ -1677,6 +1866,24 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
                                (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N,
                                scale);
             return check_launch("maest_attn_bwd(fused)");
+        }
+    }
+    if constexpr (sizeof(T) == 2 && !X3) {
+        if (option(MAEST_OPT_ATTN_BWD) != 4) {                            // DMA-fed tiles (4 = register-staged padded tiles: A/B, tests)
+            constexpr int smem_da = 2 * (2 * 64 * 128 + 512), smem_db = 4 * 64 * 128;
+            static DeviceOnce once_da, once_db;
+            ensure_dynamic_lds(once_da, &attn_bwd_dkdv_dma_kernel, smem_da);
+            ensure_dynamic_lds(once_db, &attn_bwd_dq_dma_kernel, smem_db);
+            const int64_t items = (int64_t)B * N * NHEADS * 4;
+            if (out != nullptr)
+                hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
+                                   (const T*)out, (const T*)dout, delta, B, N, N);
+            dim3 grid(((N + 127) / 128) * NHEADS * B);
+            hipLaunchKernelGGL(attn_bwd_dkdv_dma_kernel, grid, dim3(256), smem_da, st, (const bf16_t*)qkv, (const bf16_t*)dout,
+                               lse, (const float*)delta, (bf16_t*)dqkv, B, N, scale);
+            hipLaunchKernelGGL(attn_bwd_dq_dma_kernel, grid, dim3(256), smem_db, st, (const bf16_t*)qkv, (const bf16_t*)dout,
+                               lse, (const float*)delta, (bf16_t*)dqkv, B, N, scale);
+            return check_launch("maest_attn_bwd(dma tiles)");
         }
     }
     const int smem_a = 2 * (2 * C::TILE + 512);

@@ -261,6 +261,16 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2, fwd_to
     close(dqkv[:, 1536:], g[:, 1536:], rt, at, "attention dV")
     close(dqkv[:, 768:1536], g[:, 768:1536], rt, at, "attention dK")
     close(dqkv[:, :768], g[:, :768], rt, at, "attention dQ")
+    if dtype == torch.bfloat16:
+        # the two-kernel dK/dV + dQ form streams its tiles by LDS-DMA (unpadded, swizzled); the register-staged padded tiles
+        # (attn_bwd = 4) run the same products in the same order: bit for bit, ragged last tiles included
+        args = (qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
+        with ops.options(attn_bwd=1):
+            dq_dma = ops.attn_bwd(*args)
+        with ops.options(attn_bwd=4):
+            dq_reg = ops.attn_bwd(*args)
+        close(dq_dma, g, rt, at, "attention backward (two-kernel, DMA-fed tiles)")
+        assert torch.equal(dq_dma, dq_reg), "DMA-fed and register-staged two-kernel attention backward differ"
     if dtype == torch.bfloat16 and N <= 320:
         # the call above took the fused one-pass kernel (bf16, <= 10 key blocks); the two-kernel dK/dV + dQ form must
         # agree with the oracle too, and the two with each other to bf16 rounding of the same quantities
