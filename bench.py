@@ -68,8 +68,8 @@ def pmc_traffic():
 def measure_pmc_traffic(timeout_s=150):
     """HBM bytes per GEMM call of the dominant kernel, MEASURED by this run: two rocprofv3 passes (--kernel-trace --pmc
     FETCH_SIZE, then WRITE_SIZE: counters in their own passes, no other trace domain) over a short child run of this same
-    file (2 steps + 1 warm-up, kernels serialized, no side cases), on this GPU.  Per call = sum over every gemm_nt256w
-    launch (256-row tiles and the 128-row-tile launch behind some of them) / number of 256-row-tile launches;
+    file (2 steps + 1 warm-up, kernels serialized, no side cases), on this GPU.  Per call = sum over every gemm_nt256o /
+    gemm_nt256w launch (256-row tiles and the 128-row-tile launch behind some of them) / number of 256-row-tile launches;
     traffic = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section: FETCH_SIZE counts half of the wide coalesced
     reads on gfx950; profiles/r03c_pmc_traffic.json holds the same passes with their calibration on known byte counts:
     x2.00 / x1.00).  Returns (bytes, source, parts) or (None, reason, None): any failure falls back to the committed figure."""
@@ -91,14 +91,16 @@ def measure_pmc_traffic(timeout_s=150):
                 total, calls = 0.0, 0
                 for f in glob.glob(os.path.join(d, "**", "p_counter_collection.csv"), recursive=True):
                     for row in csv.DictReader(open(f)):
-                        if "gemm_nt256w_kernel" not in row["Kernel_Name"] or row["Counter_Name"] != counter:
+                        if ("gemm_nt256w_kernel" not in row["Kernel_Name"] and "gemm_nt256o_kernel" not in row["Kernel_Name"]) \
+                                or row["Counter_Name"] != counter:
                             continue
                         total += float(row["Counter_Value"])
                         name = row["Kernel_Name"].split("(")[0].replace(" ", "")
-                        if name.endswith(",4>"):          # the 256-row-tile instantiation: one launch per GEMM call
+                        # the 256-row-tile kernels (bf16: gemm_nt256o; otherwise gemm_nt256w<.., 4>): one launch per GEMM call
+                        if "gemm_nt256o_kernel" in name or name.endswith(",4>"):
                             calls += 1
                 if calls == 0:
-                    return None, f"no gemm_nt256w launches in the --pmc {counter} pass", None
+                    return None, f"no gemm_nt256o / gemm_nt256w launches in the --pmc {counter} pass", None
                 parts[counter] = (total * 1024.0 / calls, calls)
     except Exception as e:      # timeout, parse error, ...
         return None, f"live PMC pass failed: {type(e).__name__}: {e}", None
@@ -399,7 +401,7 @@ def kernel_report(case, timer, steps, precision, with_traffic, live_traffic=None
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12
         # bf16x3 spends 3 bf16 MFMAs per product: its algorithmic rate is priced against a third of the bf16 peak
         peak = {"bf16": PEAK_BF16_TFLOPS, "bf16x3": round(PEAK_BF16_TFLOPS / 3, 1)}.get(precision, 157.3)
-        out["roofline"] = {"bound": "mfma", "kernel": ("maest_gemm_nt (gemm_nt256w_kernel<bf16>: every token-major GEMM of the blocks; the head and the last block's head-token rows, M <= 512, run gemm_nt_kernel and are listed as maest_gemm_nt_small)"
+        out["roofline"] = {"bound": "mfma", "kernel": ("maest_gemm_nt (gemm_nt256o_kernel, bf16, one wave per SIMD -- plus gemm_nt256w_kernel<bf16, 2> for the 128-row tail tiles: every token-major GEMM of the blocks; the head and the last block's head-token rows, M <= 512, run gemm_nt_kernel and are listed as maest_gemm_nt_small)"
                                                       if precision == "bf16" else
                                                       ("maest_gemm_nt (gemm_nt256w_kernel<float, X3>: 3 bf16 MFMAs per fp32 product)"
                                                        if precision == "bf16x3" else "maest_gemm_nt (fp32 MFMA)")),

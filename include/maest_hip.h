@@ -58,8 +58,10 @@ const char* maest_last_error(void);
 /* ---- process-wide tuning / test switches.  Thread-safe (atomics); the defaults are taken from the environment
  * variables named below, which are read ONCE, at the first use of any switch.  restore_default != 0 ignores `value`.
  *   MAEST_OPT_GEMM_MIN_M    (env MAEST_GEMM_MIN_M,    default 8192): smallest M routed to the 256-row-tile GEMMs
- *   MAEST_OPT_GEMM_VARIANT  (env MAEST_GEMM_VARIANT,  default 0):    0 = full-line 256x256 kernel, 1 = 64-byte-slice
- *                            256x256, 2 = 256x128 two-per-CU, 4 = 256-tile TN kernel at any qualifying shape
+ *   MAEST_OPT_GEMM_VARIANT  (env MAEST_GEMM_VARIANT,  default 0):    0 = full-line 256x256 kernels (bf16 operands: four waves,
+ *                            one per SIMD, 128 x 128 outputs each -- gemm_nt_ow.hip; fp32 / split-bf16 / row-dot: eight waves),
+ *                            1 = 64-byte-slice 256x256, 2 = 256x128 two-per-CU, 3 = as 0 with the eight-wave kernel for bf16 too
+ *                            (A/B, tests), 4 = 256-tile TN kernel at any qualifying shape
  *   MAEST_OPT_GEMM_EPILOGUE (env MAEST_GEMM_EPILOGUE, default -1):   -1 = per-epilogue choice, 0/1/2 force a C-tile
  *                            epilogue form of the full-line kernel */
 #define MAEST_OPT_GEMM_MIN_M 0

@@ -1,0 +1,541 @@
+// NT GEMM, 256 x 256 tile, ONE WAVE PER SIMD (bf16 operands): C[m][n] = epilogue(sum_k A[m][k] B[n][k]) for the large ViT
+// linears (same contract and epilogues as gemm256.hip:gemm_nt256w_kernel, which it replaces for bf16 inputs; reference call
+// sites: nn.Linear forward / dgrad, models/maest.py:353-376, 197-208).
+//
+// Why another kernel.  gemm_nt256w_kernel runs 8 waves of 128 x 64 outputs: per 64-deep K stage its waves read 192 KiB of fragments
+// out of LDS against 64 KiB of LDS-DMA coming in -- 768 + 512 LDS cycles against 2048 matrix-pipe cycles -- and they hide their
+// fragment reads behind the other wave group's MFMAs with four barriers per stage.  Its removal ablation
+// (profiles/r02c_nt_mainloop_ablation.txt) puts the MFMA stream alone and the load stream alone at 60 % of the kernel each: what is
+// lost is their overlap.  Here a workgroup is FOUR waves, one per SIMD, each owning 128 x 128 outputs:
+//   * the 256 fp32 accumulators of a wave live in the accumulator half of the register file (a0 .. a255), the fragments of two
+//     16-deep k-steps in v192 .. v255; both ranges are owned by this file -- touched only by the inline asm below, audited in the
+//     code object by maest_amd/build.py (maest_amd/pw_audit.py), exactly as attn_fwd_pw.hip does it;
+//   * per K stage a wave reads 32 KiB of fragments for 64 MFMAs (LDS: 512 + 512 cycles against 2048), two ds_read_b128 per four
+//     MFMAs, issued one k-step ahead in the shadow of the MFMAs of the running k-step: the statements below execute in program
+//     order, so the source is the schedule -- one instruction stream per SIMD, no wave to take turns with, ONE barrier per stage;
+//   * the operand ring is gemm_nt256w_kernel's: 128-byte rows (whole cache lines), units A_j / B_j of 256 rows = 32 KiB through five
+//     buffers, source-side swizzle  chunk ^= (row >> 1) & 7,  LDS-DMA requests dealt out between the MFMAs (8 behind the stage's
+//     barrier, 4 + 4 in the next two k-steps), a counted vmcnt(8) in front of the barrier (only the unit requested last may fly);
+//   * the first k-step's MFMAs take the constant 0 as their C operand (no clearing pass over 256 registers).
+// The C tile leaves through LDS in four 64-row passes, double buffered, with the bias / GELU / GELU' / residual / multiply
+// epilogues of gemm256_epi.h.
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "gemm256_epi.h"
+
+namespace maest {
+
+constexpr int OW_UNIT = 256 * 128;            // one operand unit: 256 rows x 128 B
+constexpr int OW_NBUF = 5;
+constexpr int OW_SMEM = OW_NBUF * OW_UNIT;    // 163840: the whole LDS, one workgroup per CU
+// register map (device build): accumulator tile (nt, mt) = a[16 (4 nt + mt) ..+15]; fragment set s (k-step parity):
+// A[mt] = v[192 + 32 s + 4 mt ..+3], B[nt] = v[208 + 32 s + 4 nt ..+3]
+constexpr int OW_V_F = 192;
+constexpr int OW_V_LO = 192, OW_V_HI = 255;   // (the audited range)
+
+#if defined(__AMDGCN__)
+#define OW_DEV 1
+#else
+#define OW_DEV 0
+#endif
+#ifndef OW_SPREAD
+#define OW_SPREAD 1       // a stage's 16 LDS-DMA requests: 1 = four per k-step (B's halves in k-steps 3 and 0, A's in 1 and 2); 0 = 8 in
+#endif                    // k-step 3 (B), 4 + 4 in k-steps 0, 1 (A)
+#ifndef OW_ABLATE
+#define OW_ABLATE 0       // timing experiments only (results wrong on purpose): bit 0 no LDS-DMA requests, 1 no barrier / vmcnt wait,
+#endif                    // 2 no MFMAs, 3 no fragment reads, 4 no epilogue
+
+// OW_PROF: timing instrumentation only (scratch/ow_prof.py builds a second library with it; never defined in the product build):
+// shader-clock time the four waves of workgroup 5 spend in each part of a stage, summed over the tile.
+#ifdef OW_PROF
+__device__ unsigned long long* g_ow_prof = nullptr;
+#define OW_TICK(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c.prof[slot] += (unsigned)(t_ - c.tprev); c.tprev = t_; } while (0)
+#else
+#define OW_TICK(slot) ((void)0)
+#endif
+
+struct OwCtx {
+    uint32_t pa[4], pb[4];       // LDS byte offsets of this lane's A / B row chunk of k-step 0 .. 3 (without buffer and tile offset)
+    uint32_t lds0;               // LDS address of the dynamic segment
+    int wave;                    // (wave-uniform)
+#ifdef OW_PROF
+    unsigned prof[24];
+    unsigned long long tprev;
+#endif
+#if !OW_DEV
+    f32x16_t acc[4][4];          // (host emulator: the state the device keeps in owned registers)
+    chunk16 fa[2][4], fb[2][4];
+    char* lds;
+#endif
+};
+
+// fragment read: one ds_read_b128 = this lane's 16-byte chunk of row (tile T) of the A (ISB = false) or B operand
+template <int SET, int T, bool ISB>
+__device__ __forceinline__ void ow_read(OwCtx& c, uint32_t addr) {
+#if OW_DEV
+    constexpr int V = OW_V_F + 32 * SET + (ISB ? 16 : 0) + 4 * T;
+    if (!(OW_ABLATE & 8))
+        asm volatile("ds_read_b128 v[%c1:%c2], %0 offset:%c3" : : "v"(addr), "i"(V), "i"(V + 3), "i"(T * 4096));
+#else
+    const chunk16 v = *reinterpret_cast<const chunk16*>(c.lds + addr + T * 4096);
+    if (ISB) c.fb[SET][T] = v;
+    else c.fa[SET][T] = v;
+#endif
+}
+// acc(nt, mt) (+)= B[nt] A[mt]^T : rows of the result tile = output columns n (4 consecutive per lane and register group), lane = row m
+template <int SET, int NT, int MT, bool ZERO>
+__device__ __forceinline__ void ow_mfma(OwCtx& c) {
+#if OW_DEV
+    constexpr int D = 16 * (4 * NT + MT), A = OW_V_F + 32 * SET + 4 * MT, B = OW_V_F + 32 * SET + 16 + 4 * NT;
+    if (OW_ABLATE & 4) return;
+    if constexpr (ZERO)
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], 0"
+                     : : "i"(D), "i"(D + 15), "i"(B), "i"(B + 3), "i"(A), "i"(A + 3));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], a[%c0:%c1]"
+                     : : "i"(D), "i"(D + 15), "i"(B), "i"(B + 3), "i"(A), "i"(A + 3));
+#else
+    if (ZERO) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c.acc[NT][MT][r] = 0.0f;
+    }
+    mma_chunk<bf16_t>(c.acc[NT][MT], c.fb[SET][NT], c.fa[SET][MT]);
+#endif
+}
+// One LDS-DMA request (1 KiB = 8 rows x 128 B): lane l's 16 bytes come from base + voff (base wave-uniform, in SGPRs) and land at
+// LDS address dst + 16 l; voff then moves on to the next K stage (+ 128 bytes), inside the same statement so that the add rides in
+// the request's slot.  Inline asm so that hipcc does not count it (attn_common.h: dma16); M0 is left holding the address.
+__device__ __forceinline__ void ow_dma(const char* base, uint32_t& voff, uint32_t dst, OwCtx& c) {
+#if OW_DEV
+    if (OW_ABLATE & 1) return;
+    const uint32_t lds = __builtin_amdgcn_readfirstlane(dst);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tv_add_u32 %0, 0x80, %0"
+                 : "+v"(voff) : "s"(base), "s"(lds) : "memory");
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff),
+                                     (__attribute__((address_space(3))) void*)(c.lds + dst), 16, 0, 0);
+    voff += 128;
+#endif
+}
+template <int N>
+__device__ __forceinline__ void ow_wait_vm() {       // all but this wave's N newest LDS-DMA requests have landed
+#if OW_DEV
+    if (OW_ABLATE & 2) return;
+    asm volatile("s_waitcnt vmcnt(%c0)" : : "i"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void ow_wait_lds() {      // every fragment read this wave has issued (hipcc does not count the asm ones)
+#if OW_DEV
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+#endif
+}
+__device__ __forceinline__ void ow_barrier() {
+#if OW_DEV
+    if (OW_ABLATE & 2) return;
+    asm volatile("s_barrier" : : : "memory");
+#else
+    __syncthreads();
+#endif
+}
+#if OW_DEV
+template <int A>
+__device__ __forceinline__ float ow_acc_read1() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "i"(A));
+    return x;
+}
+template <int A, int... R>
+__device__ __forceinline__ void ow_acc_read16(f32x16_t& v, std::integer_sequence<int, R...>) {
+    ((v[R] = ow_acc_read1<A + R>()), ...);
+}
+#endif
+// accumulator tile (NT, MT) out of the owned registers (the caller has put the wait states behind the last MFMA)
+template <int NT, int MT>
+__device__ __forceinline__ f32x16_t ow_acc_read(OwCtx& c) {
+#if OW_DEV
+    f32x16_t v;
+    ow_acc_read16<16 * (4 * NT + MT)>(v, std::make_integer_sequence<int, 16>{});
+    return v;
+#else
+    return c.acc[NT][MT];
+#endif
+}
+
+// One slot of a k-step: an MFMA and what rides in its shadow.  k-step S of a stage multiplies fragment set S & 1; slots 0 .. 7
+// carry the fragment reads of the NEXT k-step (A tiles 0 .. 3, then B tiles 0 .. 3) into the other set, slots 8 .. 15 this
+// wave's LDS-DMA requests into the unit buffer at LDS address dst: NDMA = 8 one per slot (pieces 0 .. 7), NDMA = 4 every other
+// slot (pieces I0 .. I0 + 3).
+template <int S, int Q, bool ZERO, int NDMA, int I0>
+__device__ __forceinline__ void ow_slot(OwCtx& c, uint32_t ra, uint32_t rb, const char* base, uint32_t (&vo)[8], uint32_t dst) {
+    constexpr int SET = S & 1;
+    ow_mfma<SET, (Q >> 2), (Q & 3), ZERO>(c);
+    if constexpr (Q < 4) {
+        ow_read<SET ^ 1, Q, false>(c, ra);
+    } else if constexpr (Q < 8) {
+        ow_read<SET ^ 1, Q - 4, true>(c, rb);
+    } else if constexpr (NDMA == 8) {
+        ow_dma(base, vo[Q - 8], dst + (Q - 8) * 1024, c);
+    } else if constexpr (NDMA == 4 && (Q & 1) == 0) {
+        constexpr int I = I0 + ((Q - 8) >> 1);
+        ow_dma(base, vo[I], dst + I * 1024, c);
+    }
+}
+template <int S, bool ZERO, int NDMA, int I0, int... Q>
+__device__ __forceinline__ void ow_step_slots(OwCtx& c, uint32_t ra, uint32_t rb, const char* base, uint32_t (&vo)[8],
+                                              uint32_t dst, std::integer_sequence<int, Q...>) {
+    (ow_slot<S, Q, ZERO, NDMA, I0>(c, ra, rb, base, vo, dst), ...);
+}
+template <int S, bool ZERO, int NDMA, int I0>
+__device__ __forceinline__ void ow_step(OwCtx& c, uint32_t ra, uint32_t rb, const char* base, uint32_t (&vo)[8],
+                                        uint32_t dst) {
+    ow_step_slots<S, ZERO, NDMA, I0>(c, ra, rb, base, vo, dst, std::make_integer_sequence<int, 16>{});
+}
+
+// ---- C tile -> LDS -> HBM: four passes, pass ps = m-tile ps of both wave rows (tile rows 128 wm + 32 ps ..+31: every wave stages
+// 32 rows x 128 columns per pass), two staging buffers, one barrier per pass: the 16-byte stores of pass ps go in flight, then
+// pass ps + 1 is read out of the accumulators, converted / activated and staged underneath them.  With one wave per SIMD nothing
+// hides a latency for free, so: the tile's 256 bias values sit in LDS (fetched into a register per lane at kernel start: a
+// global load per use was two thirds of this epilogue), a pass's LDS reads are issued as one batch, and the second operand of
+// the RESIDUAL / MUL forms is fetched into registers a pass ahead (AuxRegs), behind the previous pass's drain.
+// GMODE: 0 none, 1 GELU, 3 GELU + GELU' side output; MODE: 0 plain, 1 RESIDUAL (+ aux), 2 MUL (* aux)
+template <int OSZ, int GMODE, int MODE>
+__device__ __forceinline__ void ow_epilogue_run(char* smem, OwCtx& c, const Gemm256Params& p, int m0, int n0, int wm, int wn,
+                                                int lane, int tid, const f32x4_t& bias_reg) {
+    using E = EpiT<OSZ, 256>;
+    constexpr bool PAIR = GMODE == 3;
+    constexpr int REGION = 64 * E::PITCH;                       // one 64-row staging region: 33792 / 66560
+    constexpr int BUF = (PAIR ? 2 : 1) * REGION;
+    constexpr int BIAS0 = 2 * BUF;                              // 256 floats behind the two staging buffers
+    static_assert(BIAS0 + 1024 <= OW_SMEM, "two staging buffers and the bias row");
+    constexpr int NCH = 32 * E::CPR / 256;                      // 16-byte chunks per thread and 32-row group: 4 / 8
+    constexpr int RS = 256 / E::CPR;                            // rows between a thread's consecutive chunks: 8 / 4
+    const int h = lane >> 5;
+    if (tid < 64) *reinterpret_cast<f32x4_t*>(smem + BIAS0 + tid * 16) = bias_reg;
+    __syncthreads();
+    // this lane's 16 bias quadruples (columns 128 wn + 32 nt + 8 g + 4 h ..+3), read once: the same for all four passes
+    f32x4_t b4[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            b4[nt][g] = *reinterpret_cast<const f32x4_t*>(smem + BIAS0 + (wn * 128 + nt * 32 + 8 * g + 4 * h) * 4);
+    auto stage_tile = [&](auto nt_tag, auto ps_tag, char* row) {
+        constexpr int NT = decltype(nt_tag)::value, PS = decltype(ps_tag)::value;
+        const f32x16_t t = ow_acc_read<NT, PS>(c);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4], d[4];
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const f32x2_t xv = {t[4 * g + e] + b4[NT][g][e], t[4 * g + e + 1] + b4[NT][g][e + 1]};
+                f32x2_t gv = xv, dv = {0.0f, 0.0f};
+                if (GMODE != 0) gelu_pair2<false>(xv, gv, dv);
+                v[e] = gv[0]; v[e + 1] = gv[1];
+                d[e] = dv[0]; d[e + 1] = dv[1];
+            }
+            char* dst = row + (NT * 32 + 8 * g) * OSZ;
+            if (OSZ == 4) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                if (PAIR) *reinterpret_cast<float4*>(dst + REGION) = make_float4(d[0], d[1], d[2], d[3]);
+            } else {
+                chunk8 o;
+                o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
+                *reinterpret_cast<chunk8*>(dst) = o;
+                if (PAIR) {
+                    chunk8 q;
+                    q[0] = pack_bf2(d[0], d[1]); q[1] = pack_bf2(d[2], d[3]);
+                    *reinterpret_cast<chunk8*>(dst + REGION) = q;
+                }
+            }
+        }
+    };
+    auto stage = [&](auto ps_tag, char* buf) {
+        using std::integral_constant;
+        char* row = buf + (wm * 32 + (lane & 31)) * E::PITCH + (wn * 128 + 4 * h) * OSZ;
+        stage_tile(integral_constant<int, 0>{}, ps_tag, row);
+        stage_tile(integral_constant<int, 1>{}, ps_tag, row);
+        stage_tile(integral_constant<int, 2>{}, ps_tag, row);
+        stage_tile(integral_constant<int, 3>{}, ps_tag, row);
+    };
+    // drain: thread t moves chunk cc = t % CPR of rows r0 + RS i (r0 = t / CPR) of a 32-row group; its pointers into C / aux are
+    // formed once, a group's rows are wave-uniform multiples of the row pitch away.  Rows beyond M exist in the last tile row only.
+    const int r0 = tid / E::CPR, cc = tid - r0 * E::CPR;
+    const bool full = m0 + 256 <= p.M;                          // (block-uniform)
+    const int64_t col = (int64_t)(n0 + cc * E::EPC) * OSZ;
+    char* c_thr = reinterpret_cast<char*>(p.C) + (int64_t)(m0 + r0) * p.ldc * OSZ + col;
+    const int64_t c_row = p.ldc * OSZ, x_row = p.ld_aux * OSZ;  // (aux_in and aux_out have the output's element size)
+    const char* a_col = reinterpret_cast<const char*>(p.aux_in) + col;
+    const char* a_thr = a_col + (int64_t)(m0 + r0) * x_row;
+    char* o_thr = reinterpret_cast<char*>(p.aux_out) + (int64_t)(m0 + r0) * x_row + col;
+    const int l_thr = r0 * E::PITCH + cc * 16;
+    chunk16 ax[2][NCH];                                         // [32-row group]: the RESIDUAL / MUL operand of the pass to drain
+    auto prefetch = [&](int ps) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ro = half * 128 + ps * 32 + i * RS;   // (wave-uniform)
+                const char* src = a_thr + ro * x_row;
+                if (!full) src = m0 + r0 + ro < p.M ? src : a_col;      // (row 0: loaded, never stored)
+                ax[half][i] = *reinterpret_cast<const chunk16*>(src);
+            }
+    };
+    auto drain_one = [&](const char* src, char* dthr, int64_t drow, const chunk16* aux, int ro0) {
+        chunk16 v[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) v[i] = *reinterpret_cast<const chunk16*>(src + l_thr + i * RS * E::PITCH);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            chunk16 o = v[i];
+            if (aux != nullptr) o = apply_aux<OSZ, MODE>(o, aux[i]);
+            // streaming output: written once, re-read by a later kernel after > L2-size of other traffic
+            if (full || m0 + r0 + ro0 + i * RS < p.M)
+                __builtin_nontemporal_store(o, reinterpret_cast<chunk16*>(dthr + (ro0 + i * RS) * drow));
+        }
+    };
+    auto drain = [&](int ps, const char* buf) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                  // the two 32-row groups of a pass are 128 rows apart
+            const char* src = buf + half * 32 * E::PITCH;
+            drain_one(src, c_thr, c_row, MODE != 0 ? ax[half] : nullptr, half * 128 + ps * 32);
+            if (PAIR) drain_one(src + REGION, o_thr, x_row, nullptr, half * 128 + ps * 32);
+        }
+    };
+    using std::integral_constant;
+    if (MODE != 0) prefetch(0);
+    stage(integral_constant<int, 0>{}, smem);
+    OW_TICK(13);
+    __syncthreads();
+    OW_TICK(14);
+    drain(0, smem);
+    OW_TICK(15);
+    if (MODE != 0) prefetch(1);
+    stage(integral_constant<int, 1>{}, smem + BUF);
+    OW_TICK(13);
+    __syncthreads();
+    OW_TICK(14);
+    drain(1, smem + BUF);
+    OW_TICK(15);
+    if (MODE != 0) prefetch(2);
+    stage(integral_constant<int, 2>{}, smem);
+    OW_TICK(13);
+    __syncthreads();
+    OW_TICK(14);
+    drain(2, smem);
+    OW_TICK(15);
+    if (MODE != 0) prefetch(3);
+    stage(integral_constant<int, 3>{}, smem + BUF);
+    OW_TICK(13);
+    __syncthreads();
+    OW_TICK(14);
+    drain(3, smem + BUF);
+    OW_TICK(15);
+}
+template <int OSZ>
+__device__ __forceinline__ void ow_epilogue(char* smem, OwCtx& c, const Gemm256Params& p, int m0, int n0, int wm, int wn, int lane,
+                                            int tid, const f32x4_t& bias_reg) {
+    const bool gelu = p.epi == MAEST_EPI_GELU;
+    if constexpr (OSZ == 2) {      // (the fp32 value + GELU' pair would not fit two staging buffers: gemm_nt256_try keeps it away)
+        if (gelu && p.aux_out != nullptr) return ow_epilogue_run<OSZ, 3, 0>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
+    }
+    if (p.epi == MAEST_EPI_RESIDUAL) ow_epilogue_run<OSZ, 0, 1>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
+    else if (p.epi == MAEST_EPI_MUL) ow_epilogue_run<OSZ, 0, 2>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
+    else if (gelu) ow_epilogue_run<OSZ, 1, 0>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
+    else ow_epilogue_run<OSZ, 0, 0>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+#if OW_DEV
+    // the registers this file owns (the clobber makes the kernel descriptor allocate them)
+    asm volatile("" : : : "a0", "a255", "v192", "v255");
+#endif
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = wg / p.tiles_n;
+    const int tile_n = wg - tile_m * p.tiles_n;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int nstages = p.K >> 6;
+
+    // this lane's share of the tile's bias row (256 floats = 64 lanes x 4): parked in a register until the epilogue puts it in LDS
+    f32x4_t bias_reg = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (p.bias != nullptr) bias_reg = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + 4 * lane);
+    OwCtx c;
+    c.wave = wave;
+#if OW_DEV
+    c.lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#else
+    c.lds0 = 0;
+    c.lds = smem;
+#endif
+    {
+        const int ra = wm * 128 + (lane & 31), rb = wn * 128 + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            c.pa[ks] = (uint32_t)(ra * 128 + ((((2 * ks) | h) ^ ((ra >> 1) & 7)) << 4));
+            c.pb[ks] = (uint32_t)(rb * 128 + ((((2 * ks) | h) ^ ((rb >> 1) & 7)) << 4));
+        }
+    }
+    // LDS-DMA sources: piece i of this wave = rows 64 wave + 8 i ..+7 of a unit, lane l = row l >> 3, 16-byte chunk (l & 7) ^ swizzle;
+    // offsets are relative to the tile's first row (rows beyond M / N repeat the last one: loaded, never stored)
+    const char* abase = p.A + ((OW_ABLATE & 32) ? 0 : (int64_t)m0 * p.lda * 2);      // (bit 5: every workgroup loads tile 0)
+    const char* bbase = p.B + ((OW_ABLATE & 32) ? 0 : (int64_t)n0 * p.ldb * 2);
+    uint32_t voa[8], vob[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (wave * 8 + i) * 8 + (lane >> 3);
+        const uint32_t csrc = (uint32_t)((((lane & 7) ^ ((r >> 1) & 7))) << 4);
+        const int ra = m0 + r < p.M ? r : p.M - 1 - m0;
+        const int rb = n0 + r < p.N ? r : p.N - 1 - n0;
+        voa[i] = (uint32_t)(ra * (int)p.lda * 2) + csrc;
+        vob[i] = (uint32_t)(rb * (int)p.ldb * 2) + csrc;
+    }
+    const uint32_t piece0 = c.lds0 + (uint32_t)(wave * 8 * 1024);
+    auto request = [&](const char* base, uint32_t (&vo)[8], int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ow_dma(base, vo[i], piece0 + (uint32_t)(buf * OW_UNIT + i * 1024), c);
+    };
+#ifdef OW_PROF
+    for (int i = 0; i < 24; ++i) c.prof[i] = 0;
+    c.tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = c.tprev;
+#endif
+    // prologue: units 0 .. 4 = A_0 B_0 A_1 B_1 A_2 as far as they exist (unit 2 j + (B ? 1 : 0) lives in buffer unit % 5)
+    request(abase, voa, 0);
+    request(bbase, vob, 1);
+    if (nstages > 2) {
+        request(abase, voa, 2);
+        request(bbase, vob, 3);
+        request(abase, voa, 4);
+        ow_wait_vm<24>();             // stage 0 has landed (this wave's share): A_1 B_1 A_2 may fly
+    } else if (nstages > 1) {
+        request(abase, voa, 2);
+        request(bbase, vob, 3);
+        ow_wait_vm<16>();
+    } else {
+        ow_wait_vm<0>();
+    }
+    ow_barrier();
+    {
+        const uint32_t la = c.lds0 + c.pa[0], lb = c.lds0 + OW_UNIT + c.pb[0];
+        ow_read<0, 0, false>(c, la); ow_read<0, 1, false>(c, la); ow_read<0, 2, false>(c, la); ow_read<0, 3, false>(c, la);
+        ow_read<0, 0, true>(c, lb); ow_read<0, 1, true>(c, lb); ow_read<0, 2, true>(c, lb); ow_read<0, 3, true>(c, lb);
+    }
+    OW_TICK(10);                      // (prologue)
+    // Stage j = four k-steps.  k-step s multiplies the fragments of set s & 1 and reads those of the next k-step (the next stage's
+    // first one behind the stage's barrier; the last stage reads the ring's next buffers there: stale bytes nobody multiplies).
+    // The barrier b_j stands between k-steps 2 and 3: in front of it every wave has read its last fragments of stage j
+    // (lgkmcnt(0)) and has seen its pieces of stage j + 1 land (vmcnt(8): only A_{j+2}, requested last, may fly), so behind it
+    // stage j + 1 may be read and stage j's two buffers refilled:
+    //   k-step 3 of stage j:        B_{j+2} -> A_j's buffer (8 requests)
+    //   k-steps 0, 1 of stage j+1:  A_{j+3} -> B_j's buffer (4 + 4)
+    // i.e. a unit has at least 3 k-steps (1536 matrix-pipe cycles) to land.  Stage 0 finds A_1 B_1 A_2 requested by the prologue.
+    // The stage loop is unrolled over the ring's period (PH = j % 5): buffer addresses are constants, the per-stage scalar work is
+    // a counter and two compares -- with one wave per SIMD every scalar instruction in front of an MFMA is a bubble in the pipe.
+    // KIND 2: the units A_{j+2}, B_{j+2} exist (j + 2 < nstages); 1: the last stage but one (B_{j+1}'s second half is still to be
+    // requested); 0: the last stage.  The last two stages wait for everything in front of their barrier.
+    auto stage_body = [&](auto ph_tag, auto first_tag, auto kind_tag) {
+        constexpr int PH = decltype(ph_tag)::value, KIND = decltype(kind_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int ABUF = (2 * PH) % 5, BBUF = (2 * PH + 1) % 5, ABUF_N = (2 * PH + 2) % 5, BBUF_N = (2 * PH + 3) % 5;
+        constexpr int BBUF_P = (2 * PH + 4) % 5;             // B_{j-1}'s buffer
+        const uint32_t la = c.lds0 + (uint32_t)(ABUF * OW_UNIT), lb = c.lds0 + (uint32_t)(BBUF * OW_UNIT);
+        const uint32_t dst_a = piece0 + (uint32_t)(BBUF_P * OW_UNIT);      // A_{j+2} -> B_{j-1}'s buffer
+        OW_TICK(0);
+        ow_wait_lds();
+        OW_TICK(1);
+#if OW_SPREAD == 1
+        // B_{j+1}'s second half -> A_{j-1}'s buffer (= B_{j+1}'s), then A_{j+2} in k-steps 1 and 2, B_{j+2}'s first half in k-step 3
+        ow_step<0, FIRST, (!FIRST && KIND >= 1) ? 4 : 0, 4>(c, la + c.pa[1], lb + c.pb[1], bbase, vob, piece0 + (uint32_t)(BBUF_N * OW_UNIT));
+        OW_TICK(2);
+        ow_wait_lds();
+        OW_TICK(3);
+        ow_step<1, false, (!FIRST && KIND == 2) ? 4 : 0, 0>(c, la + c.pa[2], lb + c.pb[2], abase, voa, dst_a);
+        OW_TICK(4);
+        ow_wait_lds();
+        OW_TICK(5);
+        ow_step<2, false, (!FIRST && KIND == 2) ? 4 : 0, 4>(c, la + c.pa[3], lb + c.pb[3], abase, voa, dst_a);
+#else
+        ow_step<0, FIRST, (!FIRST && KIND == 2) ? 4 : 0, 0>(c, la + c.pa[1], lb + c.pb[1], abase, voa, dst_a);
+        OW_TICK(2);
+        ow_wait_lds();
+        OW_TICK(3);
+        ow_step<1, false, (!FIRST && KIND == 2) ? 4 : 0, 4>(c, la + c.pa[2], lb + c.pb[2], abase, voa, dst_a);
+        OW_TICK(4);
+        ow_wait_lds();
+        OW_TICK(5);
+        ow_step<2, false, 0, 0>(c, la + c.pa[3], lb + c.pb[3], abase, voa, 0u);
+#endif
+        OW_TICK(6);
+        ow_wait_lds();
+        OW_TICK(7);
+        ow_wait_vm<(KIND == 2 ? 8 : 0)>();
+        OW_TICK(8);
+        ow_barrier();                 // b_j
+        OW_TICK(9);
+        ow_step<3, false, (KIND == 2 ? (OW_SPREAD == 1 ? 4 : 8) : 0), 0>(c, c.lds0 + (uint32_t)(ABUF_N * OW_UNIT) + c.pa[0],
+                                                                        c.lds0 + (uint32_t)(BBUF_N * OW_UNIT) + c.pb[0], bbase, vob,
+                                                                        piece0 + (uint32_t)(ABUF * OW_UNIT));
+    };
+    // stages [j, jend) starting at ring phase ph (= j % 5), all of one kind; steady state: a counter, a compare, a branch not taken
+    auto run = [&](auto kind_tag, int& j, int jend, int& ph) {
+        using std::integral_constant;
+        while (j < jend) {
+            switch (ph) {
+            case 1: stage_body(integral_constant<int, 1>{}, std::false_type{}, kind_tag); ph = 2; if (++j == jend) break; [[fallthrough]];
+            case 2: stage_body(integral_constant<int, 2>{}, std::false_type{}, kind_tag); ph = 3; if (++j == jend) break; [[fallthrough]];
+            case 3: stage_body(integral_constant<int, 3>{}, std::false_type{}, kind_tag); ph = 4; if (++j == jend) break; [[fallthrough]];
+            case 4: stage_body(integral_constant<int, 4>{}, std::false_type{}, kind_tag); ph = 0; if (++j == jend) break; [[fallthrough]];
+            default: stage_body(integral_constant<int, 0>{}, std::false_type{}, kind_tag); ph = 1; ++j;
+            }
+        }
+    };
+    {
+        using std::integral_constant;
+        if (nstages > 2) stage_body(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, 2>{});
+        else stage_body(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, 0>{});
+        int j = 1, ph = 1;
+        run(integral_constant<int, 2>{}, j, nstages - 2, ph);
+        run(integral_constant<int, 1>{}, j, nstages - 1, ph);
+        run(integral_constant<int, 0>{}, j, nstages, ph);
+    }
+
+    OW_TICK(0);                       // (the last k-step 3 counts as "step 3" = slot 0 of the next stage)
+    ow_wait_vm<0>();
+    __syncthreads();
+#if OW_DEV
+    if (OW_ABLATE & 16) return;
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");      // the last MFMAs' results are in the accumulator registers
+#endif
+    OW_TICK(11);                      // (drain)
+    if (p.out_dtype == MAEST_BF16) ow_epilogue<2>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
+    else ow_epilogue<4>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
+#ifdef OW_PROF
+    __builtin_amdgcn_s_waitcnt(0);
+    OW_TICK(12);                      // (epilogue, stores acknowledged)
+    if ((blockIdx.x == 5 || blockIdx.x == gridDim.x - 3) && g_ow_prof != nullptr && lane == 0) {
+        unsigned long long* out = g_ow_prof + (blockIdx.x == 5 ? 0 : 96);
+        for (int i = 0; i < 22; ++i) out[wave * 24 + i] = c.prof[i];
+        out[wave * 24 + 22] = t_begin;
+        out[wave * 24 + 23] = c.tprev;
+    }
+#endif
+}
+#ifdef OW_PROF
+extern "C" int maest_debug_ow_prof(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ow_prof), &p, sizeof(p)); }
+#endif
+
+int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream) {
+    static DeviceOnce once;
+    ensure_dynamic_lds(once, &gemm_nt256o_kernel, OW_SMEM);
+    hipLaunchKernelGGL(gemm_nt256o_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), OW_SMEM, stream, p);
+    return check_launch("maest_gemm_nt(256o)");
+}
+
+}  // namespace maest

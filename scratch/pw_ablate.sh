@@ -15,7 +15,7 @@ done
 wait
 for a in "$@"; do
   name=${a%%:*}
-  objs=$(ls maest_amd/build/*.o | grep -v attn_fwd_pw)
+  objs=$(ls maest_amd/build/*.hip.o | grep -v attn_fwd_pw)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/pw_abl/libmaest_$name.so $objs scratch/pw_abl/pw_$name.o
   rm scratch/pw_abl/pw_$name.o
 done

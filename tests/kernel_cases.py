@@ -75,6 +75,42 @@ def case_gemm(dev, dtype, M, N, K, seed=0, identity=True):
     close(acc, ref - bias, rt, at * math.sqrt(K / 64), "gemm split-k")
 
 
+def case_gemm_one_wave_per_simd(dev, M, N, K, seed=11, only=None, pair=True):
+    """gemm_nt256o_kernel (gemm_nt_ow.hip: bf16 operands, the default of the 256 x 256 path) against the 8-wave kernel it replaces
+    (gemm_variant = 3): the same products summed in the same order and the same epilogue arithmetic -- bit for bit, in every
+    epilogue form, ragged last tile row included -- and against the oracle's fp32 matmul."""
+    dt = torch.bfloat16
+    a = rnd((M, K), seed).to(dt).to(dev)
+    w = (rnd((N, K), seed + 1) * 0.1).to(dt).to(dev)
+    bias = rnd((N,), seed + 2).to(dev)
+    res = rnd((M, N), seed + 3).to(dev)
+    mul = rnd((M, N), seed + 4).to(dt).to(dev)
+    ref = a.float().cpu() @ w.float().cpu().t() + bias.cpu()
+    forms = [("none -> bf16", dict(out_dtype=dt)), ("none -> fp32", dict(out_dtype=torch.float32)),
+             ("gelu -> bf16", dict(out_dtype=dt, epi=ops.EPI_GELU)), ("gelu -> fp32", dict(out_dtype=torch.float32, epi=ops.EPI_GELU)),
+             ("residual -> fp32", dict(out_dtype=torch.float32, epi=ops.EPI_RESIDUAL, aux_in=res)),
+             ("mul -> bf16", dict(out_dtype=dt, epi=ops.EPI_MUL, aux_in=mul))]
+    for name, kw in forms:
+        if only is not None and name not in only:
+            continue
+        for b in ((bias, None) if only is None else (bias,)):
+            new = ops.gemm_nt(a, w, b, **kw)
+            with ops.options(gemm_variant=3):
+                old = ops.gemm_nt(a, w, b, **kw)
+            assert torch.equal(new, old), f"one-wave-per-SIMD GEMM differs from the 8-wave kernel: {name}, bias {b is not None}"
+    c = ops.gemm_nt(a, w, bias, out_dtype=torch.float32)
+    close(c, ref, 1e-5, 4e-7 * K, "one-wave-per-SIMD GEMM vs fp32 matmul")
+    if not pair:
+        return
+    aux_n = torch.empty((M, N), dtype=dt, device=dev)
+    aux_o = torch.empty((M, N), dtype=dt, device=dev)
+    g_n = ops.gemm_nt(a, w, bias, out_dtype=dt, epi=ops.EPI_GELU, aux_out=aux_n)
+    with ops.options(gemm_variant=3):
+        g_o = ops.gemm_nt(a, w, bias, out_dtype=dt, epi=ops.EPI_GELU, aux_out=aux_o)
+    assert torch.equal(g_n, g_o) and torch.equal(aux_n, aux_o), "GELU + GELU' pair differs between the two 256 x 256 kernels"
+    close(g_n, F.gelu(ref), 1e-2, 1e-2 * math.sqrt(K / 64), "one-wave-per-SIMD GEMM: gelu")
+
+
 def case_gemm_rowdot(dev, dtype, M, N, K, ntok, seed=7):
     """maest_gemm_nt_rowdot: C = A B^T + bias in `dtype`, and rowdot[item, 64-column group, row in item] = the dot
     product of the STORED row segment of C with `other` -- the attention backward's delta out of the dgrad GEMM's

@@ -40,6 +40,18 @@ def test_emu_gemm_256_tile_full_line_stages(emu, dtype, gemm_options):
     KC.case_gemm(emu, dtype, 512, 256, 192 if dtype == torch.float32 else 384, identity=False)   # 6 stages > 5 buffers
 
 
+
+def test_emu_gemm_one_wave_per_simd_kernel(emu, gemm_options):
+    """gemm_nt256o_kernel's host twin (the C++ form of every owned-register primitive of gemm_nt_ow.hip): 1, 2, 3 and 7 K stages
+    (the prologue's three forms, the stage kinds FIRST / full / last-but-one / last, two ring phases beyond the period) and a
+    ragged second tile row, bit for bit against the 8-wave kernel in every epilogue form."""
+    gemm_options(gemm_min_m=512, gemm_tail=0)
+    KC.case_gemm_one_wave_per_simd(emu, 512, 256, 64, only=("none -> bf16",), pair=False)
+    KC.case_gemm_one_wave_per_simd(emu, 512, 256, 128, only=("residual -> fp32",), pair=False)
+    KC.case_gemm_one_wave_per_simd(emu, 512, 256, 192, only=("mul -> bf16", "gelu -> fp32"), pair=False)
+    KC.case_gemm_one_wave_per_simd(emu, 520, 256, 448, only=("none -> fp32",))
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_emu_gemm_128_row_tiles_of_the_last_partial_round(emu, dtype, gemm_options):
     """gemm_nt256w_kernel<MTW = 2>: 128 x 256 tiles (A units of 128 rows in the same ring, vmcnt(2) waits, one-pass

@@ -33,6 +33,21 @@ def test_gemm_128_row_tiles_forced(dtype, shape, gemm_options):
     KC.case_gemm(DEV, dtype, *shape)
 
 
+@pytest.mark.parametrize("shape", [(512, 256, 64), (512, 256, 128), (777, 512, 192), (1120, 2304, 768), (2560 + 77, 768, 3072),
+                                   (74240, 768, 768), (66000, 2304, 768)])
+def test_gemm_one_wave_per_simd_kernel(shape, gemm_options):
+    """gemm_nt256o_kernel (bf16, the default 256 x 256 kernel) bit for bit against the 8-wave kernel in every epilogue form: 1 / 2 / 3 /
+    12 / 48 K stages, ragged last tile rows, the production shapes (incl. the split into full rounds + 128-row tail tiles)"""
+    gemm_options(gemm_min_m=512)
+    KC.case_gemm_one_wave_per_simd(DEV, *shape)
+
+
+def test_gemm_eight_wave_kernel_still_serves_bf16(gemm_options):
+    """gemm_variant = 3: gemm_nt256w_kernel<bf16> (the A/B reference of the kernel above) against the oracle on its own"""
+    gemm_options(gemm_min_m=512, gemm_variant=3)
+    KC.case_gemm(DEV, torch.bfloat16, 1120, 2304, 768)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_gemm_last_partial_round_split(dtype):
     """66000 x 768: 774 tiles of 256 rows = 3 rounds + 6 tiles -> rows 0..65535 in 256-row tiles, the remaining 464
