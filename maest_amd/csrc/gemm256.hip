@@ -1138,17 +1138,6 @@ __device__ __forceinline__ chunk16 frag_tn256<float>(const char* tile, int ks, i
     return c;
 }
 
-struct GemmTn256Params {
-    const char* A;
-    const char* B;
-    float* C;
-    float* colsum;
-    int64_t lda, ldb, ldc;
-    int M, N, K;
-    int tiles_m, tiles_n;
-    int k_slices_per_split, split_k;
-    float* ws;      // NULL: the split-K partials are added to C with fp32 atomics; else [split][tile][wave][32 chunks][64 lanes][4] fp32
-};
 
 template <typename T, bool X3 = false>
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
@@ -1439,6 +1428,11 @@ int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int d
     const bool use_ws = ws != nullptr && split_k >= 2 && ws_bytes >= need && option(MAEST_OPT_TN_REDUCE) != 0 &&
                         ((uintptr_t)ws % 16) == 0 && ((uintptr_t)C % 16) == 0 && (ldc % 4) == 0;
     p.ws = use_ws ? (float*)ws : nullptr;
+    // bf16 operands, atomic combine: the one-wave-per-SIMD kernel (gemm_tn_ow.hip; 32-bit slice offsets); MAEST_OPT_GEMM_VARIANT = 3
+    // keeps the 8-wave kernel (A/B, tests)
+    if (!x3 && dtype == MAEST_BF16 && !use_ws && option(MAEST_OPT_GEMM_VARIANT) != 3 &&
+        (int64_t)K * lda * 2 < ((int64_t)1 << 31) && (int64_t)K * ldb * 2 < ((int64_t)1 << 31))
+        return gemm_tn256o_launch(p, split_k, stream);
     if (x3) return launch_tn256<float, true>(p, split_k, stream);
     return dtype == MAEST_BF16 ? launch_tn256<bf16_t>(p, split_k, stream) : launch_tn256<float>(p, split_k, stream);
 }

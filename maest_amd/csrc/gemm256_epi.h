@@ -148,6 +148,20 @@ __device__ __forceinline__ void drainT(const char* smem, int rows, void* dst, in
     }
 }
 
+struct GemmTn256Params {
+    const char* A;
+    const char* B;
+    float* C;
+    float* colsum;
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    int k_slices_per_split, split_k;
+    float* ws;      // NULL: the split-K partials are added to C with fp32 atomics; else [split][tile][wave][32 chunks][64 lanes][4] fp32
+};
+// gemm_tn_ow.hip: the one-wave-per-SIMD 256 x 256 wgrad kernel (bf16 operands, atomic split-K combine: p.ws == NULL)
+int gemm_tn256o_launch(GemmTn256Params& p, int split_k, hipStream_t stream);
+
 // gemm_nt_ow.hip: the one-wave-per-SIMD 256 x 256 kernel (bf16 operands; N % 256 == 0, K % 64 == 0, no ROWDOT epilogue, fp32
 // output for RESIDUAL, bf16 output for the GELU + GELU' pair)
 int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream);

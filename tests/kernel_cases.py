@@ -128,7 +128,7 @@ def case_gemm_rowdot(dev, dtype, M, N, K, ntok, seed=7):
     close(rd, want, 1e-5, 1e-5 * math.sqrt(64) * float(c.float().abs().max()), "gemm rowdot: per-(row, group) dot products")
 
 
-def case_gemm_tn(dev, dtype, K, M, N, seed=3, lda_pad=0):
+def case_gemm_tn(dev, dtype, K, M, N, seed=3, lda_pad=0, splits=(1, 3, 0)):
     """wgrad form: out[M,N] += a[K,M]^T b[K,N], colsum[M] += a.sum(0); ragged K (token tail)."""
     a_full = rnd((K, M + lda_pad), seed).to(dtype)
     a = a_full[:, :M]
@@ -136,7 +136,7 @@ def case_gemm_tn(dev, dtype, K, M, N, seed=3, lda_pad=0):
     ref = a.float().t() @ b.float()
     ref_cs = a.float().sum(0)
     at = 4e-7 * K + (0 if dtype == torch.float32 else 1e-3)
-    for sk in (1, 3, 0):
+    for sk in splits:
         out = torch.zeros((M, N), dtype=torch.float32, device=dev)
         cs = torch.zeros(M, dtype=torch.float32, device=dev)
         a_dev = a_full.to(dev)[:, :M]

@@ -79,6 +79,15 @@ def test_emu_gemm_tn_256_tile_lds_dma_kernel(emu, dtype, gemm_options):
     KC.case_gemm_tn(emu, dtype, 288 if dtype == torch.bfloat16 else 144, 256, 512)
 
 
+def test_emu_gemm_tn_one_wave_per_simd_kernel(emu, gemm_options):
+    """gemm_tn256o_kernel's host twin (gemm_tn_ow.hip; the bf16 case of the test above runs it with 9 and 3 slices per workgroup):
+    5 and 4 slices (split_k = 2 of 9: the prologue's A-half-of-slice-4 form and the short one, slice kinds 1 and 0 first) and 12
+    (two trips round the five-buffer ring).  The workspace form inside case_gemm_tn keeps running the 8-wave kernel."""
+    gemm_options(gemm_variant=4)
+    KC.case_gemm_tn(emu, torch.bfloat16, 288, 256, 512, splits=(2,))
+    KC.case_gemm_tn(emu, torch.bfloat16, 384, 256, 256, splits=(1,))
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_emu_gemm_tn(emu, dtype):
     KC.case_gemm_tn(emu, dtype, 150, 136, 200)

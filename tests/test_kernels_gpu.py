@@ -81,6 +81,16 @@ def test_gemm_tn(dtype, shape):
         KC.case_gemm_tn(DEV, dtype, K, M, N)
 
 
+@pytest.mark.parametrize("shape", [(74240, 768, 768), (9280, 2304, 768), (8352, 768, 3072), (160 * 32, 3072, 768)])
+def test_gemm_tn_one_wave_per_simd_kernel(shape, gemm_options):
+    """gemm_tn256o_kernel (bf16, the default 256 x 256 wgrad kernel) at the production shapes, automatic and forced splits, against the
+    oracle's fp32 matmul -- and the 8-wave kernel it replaces on the same operands (gemm_variant = 3)"""
+    K, M, N = shape
+    KC.case_gemm_tn(DEV, torch.bfloat16, K, M, N, splits=(0, 1, 5, 29))
+    gemm_options(gemm_variant=3)
+    KC.case_gemm_tn(DEV, torch.bfloat16, K, M, N, splits=(0,))
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_gemm_ragged_n(dtype):
     KC.case_gemm(DEV, dtype, 300, 519, 768)
