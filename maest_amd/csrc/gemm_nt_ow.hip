@@ -14,8 +14,10 @@
 //     MFMAs, issued one k-step ahead in the shadow of the MFMAs of the running k-step: the statements below execute in program
 //     order, so the source is the schedule -- one instruction stream per SIMD, no wave to take turns with, ONE barrier per stage;
 //   * the operand ring is gemm_nt256w_kernel's: 128-byte rows (whole cache lines), units A_j / B_j of 256 rows = 32 KiB through five
-//     buffers, source-side swizzle  chunk ^= (row >> 1) & 7,  LDS-DMA requests dealt out between the MFMAs (8 behind the stage's
-//     barrier, 4 + 4 in the next two k-steps), a counted vmcnt(8) in front of the barrier (only the unit requested last may fly);
+//     buffers, source-side swizzle  chunk ^= (row >> 1) & 7,  LDS-DMA requests dealt out between the MFMAs (four per k-step), a
+//     counted vmcnt(8) in front of the barrier (only the unit requested last may fly);
+//   * the stage loop is unrolled over the ring's period with one body per stage kind, so that a stage boundary costs a counter, a
+//     compare and a branch not taken: with one wave per SIMD every scalar instruction in front of an MFMA is a bubble in the pipe;
 //   * the first k-step's MFMAs take the constant 0 as their C operand (no clearing pass over 256 registers).
 // The C tile leaves through LDS in four 64-row passes, double buffered, with the bias / GELU / GELU' / residual / multiply
 // epilogues of gemm256_epi.h.
@@ -41,9 +43,6 @@ constexpr int OW_V_LO = 192, OW_V_HI = 255;   // (the audited range)
 #else
 #define OW_DEV 0
 #endif
-#ifndef OW_SPREAD
-#define OW_SPREAD 1       // a stage's 16 LDS-DMA requests: 1 = four per k-step (B's halves in k-steps 3 and 0, A's in 1 and 2); 0 = 8 in
-#endif                    // k-step 3 (B), 4 + 4 in k-steps 0, 1 (A)
 #ifndef OW_ABLATE
 #define OW_ABLATE 0       // timing experiments only (results wrong on purpose): bit 0 no LDS-DMA requests, 1 no barrier / vmcnt wait,
 #endif                    // 2 no MFMAs, 3 no fragment reads, 4 no epilogue
@@ -406,18 +405,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
     c.tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin = c.tprev;
 #endif
-    // prologue: units 0 .. 4 = A_0 B_0 A_1 B_1 A_2 as far as they exist (unit 2 j + (B ? 1 : 0) lives in buffer unit % 5)
+    // prologue: A_0 B_0, then A_1 and the first half of B_1 (unit 2 j + (B ? 1 : 0) lives in buffer unit % 5) -- what stage 0 would
+    // find requested by a stage "-1"; everything else rides in stage 0's k-steps like in any other stage.  (All five units up front
+    // cost 160 requests of the CU's memory front end before the first MFMA: 30 % more prologue for nothing.)
     request(abase, voa, 0);
     request(bbase, vob, 1);
-    if (nstages > 2) {
+    if (nstages > 1) {
         request(abase, voa, 2);
-        request(bbase, vob, 3);
-        request(abase, voa, 4);
-        ow_wait_vm<24>();             // stage 0 has landed (this wave's share): A_1 B_1 A_2 may fly
-    } else if (nstages > 1) {
-        request(abase, voa, 2);
-        request(bbase, vob, 3);
-        ow_wait_vm<16>();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ow_dma(bbase, vob[i], piece0 + (uint32_t)(3 * OW_UNIT + i * 1024), c);
+        ow_wait_vm<12>();             // stage 0 has landed (this wave's share): A_1 and half of B_1 may fly
     } else {
         ow_wait_vm<0>();
     }
@@ -432,10 +429,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
     // first one behind the stage's barrier; the last stage reads the ring's next buffers there: stale bytes nobody multiplies).
     // The barrier b_j stands between k-steps 2 and 3: in front of it every wave has read its last fragments of stage j
     // (lgkmcnt(0)) and has seen its pieces of stage j + 1 land (vmcnt(8): only A_{j+2}, requested last, may fly), so behind it
-    // stage j + 1 may be read and stage j's two buffers refilled:
-    //   k-step 3 of stage j:        B_{j+2} -> A_j's buffer (8 requests)
-    //   k-steps 0, 1 of stage j+1:  A_{j+3} -> B_j's buffer (4 + 4)
-    // i.e. a unit has at least 3 k-steps (1536 matrix-pipe cycles) to land.  Stage 0 finds A_1 B_1 A_2 requested by the prologue.
+    // stage j + 1 may be read and stage j's two buffers refilled, four requests per k-step (the memory front end takes a request
+    // per ~30 cycles and CU: a burst of 8 per wave parks the waves in its queue, measured +100 cycles per stage):
+    //   k-step 3 of stage j:           first half of B_{j+2} -> A_j's buffer
+    //   k-step 0 of stage j+1:         second half of B_{j+2}
+    //   k-steps 1, 2 of stage j+1:     A_{j+3} -> B_j's buffer
+    // i.e. a request has at least 2.5 k-steps to land.  Stage 0 is a stage like any other (its first MFMAs take C = 0).
     // The stage loop is unrolled over the ring's period (PH = j % 5): buffer addresses are constants, the per-stage scalar work is
     // a counter and two compares -- with one wave per SIMD every scalar instruction in front of an MFMA is a bubble in the pipe.
     // KIND 2: the units A_{j+2}, B_{j+2} exist (j + 2 < nstages); 1: the last stage but one (B_{j+1}'s second half is still to be
@@ -450,28 +449,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
         OW_TICK(0);
         ow_wait_lds();
         OW_TICK(1);
-#if OW_SPREAD == 1
         // B_{j+1}'s second half -> A_{j-1}'s buffer (= B_{j+1}'s), then A_{j+2} in k-steps 1 and 2, B_{j+2}'s first half in k-step 3
-        ow_step<0, FIRST, (!FIRST && KIND >= 1) ? 4 : 0, 4>(c, la + c.pa[1], lb + c.pb[1], bbase, vob, piece0 + (uint32_t)(BBUF_N * OW_UNIT));
+        ow_step<0, FIRST, KIND >= 1 ? 4 : 0, 4>(c, la + c.pa[1], lb + c.pb[1], bbase, vob, piece0 + (uint32_t)(BBUF_N * OW_UNIT));
         OW_TICK(2);
         ow_wait_lds();
         OW_TICK(3);
-        ow_step<1, false, (!FIRST && KIND == 2) ? 4 : 0, 0>(c, la + c.pa[2], lb + c.pb[2], abase, voa, dst_a);
+        ow_step<1, false, KIND == 2 ? 4 : 0, 0>(c, la + c.pa[2], lb + c.pb[2], abase, voa, dst_a);
         OW_TICK(4);
         ow_wait_lds();
         OW_TICK(5);
-        ow_step<2, false, (!FIRST && KIND == 2) ? 4 : 0, 4>(c, la + c.pa[3], lb + c.pb[3], abase, voa, dst_a);
-#else
-        ow_step<0, FIRST, (!FIRST && KIND == 2) ? 4 : 0, 0>(c, la + c.pa[1], lb + c.pb[1], abase, voa, dst_a);
-        OW_TICK(2);
-        ow_wait_lds();
-        OW_TICK(3);
-        ow_step<1, false, (!FIRST && KIND == 2) ? 4 : 0, 4>(c, la + c.pa[2], lb + c.pb[2], abase, voa, dst_a);
-        OW_TICK(4);
-        ow_wait_lds();
-        OW_TICK(5);
-        ow_step<2, false, 0, 0>(c, la + c.pa[3], lb + c.pb[3], abase, voa, 0u);
-#endif
+        ow_step<2, false, KIND == 2 ? 4 : 0, 4>(c, la + c.pa[3], lb + c.pb[3], abase, voa, dst_a);
         OW_TICK(6);
         ow_wait_lds();
         OW_TICK(7);
@@ -479,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
         OW_TICK(8);
         ow_barrier();                 // b_j
         OW_TICK(9);
-        ow_step<3, false, (KIND == 2 ? (OW_SPREAD == 1 ? 4 : 8) : 0), 0>(c, c.lds0 + (uint32_t)(ABUF_N * OW_UNIT) + c.pa[0],
+        ow_step<3, false, (KIND == 2 ? 4 : 0), 0>(c, c.lds0 + (uint32_t)(ABUF_N * OW_UNIT) + c.pa[0],
                                                                         c.lds0 + (uint32_t)(BBUF_N * OW_UNIT) + c.pb[0], bbase, vob,
                                                                         piece0 + (uint32_t)(ABUF * OW_UNIT));
     };
@@ -499,6 +486,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
     {
         using std::integral_constant;
         if (nstages > 2) stage_body(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, 2>{});
+        else if (nstages > 1) stage_body(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, 1>{});
         else stage_body(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, 0>{});
         int j = 1, ph = 1;
         run(integral_constant<int, 2>{}, j, nstages - 2, ph);

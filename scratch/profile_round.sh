@@ -40,7 +40,7 @@ fetch_factor = None
 if ln and "FETCH_SIZE" in ln:
     fetch_factor = (74240 * 768 * 4) / ln["FETCH_SIZE"]["avg_bytes"]
 write_factor = (74240 * 768 * 2) / ln["WRITE_SIZE"]["avg_bytes"] if ln and "WRITE_SIZE" in ln else None
-nt = {k: v for k, v in bench.items() if "gemm_nt256w" in k}
+nt = {k: v for k, v in bench.items() if "gemm_nt256w" in k or "gemm_nt256o" in k}
 steps = 4   # 1 warm-up + 3 steps profiled
 # per GEMM CALL (bench.py times a call, i.e. the 256-row-tile launch plus, where the last partial round is split off, the
 # 128-row-tile launch behind it): 91 calls per training step
@@ -51,7 +51,7 @@ fetch = sum(cs["FETCH_SIZE"][1] for cs in nt.values()) * 1024 / calls
 write = sum(cs["WRITE_SIZE"][1] for cs in nt.values()) * 1024 / calls
 out = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 "
                  f"--no-cpu-baseline --no-kernel-timing --serial-kernels  (scratch/profile_round.sh {TAG})",
-       "kernel": "gemm_nt256w_kernel<bf16, ...> (256-row and 128-row tile instantiations: all launches of a step)",
+       "kernel": "gemm_nt256o_kernel (bf16, one wave per SIMD) + gemm_nt256w_kernel<bf16, ...> (128-row tail tiles, row-dot form): all launches of a step",
        "launches_per_step": launches // steps, "kernel_launches_per_step": kernel_launches // steps,
        "fetch_bytes_per_launch_raw": fetch, "write_bytes_per_launch": write,
        "fetch_correction": "x2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM section)",
