@@ -66,7 +66,7 @@ SIGNATURES = {
 
 ABI_VERSION = 5
 OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "ln_bwd_blocks": 4, "gemm_tail": 5, "attn_fwd": 6, "attn_fwd_waves": 7,
-           "tn_reduce": 8}
+           "tn_reduce": 8, "gemm_wgs": 9}
 
 _lib = None
 _host_emulation = False  # set only by tests/emu

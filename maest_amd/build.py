@@ -12,7 +12,7 @@ SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "gemm_nt_ow.hip", "gemm_tn_ow.
 
 
 # sources whose inline asm owns fixed registers: {file: (first, last owned arch VGPR)}; all accumulator registers are owned too
-AUDITED = {"attn_fwd_pw.hip": (96, 245), "gemm_nt_ow.hip": (192, 255), "gemm_tn_ow.hip": (176, 255)}
+AUDITED = {"attn_fwd_pw.hip": (96, 245), "gemm_nt_ow.hip": (188, 255, True), "gemm_tn_ow.hip": (176, 255)}
 
 
 def _hipcc():
@@ -55,9 +55,10 @@ def build(force=False, verbose=True):
             sys.stderr.write(out.decode())
     # kernels that own registers by hand: the compiler must have stayed out of them (maest_amd/pw_audit.py)
     from maest_amd import pw_audit
-    for name, (lo, hi) in AUDITED.items():
+    for name, rng in AUDITED.items():
+        lo, hi, regions = rng[0], rng[1], len(rng) > 2
         asm = os.path.join(HERE, "build", os.path.splitext(name)[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
-        bad, maxv, meta = pw_audit.audit(asm, lo, hi)
+        bad, maxv, meta = pw_audit.audit(asm, lo, hi, regions)
         if bad:
             for n, why, st in bad[:20]:
                 sys.stderr.write(f"{name}: line {n}: {why}: {st}\n")

@@ -33,10 +33,13 @@ namespace maest {
 constexpr int OW_UNIT = 256 * 128;            // one operand unit: 256 rows x 128 B
 constexpr int OW_NBUF = 5;
 constexpr int OW_SMEM = OW_NBUF * OW_UNIT;    // 163840: the whole LDS, one workgroup per CU
+constexpr int OW_EPI0 = 2 * OW_UNIT;          // the C staging area starts behind the ring's first two units
 // register map (device build): accumulator tile (nt, mt) = a[16 (4 nt + mt) ..+15]; fragment set s (k-step parity):
 // A[mt] = v[192 + 32 s + 4 mt ..+3], B[nt] = v[208 + 32 s + 4 nt ..+3]
 constexpr int OW_V_F = 192;
-constexpr int OW_V_LO = 192, OW_V_HI = 255;   // (the audited range)
+constexpr int OW_V_BIAS = 188;                // this lane's four bias values of the tile (columns 4 lane ..+3), tile top -> epilogue
+constexpr int OW_V_LO = 188, OW_V_HI = 255;   // (the audited range)
+constexpr int OW_BIAS0 = 2 * 33792;           // the bias row's place in the C staging area: behind the largest staging buffer
 
 #if defined(__AMDGCN__)
 #define OW_DEV 1
@@ -56,8 +59,16 @@ __device__ unsigned long long* g_ow_prof = nullptr;
 #define OW_TICK(slot) ((void)0)
 #endif
 
+// The fragment and bias registers (OW_FRAGS, on every main-loop statement) and the whole accumulator half (OW_ACCS, on the waits and
+// barriers only: four statements per stage keep hipcc from parking a value there across the loop; on every statement they cost minutes
+// of compile time), as clobber lists on every main-loop statement: hipcc may then use v192 .. v255 for values that do not live
+// across the main loop (the epilogue, which needs them), and must keep everything else out of them.
+#define OW_FRAGS "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+#define OW_ACCS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+
 struct OwCtx {
-    uint32_t pa[4], pb[4];       // LDS byte offsets of this lane's A / B row chunk of k-step 0 .. 3 (without buffer and tile offset)
+    uint32_t pa[3][4], pb[3][4]; // LDS addresses of this lane's A / B row chunk of k-step 0 .. 3 in ring buffers 0, 2, 4 (buffers 1, 3 and
+                                 // the wave's m- / n-tile go into the read's immediate offset: nothing per stage is left to compute)
     uint32_t lds0;               // LDS address of the dynamic segment
     int wave;                    // (wave-uniform)
 #ifdef OW_PROF
@@ -67,19 +78,20 @@ struct OwCtx {
 #if !OW_DEV
     f32x16_t acc[4][4];          // (host emulator: the state the device keeps in owned registers)
     chunk16 fa[2][4], fb[2][4];
+    f32x4_t bias;
     char* lds;
 #endif
 };
 
 // fragment read: one ds_read_b128 = this lane's 16-byte chunk of row (tile T) of the A (ISB = false) or B operand
-template <int SET, int T, bool ISB>
+template <int SET, int T, bool ISB, int OFF = 0>
 __device__ __forceinline__ void ow_read(OwCtx& c, uint32_t addr) {
 #if OW_DEV
     constexpr int V = OW_V_F + 32 * SET + (ISB ? 16 : 0) + 4 * T;
     if (!(OW_ABLATE & 8))
-        asm volatile("ds_read_b128 v[%c1:%c2], %0 offset:%c3" : : "v"(addr), "i"(V), "i"(V + 3), "i"(T * 4096));
+        asm volatile("ds_read_b128 v[%c1:%c2], %0 offset:%c3" : : "v"(addr), "i"(V), "i"(V + 3), "i"(OFF + T * 4096) : OW_FRAGS);
 #else
-    const chunk16 v = *reinterpret_cast<const chunk16*>(c.lds + addr + T * 4096);
+    const chunk16 v = *reinterpret_cast<const chunk16*>(c.lds + addr + OFF + T * 4096);
     if (ISB) c.fb[SET][T] = v;
     else c.fa[SET][T] = v;
 #endif
@@ -92,10 +104,10 @@ __device__ __forceinline__ void ow_mfma(OwCtx& c) {
     if (OW_ABLATE & 4) return;
     if constexpr (ZERO)
         asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], 0"
-                     : : "i"(D), "i"(D + 15), "i"(B), "i"(B + 3), "i"(A), "i"(A + 3));
+                     : : "i"(D), "i"(D + 15), "i"(B), "i"(B + 3), "i"(A), "i"(A + 3) : OW_FRAGS);
     else
         asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], a[%c0:%c1]"
-                     : : "i"(D), "i"(D + 15), "i"(B), "i"(B + 3), "i"(A), "i"(A + 3));
+                     : : "i"(D), "i"(D + 15), "i"(B), "i"(B + 3), "i"(A), "i"(A + 3) : OW_FRAGS);
 #else
     if (ZERO) {
 #pragma unroll
@@ -107,15 +119,16 @@ __device__ __forceinline__ void ow_mfma(OwCtx& c) {
 // One LDS-DMA request (1 KiB = 8 rows x 128 B): lane l's 16 bytes come from base + voff (base wave-uniform, in SGPRs) and land at
 // LDS address dst + 16 l; voff then moves on to the next K stage (+ 128 bytes), inside the same statement so that the add rides in
 // the request's slot.  Inline asm so that hipcc does not count it (attn_common.h: dma16); M0 is left holding the address.
-__device__ __forceinline__ void ow_dma(const char* base, uint32_t& voff, uint32_t dst, OwCtx& c) {
+template <int DST>               // DST: byte offset of the piece from the wave's first piece of ring buffer 0 (`piece0`, an SGPR)
+__device__ __forceinline__ void ow_dma(const char* base, uint32_t& voff, uint32_t piece0, OwCtx& c) {
 #if OW_DEV
     if (OW_ABLATE & 1) return;
-    const uint32_t lds = __builtin_amdgcn_readfirstlane(dst);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tv_add_u32 %0, 0x80, %0"
-                 : "+v"(voff) : "s"(base), "s"(lds) : "memory");
+    const uint32_t lds = __builtin_amdgcn_readfirstlane(piece0);
+    asm volatile("s_add_u32 m0, %2, %c3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tv_add_u32 %0, 0x80, %0"
+                 : "+v"(voff) : "s"(base), "s"(lds), "i"(DST) : "memory", "scc", OW_FRAGS);
 #else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff),
-                                     (__attribute__((address_space(3))) void*)(c.lds + dst), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(c.lds + piece0 + DST), 16, 0, 0);
     voff += 128;
 #endif
 }
@@ -123,20 +136,48 @@ template <int N>
 __device__ __forceinline__ void ow_wait_vm() {       // all but this wave's N newest LDS-DMA requests have landed
 #if OW_DEV
     if (OW_ABLATE & 2) return;
-    asm volatile("s_waitcnt vmcnt(%c0)" : : "i"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%c0)" : : "i"(N) : "memory", OW_FRAGS);
 #endif
 }
 __device__ __forceinline__ void ow_wait_lds() {      // every fragment read this wave has issued (hipcc does not count the asm ones)
 #if OW_DEV
-    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory", OW_FRAGS, OW_ACCS);
 #endif
 }
 __device__ __forceinline__ void ow_barrier() {
 #if OW_DEV
     if (OW_ABLATE & 2) return;
-    asm volatile("s_barrier" : : : "memory");
+    asm volatile("s_barrier" : : : "memory", OW_FRAGS, OW_ACCS);
 #else
     __syncthreads();
+#endif
+}
+// the epilogue's barrier: LDS traffic only, and no claim on the fragment registers (hipcc's values may sit in them there)
+__device__ __forceinline__ void ow_sync_epilogue() {
+#if OW_DEV
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+#else
+    __syncthreads();
+#endif
+}
+// The tile's bias row: requested at the tile's top into owned registers (a value hipcc holds across the main loop ends up in the
+// accumulator half under this kernel's register pressure), stored to LDS when the ring has been drained.
+__device__ __forceinline__ void ow_bias_load(OwCtx& c, const float* src) {      // src == nullptr: zeros
+#if OW_DEV
+    if (src != nullptr)
+        asm volatile("global_load_dwordx4 v[%c1:%c2], %0, off" : : "v"(src), "i"(OW_V_BIAS), "i"(OW_V_BIAS + 3) : "memory", OW_FRAGS);
+    else
+        asm volatile("v_mov_b32 v%c0, 0\n\tv_mov_b32 v%c1, 0\n\tv_mov_b32 v%c2, 0\n\tv_mov_b32 v%c3, 0"
+                     : : "i"(OW_V_BIAS), "i"(OW_V_BIAS + 1), "i"(OW_V_BIAS + 2), "i"(OW_V_BIAS + 3) : OW_FRAGS);
+#else
+    c.bias = src != nullptr ? *reinterpret_cast<const f32x4_t*>(src) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#endif
+}
+__device__ __forceinline__ void ow_bias_store(OwCtx& c, uint32_t addr) {        // (behind a vmcnt(0))
+#if OW_DEV
+    asm volatile("ds_write_b128 %0, v[%c1:%c2]" : : "v"(addr), "i"(OW_V_BIAS), "i"(OW_V_BIAS + 3) : "memory");
+#else
+    *reinterpret_cast<f32x4_t*>(c.lds + addr) = c.bias;
 #endif
 }
 #if OW_DEV
@@ -167,30 +208,28 @@ __device__ __forceinline__ f32x16_t ow_acc_read(OwCtx& c) {
 // carry the fragment reads of the NEXT k-step (A tiles 0 .. 3, then B tiles 0 .. 3) into the other set, slots 8 .. 15 this
 // wave's LDS-DMA requests into the unit buffer at LDS address dst: NDMA = 8 one per slot (pieces 0 .. 7), NDMA = 4 every other
 // slot (pieces I0 .. I0 + 3).
-template <int S, int Q, bool ZERO, int NDMA, int I0>
-__device__ __forceinline__ void ow_slot(OwCtx& c, uint32_t ra, uint32_t rb, const char* base, uint32_t (&vo)[8], uint32_t dst) {
+template <int S, int Q, bool ZERO, int NDMA, int I0, int RA, int RB, int KS, int DBUF>
+__device__ __forceinline__ void ow_slot(OwCtx& c, const char* base, uint32_t (&vo)[8], uint32_t piece0) {
     constexpr int SET = S & 1;
     ow_mfma<SET, (Q >> 2), (Q & 3), ZERO>(c);
     if constexpr (Q < 4) {
-        ow_read<SET ^ 1, Q, false>(c, ra);
+        ow_read<SET ^ 1, Q, false, (RA & 1) * OW_UNIT>(c, c.pa[RA >> 1][KS]);
     } else if constexpr (Q < 8) {
-        ow_read<SET ^ 1, Q - 4, true>(c, rb);
-    } else if constexpr (NDMA == 8) {
-        ow_dma(base, vo[Q - 8], dst + (Q - 8) * 1024, c);
+        ow_read<SET ^ 1, Q - 4, true, (RB & 1) * OW_UNIT>(c, c.pb[RB >> 1][KS]);
     } else if constexpr (NDMA == 4 && (Q & 1) == 0) {
         constexpr int I = I0 + ((Q - 8) >> 1);
-        ow_dma(base, vo[I], dst + I * 1024, c);
+        ow_dma<DBUF * OW_UNIT + I * 1024>(base, vo[I], piece0, c);
     }
 }
-template <int S, bool ZERO, int NDMA, int I0, int... Q>
-__device__ __forceinline__ void ow_step_slots(OwCtx& c, uint32_t ra, uint32_t rb, const char* base, uint32_t (&vo)[8],
-                                              uint32_t dst, std::integer_sequence<int, Q...>) {
-    (ow_slot<S, Q, ZERO, NDMA, I0>(c, ra, rb, base, vo, dst), ...);
+template <int S, bool ZERO, int NDMA, int I0, int RA, int RB, int KS, int DBUF, int... Q>
+__device__ __forceinline__ void ow_step_slots(OwCtx& c, const char* base, uint32_t (&vo)[8], uint32_t piece0,
+                                              std::integer_sequence<int, Q...>) {
+    (ow_slot<S, Q, ZERO, NDMA, I0, RA, RB, KS, DBUF>(c, base, vo, piece0), ...);
 }
-template <int S, bool ZERO, int NDMA, int I0>
-__device__ __forceinline__ void ow_step(OwCtx& c, uint32_t ra, uint32_t rb, const char* base, uint32_t (&vo)[8],
-                                        uint32_t dst) {
-    ow_step_slots<S, ZERO, NDMA, I0>(c, ra, rb, base, vo, dst, std::make_integer_sequence<int, 16>{});
+// k-step S: reads k-step KS of the operand units in ring buffers RA / RB, requests pieces I0 .. I0 + 3 (NDMA = 4) into buffer DBUF
+template <int S, bool ZERO, int NDMA, int I0, int RA, int RB, int KS, int DBUF>
+__device__ __forceinline__ void ow_step(OwCtx& c, const char* base, uint32_t (&vo)[8], uint32_t piece0) {
+    ow_step_slots<S, ZERO, NDMA, I0, RA, RB, KS, DBUF>(c, base, vo, piece0, std::make_integer_sequence<int, 16>{});
 }
 
 // ---- C tile -> LDS -> HBM: four passes, pass ps = m-tile ps of both wave rows (tile rows 128 wm + 32 ps ..+31: every wave stages
@@ -200,28 +239,26 @@ __device__ __forceinline__ void ow_step(OwCtx& c, uint32_t ra, uint32_t rb, cons
 // global load per use was two thirds of this epilogue), a pass's LDS reads are issued as one batch, and the second operand of
 // the RESIDUAL / MUL forms is fetched into registers a pass ahead (AuxRegs), behind the previous pass's drain.
 // GMODE: 0 none, 1 GELU, 3 GELU + GELU' side output; MODE: 0 plain, 1 RESIDUAL (+ aux), 2 MUL (* aux)
-template <int OSZ, int GMODE, int MODE>
-__device__ __forceinline__ void ow_epilogue_run(char* smem, OwCtx& c, const Gemm256Params& p, int m0, int n0, int wm, int wn,
-                                                int lane, int tid, const f32x4_t& bias_reg) {
+template <int OSZ, int GMODE, int MODE, typename NEXT>
+__device__ __forceinline__ void ow_epilogue_run(char* smem0, OwCtx& c, const Gemm256Params& p, int m0, int n0, int wm, int wn,
+                                                int lane, int tid, NEXT&& request_next) {
     using E = EpiT<OSZ, 256>;
     constexpr bool PAIR = GMODE == 3;
     constexpr int REGION = 64 * E::PITCH;                       // one 64-row staging region: 33792 / 66560
     constexpr int BUF = (PAIR ? 2 : 1) * REGION;
-    constexpr int BIAS0 = 2 * BUF;                              // 256 floats behind the two staging buffers
-    static_assert(BIAS0 + 1024 <= OW_SMEM, "two staging buffers and the bias row");
+    constexpr int BIAS0 = OW_BIAS0;                             // 256 floats behind the (largest) staging buffer, stored by the caller
+    static_assert(BUF <= OW_BIAS0 && OW_EPI0 + BIAS0 + 1024 <= OW_SMEM, "the staging buffer and the bias row");
+    char* smem = smem0 + OW_EPI0;                               // (the ring's first two units stay free for the next tile's A_0 B_0)
     constexpr int NCH = 32 * E::CPR / 256;                      // 16-byte chunks per thread and 32-row group: 4 / 8
     constexpr int RS = 256 / E::CPR;                            // rows between a thread's consecutive chunks: 8 / 4
     const int h = lane >> 5;
-    if (tid < 64) *reinterpret_cast<f32x4_t*>(smem + BIAS0 + tid * 16) = bias_reg;
-    __syncthreads();
-    // this lane's 16 bias quadruples (columns 128 wn + 32 nt + 8 g + 4 h ..+3), read once: the same for all four passes
-    f32x4_t b4[4][4];
+    // this lane's bias quadruples (columns 128 wn + 32 nt + 8 g + 4 h ..+3) come out of LDS one n-tile ahead of their use (4 registers x
+    // 4 instead of 64 held through the epilogue: the persistent loop needs the registers)
+    auto bias_tile = [&](int nt, f32x4_t (&b)[4]) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            b4[nt][g] = *reinterpret_cast<const f32x4_t*>(smem + BIAS0 + (wn * 128 + nt * 32 + 8 * g + 4 * h) * 4);
-    auto stage_tile = [&](auto nt_tag, auto ps_tag, char* row) {
+        for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4_t*>(smem + BIAS0 + (wn * 128 + nt * 32 + 8 * g + 4 * h) * 4);
+    };
+    auto stage_tile = [&](auto nt_tag, auto ps_tag, char* row, const f32x4_t (&b4)[4]) {
         constexpr int NT = decltype(nt_tag)::value, PS = decltype(ps_tag)::value;
         const f32x16_t t = ow_acc_read<NT, PS>(c);
 #pragma unroll
@@ -229,7 +266,7 @@ __device__ __forceinline__ void ow_epilogue_run(char* smem, OwCtx& c, const Gemm
             float v[4], d[4];
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
-                const f32x2_t xv = {t[4 * g + e] + b4[NT][g][e], t[4 * g + e + 1] + b4[NT][g][e + 1]};
+                const f32x2_t xv = {t[4 * g + e] + b4[g][e], t[4 * g + e + 1] + b4[g][e + 1]};
                 f32x2_t gv = xv, dv = {0.0f, 0.0f};
                 if (GMODE != 0) gelu_pair2<false>(xv, gv, dv);
                 v[e] = gv[0]; v[e + 1] = gv[1];
@@ -254,10 +291,15 @@ __device__ __forceinline__ void ow_epilogue_run(char* smem, OwCtx& c, const Gemm
     auto stage = [&](auto ps_tag, char* buf) {
         using std::integral_constant;
         char* row = buf + (wm * 32 + (lane & 31)) * E::PITCH + (wn * 128 + 4 * h) * OSZ;
-        stage_tile(integral_constant<int, 0>{}, ps_tag, row);
-        stage_tile(integral_constant<int, 1>{}, ps_tag, row);
-        stage_tile(integral_constant<int, 2>{}, ps_tag, row);
-        stage_tile(integral_constant<int, 3>{}, ps_tag, row);
+        f32x4_t b0[4], b1[4];
+        bias_tile(0, b0);
+        bias_tile(1, b1);
+        stage_tile(integral_constant<int, 0>{}, ps_tag, row, b0);
+        bias_tile(2, b0);
+        stage_tile(integral_constant<int, 1>{}, ps_tag, row, b1);
+        bias_tile(3, b1);
+        stage_tile(integral_constant<int, 2>{}, ps_tag, row, b0);
+        stage_tile(integral_constant<int, 3>{}, ps_tag, row, b1);
     };
     // drain: thread t moves chunk cc = t % CPR of rows r0 + RS i (r0 = t / CPR) of a 32-row group; its pointers into C / aux are
     // formed once, a group's rows are wave-uniform multiples of the row pitch away.  Rows beyond M exist in the last tile row only.
@@ -265,7 +307,10 @@ __device__ __forceinline__ void ow_epilogue_run(char* smem, OwCtx& c, const Gemm
     const bool full = m0 + 256 <= p.M;                          // (block-uniform)
     const int64_t col = (int64_t)(n0 + cc * E::EPC) * OSZ;
     char* c_thr = reinterpret_cast<char*>(p.C) + (int64_t)(m0 + r0) * p.ldc * OSZ + col;
-    const int64_t c_row = p.ldc * OSZ, x_row = p.ld_aux * OSZ;  // (aux_in and aux_out have the output's element size)
+    int64_t c_row = p.ldc * OSZ, x_row = p.ld_aux * OSZ;        // (aux_in and aux_out have the output's element size)
+#if OW_DEV
+    asm volatile("" : "+s"(c_row), "+s"(x_row));                // (their multiples are formed where they are used, not in front of the tile loop)
+#endif
     const char* a_col = reinterpret_cast<const char*>(p.aux_in) + col;
     const char* a_thr = a_col + (int64_t)(m0 + r0) * x_row;
     char* o_thr = reinterpret_cast<char*>(p.aux_out) + (int64_t)(m0 + r0) * x_row + col;
@@ -303,49 +348,60 @@ __device__ __forceinline__ void ow_epilogue_run(char* smem, OwCtx& c, const Gemm
             if (PAIR) drain_one(src + REGION, o_thr, x_row, nullptr, half * 128 + ps * 32);
         }
     };
+    // One staging buffer: a pass is  stage -> barrier -> drain (its LDS reads, then the stores) -> barrier.  The barriers are raw
+    // (LDS traffic only: __syncthreads would also wait for every store and for the next tile's requests).  The next tile's A_0 / B_0
+    // are requested as early as no load of this epilogue can queue up behind them (loads return in order): at once without a second
+    // operand, behind the last pass's operand fetch otherwise.
     using std::integral_constant;
+    auto sync = [&]() { ow_sync_epilogue(); };
+    auto consume_aux = [&]() {          // every ax register has arrived (hipcc places the wait) before what follows is issued
+#if OW_DEV
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(ax[half][i]));
+#endif
+    };
+    if (MODE == 0) request_next();
     if (MODE != 0) prefetch(0);
     stage(integral_constant<int, 0>{}, smem);
     OW_TICK(13);
-    __syncthreads();
+    sync();
     OW_TICK(14);
     drain(0, smem);
     OW_TICK(15);
     if (MODE != 0) prefetch(1);
-    stage(integral_constant<int, 1>{}, smem + BUF);
+    sync();
+    stage(integral_constant<int, 1>{}, smem);
     OW_TICK(13);
-    __syncthreads();
+    sync();
     OW_TICK(14);
-    drain(1, smem + BUF);
+    drain(1, smem);
     OW_TICK(15);
     if (MODE != 0) prefetch(2);
+    sync();
     stage(integral_constant<int, 2>{}, smem);
     OW_TICK(13);
-    __syncthreads();
+    sync();
     OW_TICK(14);
     drain(2, smem);
     OW_TICK(15);
     if (MODE != 0) prefetch(3);
-    stage(integral_constant<int, 3>{}, smem + BUF);
+    sync();
+    stage(integral_constant<int, 3>{}, smem);
     OW_TICK(13);
-    __syncthreads();
+    sync();
     OW_TICK(14);
-    drain(3, smem + BUF);
+    if (MODE != 0) {
+        consume_aux();
+        request_next();
+    }
+    drain(3, smem);
     OW_TICK(15);
 }
-template <int OSZ>
-__device__ __forceinline__ void ow_epilogue(char* smem, OwCtx& c, const Gemm256Params& p, int m0, int n0, int wm, int wn, int lane,
-                                            int tid, const f32x4_t& bias_reg) {
-    const bool gelu = p.epi == MAEST_EPI_GELU;
-    if constexpr (OSZ == 2) {      // (the fp32 value + GELU' pair would not fit two staging buffers: gemm_nt256_try keeps it away)
-        if (gelu && p.aux_out != nullptr) return ow_epilogue_run<OSZ, 3, 0>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
-    }
-    if (p.epi == MAEST_EPI_RESIDUAL) ow_epilogue_run<OSZ, 0, 1>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
-    else if (p.epi == MAEST_EPI_MUL) ow_epilogue_run<OSZ, 0, 2>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
-    else if (gelu) ow_epilogue_run<OSZ, 1, 0>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
-    else ow_epilogue_run<OSZ, 0, 0>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
-}
-
+// One kernel per epilogue form (OSZ: bytes per output element; GMODE / MODE as above): the launcher picks.  (All forms inlined into one
+// persistent kernel made hipcc hoist every form's loop invariants in front of the tile loop and spill them -- into the accumulator half.)
+template <int OSZ, int GMODE, int MODE>
 __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -356,15 +412,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
     asm volatile("" : : : "a0", "a255", "v192", "v255");
 #endif
     const int nwg = p.tiles_m * p.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = wg / p.tiles_n;
-    const int tile_n = wg - tile_m * p.tiles_n;
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
     const int nstages = p.K >> 6;
-
-    // this lane's share of the tile's bias row (256 floats = 64 lanes x 4): parked in a register until the epilogue puts it in LDS
-    f32x4_t bias_reg = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (p.bias != nullptr) bias_reg = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + 4 * lane);
     OwCtx c;
     c.wave = wave;
 #if OW_DEV
@@ -377,53 +425,82 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
         const int ra = wm * 128 + (lane & 31), rb = wn * 128 + (lane & 31);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            c.pa[ks] = (uint32_t)(ra * 128 + ((((2 * ks) | h) ^ ((ra >> 1) & 7)) << 4));
-            c.pb[ks] = (uint32_t)(rb * 128 + ((((2 * ks) | h) ^ ((rb >> 1) & 7)) << 4));
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                c.pa[g][ks] = c.lds0 + (uint32_t)(g * 2 * OW_UNIT + ra * 128 + ((((2 * ks) | h) ^ ((ra >> 1) & 7)) << 4));
+                c.pb[g][ks] = c.lds0 + (uint32_t)(g * 2 * OW_UNIT + rb * 128 + ((((2 * ks) | h) ^ ((rb >> 1) & 7)) << 4));
+            }
         }
     }
+    // The kernel is PERSISTENT: workgroup b (XCD b % 8) walks the virtual block ids b, b + gridDim.x, ... (gridDim.x a multiple of 8
+    // whenever there is more than one round), so that an XCD still works through its contiguous tile range round by round.
+    auto tile_of = [&](int v, int& tm0, int& tn0) {
+        const int wg = xcd_remap(v, nwg);
+        const int tile_m = wg / p.tiles_n;
+        tm0 = tile_m * 256;
+        tn0 = (wg - tile_m * p.tiles_n) * 256;
+    };
     // LDS-DMA sources: piece i of this wave = rows 64 wave + 8 i ..+7 of a unit, lane l = row l >> 3, 16-byte chunk (l & 7) ^ swizzle;
     // offsets are relative to the tile's first row (rows beyond M / N repeat the last one: loaded, never stored)
-    const char* abase = p.A + ((OW_ABLATE & 32) ? 0 : (int64_t)m0 * p.lda * 2);      // (bit 5: every workgroup loads tile 0)
-    const char* bbase = p.B + ((OW_ABLATE & 32) ? 0 : (int64_t)n0 * p.ldb * 2);
+    const char* abase = nullptr;
+    const char* bbase = nullptr;
     uint32_t voa[8], vob[8];
+    auto set_sources = [&](int tm0, int tn0) {
+        abase = p.A + ((OW_ABLATE & 32) ? 0 : (int64_t)tm0 * p.lda * 2);      // (bit 5: every workgroup loads tile 0)
+        bbase = p.B + ((OW_ABLATE & 32) ? 0 : (int64_t)tn0 * p.ldb * 2);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = (wave * 8 + i) * 8 + (lane >> 3);
-        const uint32_t csrc = (uint32_t)((((lane & 7) ^ ((r >> 1) & 7))) << 4);
-        const int ra = m0 + r < p.M ? r : p.M - 1 - m0;
-        const int rb = n0 + r < p.N ? r : p.N - 1 - n0;
-        voa[i] = (uint32_t)(ra * (int)p.lda * 2) + csrc;
-        vob[i] = (uint32_t)(rb * (int)p.ldb * 2) + csrc;
-    }
-    const uint32_t piece0 = c.lds0 + (uint32_t)(wave * 8 * 1024);
-    auto request = [&](const char* base, uint32_t (&vo)[8], int buf) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ow_dma(base, vo[i], piece0 + (uint32_t)(buf * OW_UNIT + i * 1024), c);
+        for (int i = 0; i < 8; ++i) {
+            const int r = (wave * 8 + i) * 8 + (lane >> 3);
+            const uint32_t csrc = (uint32_t)((((lane & 7) ^ ((r >> 1) & 7))) << 4);
+            const int ra = tm0 + r < p.M ? r : p.M - 1 - tm0;
+            const int rb = tn0 + r < p.N ? r : p.N - 1 - tn0;
+            voa[i] = (uint32_t)(ra * (int)p.lda * 2) + csrc;
+            vob[i] = (uint32_t)(rb * (int)p.ldb * 2) + csrc;
+        }
     };
+    const uint32_t piece0 = c.lds0 + (uint32_t)(wave * 8 * 1024);
+    auto request = [&](const char* base, uint32_t (&vo)[8], auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        ow_dma<BUF * OW_UNIT + 0 * 1024>(base, vo[0], piece0, c); ow_dma<BUF * OW_UNIT + 1 * 1024>(base, vo[1], piece0, c);
+        ow_dma<BUF * OW_UNIT + 2 * 1024>(base, vo[2], piece0, c); ow_dma<BUF * OW_UNIT + 3 * 1024>(base, vo[3], piece0, c);
+        ow_dma<BUF * OW_UNIT + 4 * 1024>(base, vo[4], piece0, c); ow_dma<BUF * OW_UNIT + 5 * 1024>(base, vo[5], piece0, c);
+        ow_dma<BUF * OW_UNIT + 6 * 1024>(base, vo[6], piece0, c); ow_dma<BUF * OW_UNIT + 7 * 1024>(base, vo[7], piece0, c);
+    };
+    using std::integral_constant;
 #ifdef OW_PROF
     for (int i = 0; i < 24; ++i) c.prof[i] = 0;
     c.tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin = c.tprev;
 #endif
-    // prologue: A_0 B_0, then A_1 and the first half of B_1 (unit 2 j + (B ? 1 : 0) lives in buffer unit % 5) -- what stage 0 would
+    int v = blockIdx.x, m0, n0;
+    tile_of(v, m0, n0);
+    set_sources(m0, n0);
+    bool fresh = true;                // this tile's A_0 / B_0 are still to be requested (the first tile of the workgroup)
+    for (;;) {
+    // prologue: A_0 B_0 (a later tile finds them requested by the previous tile's epilogue), then A_1 and the first half of B_1 (unit 2 j + (B ? 1 : 0) lives in buffer unit % 5) -- what stage 0 would
     // find requested by a stage "-1"; everything else rides in stage 0's k-steps like in any other stage.  (All five units up front
     // cost 160 requests of the CU's memory front end before the first MFMA: 30 % more prologue for nothing.)
-    request(abase, voa, 0);
-    request(bbase, vob, 1);
+    if (fresh) {
+        request(abase, voa, integral_constant<int, 0>{});
+        request(bbase, vob, integral_constant<int, 1>{});
+    }
     if (nstages > 1) {
-        request(abase, voa, 2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ow_dma(bbase, vob[i], piece0 + (uint32_t)(3 * OW_UNIT + i * 1024), c);
+        request(abase, voa, integral_constant<int, 2>{});
+        ow_dma<3 * OW_UNIT + 0 * 1024>(bbase, vob[0], piece0, c); ow_dma<3 * OW_UNIT + 1 * 1024>(bbase, vob[1], piece0, c);
+        ow_dma<3 * OW_UNIT + 2 * 1024>(bbase, vob[2], piece0, c); ow_dma<3 * OW_UNIT + 3 * 1024>(bbase, vob[3], piece0, c);
         ow_wait_vm<12>();             // stage 0 has landed (this wave's share): A_1 and half of B_1 may fly
     } else {
         ow_wait_vm<0>();
     }
     ow_barrier();
     {
-        const uint32_t la = c.lds0 + c.pa[0], lb = c.lds0 + OW_UNIT + c.pb[0];
+        const uint32_t la = c.pa[0][0], lb = c.pb[0][0];
         ow_read<0, 0, false>(c, la); ow_read<0, 1, false>(c, la); ow_read<0, 2, false>(c, la); ow_read<0, 3, false>(c, la);
-        ow_read<0, 0, true>(c, lb); ow_read<0, 1, true>(c, lb); ow_read<0, 2, true>(c, lb); ow_read<0, 3, true>(c, lb);
+        ow_read<0, 0, true, OW_UNIT>(c, lb); ow_read<0, 1, true, OW_UNIT>(c, lb); ow_read<0, 2, true, OW_UNIT>(c, lb); ow_read<0, 3, true, OW_UNIT>(c, lb);
     }
+    const float* bias_src = p.bias != nullptr ? p.bias + n0 + 4 * lane : nullptr;
+    const uint32_t bias_dst = c.lds0 + (uint32_t)(OW_EPI0 + OW_BIAS0 + lane * 16);
+    ow_bias_load(c, bias_src);
     OW_TICK(10);                      // (prologue)
     // Stage j = four k-steps.  k-step s multiplies the fragments of set s & 1 and reads those of the next k-step (the next stage's
     // first one behind the stage's barrier; the last stage reads the ring's next buffers there: stale bytes nobody multiplies).
@@ -444,21 +521,20 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int ABUF = (2 * PH) % 5, BBUF = (2 * PH + 1) % 5, ABUF_N = (2 * PH + 2) % 5, BBUF_N = (2 * PH + 3) % 5;
         constexpr int BBUF_P = (2 * PH + 4) % 5;             // B_{j-1}'s buffer
-        const uint32_t la = c.lds0 + (uint32_t)(ABUF * OW_UNIT), lb = c.lds0 + (uint32_t)(BBUF * OW_UNIT);
-        const uint32_t dst_a = piece0 + (uint32_t)(BBUF_P * OW_UNIT);      // A_{j+2} -> B_{j-1}'s buffer
         OW_TICK(0);
         ow_wait_lds();
         OW_TICK(1);
-        // B_{j+1}'s second half -> A_{j-1}'s buffer (= B_{j+1}'s), then A_{j+2} in k-steps 1 and 2, B_{j+2}'s first half in k-step 3
-        ow_step<0, FIRST, KIND >= 1 ? 4 : 0, 4>(c, la + c.pa[1], lb + c.pb[1], bbase, vob, piece0 + (uint32_t)(BBUF_N * OW_UNIT));
+        // B_{j+1}'s second half -> A_{j-1}'s buffer (= B_{j+1}'s), then A_{j+2} -> B_{j-1}'s buffer in k-steps 1 and 2, B_{j+2}'s first half
+        // -> A_j's buffer in k-step 3
+        ow_step<0, FIRST, (KIND >= 1 ? 4 : 0), 4, ABUF, BBUF, 1, BBUF_N>(c, bbase, vob, piece0);
         OW_TICK(2);
         ow_wait_lds();
         OW_TICK(3);
-        ow_step<1, false, KIND == 2 ? 4 : 0, 0>(c, la + c.pa[2], lb + c.pb[2], abase, voa, dst_a);
+        ow_step<1, false, (KIND == 2 ? 4 : 0), 0, ABUF, BBUF, 2, BBUF_P>(c, abase, voa, piece0);
         OW_TICK(4);
         ow_wait_lds();
         OW_TICK(5);
-        ow_step<2, false, KIND == 2 ? 4 : 0, 4>(c, la + c.pa[3], lb + c.pb[3], abase, voa, dst_a);
+        ow_step<2, false, (KIND == 2 ? 4 : 0), 4, ABUF, BBUF, 3, BBUF_P>(c, abase, voa, piece0);
         OW_TICK(6);
         ow_wait_lds();
         OW_TICK(7);
@@ -466,13 +542,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
         OW_TICK(8);
         ow_barrier();                 // b_j
         OW_TICK(9);
-        ow_step<3, false, (KIND == 2 ? 4 : 0), 0>(c, c.lds0 + (uint32_t)(ABUF_N * OW_UNIT) + c.pa[0],
-                                                                        c.lds0 + (uint32_t)(BBUF_N * OW_UNIT) + c.pb[0], bbase, vob,
-                                                                        piece0 + (uint32_t)(ABUF * OW_UNIT));
+        ow_step<3, false, (KIND == 2 ? 4 : 0), 0, ABUF_N, BBUF_N, 0, ABUF>(c, bbase, vob, piece0);
     };
     // stages [j, jend) starting at ring phase ph (= j % 5), all of one kind; steady state: a counter, a compare, a branch not taken
     auto run = [&](auto kind_tag, int& j, int jend, int& ph) {
-        using std::integral_constant;
         while (j < jend) {
             switch (ph) {
             case 1: stage_body(integral_constant<int, 1>{}, std::false_type{}, kind_tag); ph = 2; if (++j == jend) break; [[fallthrough]];
@@ -484,7 +557,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
         }
     };
     {
-        using std::integral_constant;
         if (nstages > 2) stage_body(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, 2>{});
         else if (nstages > 1) stage_body(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, 1>{});
         else stage_body(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, 0>{});
@@ -496,34 +568,78 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
 
     OW_TICK(0);                       // (the last k-step 3 counts as "step 3" = slot 0 of the next stage)
     ow_wait_vm<0>();
-    __syncthreads();
+    ow_wait_lds();
+    ow_barrier();                     // the ring is drained and read: LDS becomes the C staging area
+    if (wave == 0) ow_bias_store(c, bias_dst);
+    ow_wait_lds();
+    ow_barrier();
 #if OW_DEV
     if (OW_ABLATE & 16) return;
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");      // the last MFMAs' results are in the accumulator registers
 #endif
     OW_TICK(11);                      // (drain)
-    if (p.out_dtype == MAEST_BF16) ow_epilogue<2>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
-    else ow_epilogue<4>(smem, c, p, m0, n0, wm, wn, lane, tid, bias_reg);
+    const int vn = v + (int)gridDim.x;
+    const bool more = vn < nwg;       // (wave-uniform)
+    int m0n = 0, n0n = 0;
+    if (more) tile_of(vn, m0n, n0n);
+    auto request_next = [&]() {
+        if (more) {
+            set_sources(m0n, n0n);
+            request(abase, voa, integral_constant<int, 0>{});
+            request(bbase, vob, integral_constant<int, 1>{});
+        }
+    };
+    // (the epilogue's per-thread pointers are formed per tile, from values hipcc cannot see through: hoisted out of the tile loop --
+    // ten inlined epilogue forms' worth of them -- they spilled over the main loop)
+    int tid_e = tid, wave_e = wave;
+#if OW_DEV
+    asm volatile("" : "+v"(tid_e));
+    asm volatile("" : "+s"(wave_e));
+#endif
+    ow_epilogue_run<OSZ, GMODE, MODE>(smem, c, p, m0, n0, wave_e >> 1, wave_e & 1, tid_e & 63, tid_e, request_next);
 #ifdef OW_PROF
-    __builtin_amdgcn_s_waitcnt(0);
-    OW_TICK(12);                      // (epilogue, stores acknowledged)
-    if ((blockIdx.x == 5 || blockIdx.x == gridDim.x - 3) && g_ow_prof != nullptr && lane == 0) {
-        unsigned long long* out = g_ow_prof + (blockIdx.x == 5 ? 0 : 96);
-        for (int i = 0; i < 22; ++i) out[wave * 24 + i] = c.prof[i];
-        out[wave * 24 + 22] = t_begin;
-        out[wave * 24 + 23] = c.tprev;
+    if (v == (int)blockIdx.x) {       // (the workgroup's first tile)
+        OW_TICK(12);
+        if ((blockIdx.x == 5 || blockIdx.x == gridDim.x - 3) && g_ow_prof != nullptr && lane == 0) {
+            unsigned long long* out = g_ow_prof + (blockIdx.x == 5 ? 0 : 96);
+            for (int i = 0; i < 22; ++i) out[wave * 24 + i] = c.prof[i];
+            out[wave * 24 + 22] = t_begin;
+            out[wave * 24 + 23] = c.tprev;
+        }
     }
 #endif
+    if (!more) break;
+    v = vn;
+    m0 = m0n;
+    n0 = n0n;
+    fresh = false;
+    ow_sync_epilogue();               // every wave has read the last pass out of the staging area: A_1 / B_1 may be requested into it
+    }
 }
 #ifdef OW_PROF
 extern "C" int maest_debug_ow_prof(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ow_prof), &p, sizeof(p)); }
 #endif
 
-int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream) {
+template <int OSZ, int GMODE, int MODE>
+static int launch256o(Gemm256Params& p, hipStream_t stream) {
     static DeviceOnce once;
-    ensure_dynamic_lds(once, &gemm_nt256o_kernel, OW_SMEM);
-    hipLaunchKernelGGL(gemm_nt256o_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), OW_SMEM, stream, p);
+    ensure_dynamic_lds(once, &gemm_nt256o_kernel<OSZ, GMODE, MODE>, OW_SMEM);
+    const int tiles = p.tiles_m * p.tiles_n;
+    int cap = option(MAEST_OPT_GEMM_WGS);             // one workgroup per CU (tests: fewer, so that a workgroup walks several tiles)
+    cap = cap < 1 ? 1 : (cap > 8 ? cap & ~7 : cap);   // more than one XCD's worth: a multiple of 8 (the tile -> XCD map)
+    hipLaunchKernelGGL((gemm_nt256o_kernel<OSZ, GMODE, MODE>), dim3(tiles < cap ? tiles : cap), dim3(256), OW_SMEM, stream, p);
     return check_launch("maest_gemm_nt(256o)");
+}
+
+int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream) {
+    const bool bf = p.out_dtype == MAEST_BF16, gelu = p.epi == MAEST_EPI_GELU;
+    if (gelu && p.aux_out != nullptr && bf) return launch256o<2, 3, 0>(p, stream);
+    if (p.epi == MAEST_EPI_RESIDUAL && !bf) return launch256o<4, 0, 1>(p, stream);
+    if (p.epi == MAEST_EPI_MUL) return bf ? launch256o<2, 0, 2>(p, stream) : launch256o<4, 0, 2>(p, stream);
+    if (gelu && p.aux_out == nullptr) return bf ? launch256o<2, 1, 0>(p, stream) : launch256o<4, 1, 0>(p, stream);
+    if (p.epi == MAEST_EPI_NONE) return bf ? launch256o<2, 0, 0>(p, stream) : launch256o<4, 0, 0>(p, stream);
+    set_error("maest_gemm_nt(256o): epilogue %d with output dtype %d is not served by this kernel", p.epi, p.out_dtype);
+    return MAEST_ERR_INVALID;
 }
 
 }  // namespace maest

@@ -44,12 +44,16 @@ def test_emu_gemm_256_tile_full_line_stages(emu, dtype, gemm_options):
 def test_emu_gemm_one_wave_per_simd_kernel(emu, gemm_options):
     """gemm_nt256o_kernel's host twin (the C++ form of every owned-register primitive of gemm_nt_ow.hip): 1, 2, 3 and 7 K stages
     (the prologue's three forms, the stage kinds FIRST / full / last-but-one / last, two ring phases beyond the period) and a
-    ragged second tile row, bit for bit against the 8-wave kernel in every epilogue form."""
+    ragged second tile row, bit for bit against the 8-wave kernel in every epilogue form; then several tiles per workgroup."""
     gemm_options(gemm_min_m=512, gemm_tail=0)
     KC.case_gemm_one_wave_per_simd(emu, 512, 256, 64, only=("none -> bf16",), pair=False)
     KC.case_gemm_one_wave_per_simd(emu, 512, 256, 128, only=("residual -> fp32",), pair=False)
     KC.case_gemm_one_wave_per_simd(emu, 512, 256, 192, only=("mul -> bf16", "gelu -> fp32"), pair=False)
     KC.case_gemm_one_wave_per_simd(emu, 520, 256, 448, only=("none -> fp32",))
+    # the persistent tile loop: ONE workgroup walks the three tiles (next tile's A_0 / B_0 requested from inside the epilogue -- at its
+    # start, and behind the last pass's operand fetch in the RESIDUAL form --, A_1 / B_1 behind it, stage 0 without its own A_0 / B_0)
+    gemm_options(gemm_wgs=1)
+    KC.case_gemm_one_wave_per_simd(emu, 520, 256, 128, only=("none -> bf16", "residual -> fp32"), pair=False)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -42,6 +42,14 @@ def test_gemm_one_wave_per_simd_kernel(shape, gemm_options):
     KC.case_gemm_one_wave_per_simd(DEV, *shape)
 
 
+@pytest.mark.parametrize("wgs", [1, 8, 24])
+def test_gemm_one_wave_per_simd_kernel_walks_tiles(wgs, gemm_options):
+    """the persistent tile loop of gemm_nt256o_kernel with 33 tiles on 1 / 8 / 24 workgroups (33, 5 and 2 tiles per workgroup, ragged
+    last tile row): every epilogue form bit for bit against the 8-wave kernel"""
+    gemm_options(gemm_min_m=512, gemm_tail=0, gemm_wgs=wgs)
+    KC.case_gemm_one_wave_per_simd(DEV, 2560 + 77, 768, 768)
+
+
 def test_gemm_eight_wave_kernel_still_serves_bf16(gemm_options):
     """gemm_variant = 3: gemm_nt256w_kernel<bf16> (the A/B reference of the kernel above) against the oracle on its own"""
     gemm_options(gemm_min_m=512, gemm_variant=3)
