@@ -7,6 +7,10 @@ import torch
 from tests import kernel_cases as KC
 
 DT = [torch.float32, torch.bfloat16]
+# The fp32-MFMA instantiations of the 256-row-tile GEMM kernels take 30-50 s each under the emulator (K = 2 per MFMA): the CPU suite runs
+# their bf16 instantiations (same template, same ring / stagger / epilogue code); fp32 runs on the GPU (tests/test_kernels_gpu.py:
+# test_gemm_big_tile_kernels_at_small_m, test_gemm_128_row_tiles_forced, test_gemm_tn).
+DT_BIG = [torch.bfloat16]
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -21,7 +25,7 @@ def test_emu_gemm_ragged_n_scalar_epilogue(emu, dtype):
     KC.case_gemm(emu, dtype, 70, 51, K)
 
 
-@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("dtype", DT_BIG)
 def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype, gemm_options):
     """The 64-byte-slice kernels of gemm256.hip: 256x128 two-per-CU (N % 256 != 0) and 256x256 (variant 1)."""
     # 6 K slices: the 3- / 4-deep rings wrap
@@ -32,11 +36,11 @@ def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype, gemm_options):
     KC.case_gemm(emu, dtype, 512, 256, K, identity=False)
 
 
-@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("dtype", DT_BIG)
 def test_emu_gemm_256_tile_full_line_stages(emu, dtype, gemm_options):
-    """gemm_nt256w_kernel (the default for M >= 512, N % 256 == 0): 128-byte K stages through a 5-buffer unit
+    """gemm_nt256w_kernel (M >= 512, N % 256 == 0; fp32 / bf16x3 operands, and bf16 under gemm_variant = 3): 128-byte K stages through a 5-buffer unit
     ring (6 stages: the ring wraps)."""
-    gemm_options(gemm_min_m=512)
+    gemm_options(gemm_min_m=512, gemm_variant=3)   # (the bf16 default is gemm_nt256o_kernel: test_emu_gemm_one_wave_per_simd_kernel)
     KC.case_gemm(emu, dtype, 512, 256, 192 if dtype == torch.float32 else 384, identity=False)   # 6 stages > 5 buffers
 
 
@@ -56,7 +60,7 @@ def test_emu_gemm_one_wave_per_simd_kernel(emu, gemm_options):
     KC.case_gemm_one_wave_per_simd(emu, 520, 256, 128, only=("none -> bf16", "residual -> fp32"), pair=False)
 
 
-@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("dtype", DT_BIG)
 def test_emu_gemm_128_row_tiles_of_the_last_partial_round(emu, dtype, gemm_options):
     """gemm_nt256w_kernel<MTW = 2>: 128 x 256 tiles (A units of 128 rows in the same ring, vmcnt(2) waits, one-pass
     epilogue with the aux operand prefetched), forced onto every tile; 576 rows = 4.5 tiles (ragged last tile)."""
@@ -76,7 +80,7 @@ def test_emu_gemm_rowdot(emu, dtype, gemm_options):
     KC.case_gemm_rowdot(emu, dtype, 576, 256, K, 96)
 
 
-@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("dtype", DT_BIG)
 def test_emu_gemm_tn_256_tile_lds_dma_kernel(emu, dtype, gemm_options):
     """M, N multiples of 256 and K a multiple of the slice route to gemm256.hip:gemm_tn256_kernel."""
     gemm_options(gemm_variant=4)   # take the 256-tile kernel although there are only 2 tiles
