@@ -1009,7 +1009,7 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
         const int ev = epi == MAEST_EPI_ROWDOT ? 0 : (eopt >= 0 ? eopt : (epi == MAEST_EPI_RESIDUAL ? 1 : 0));
         auto full = [&](Gemm256Params& q) {
             // bf16 operands: the one-wave-per-SIMD kernel (gemm_nt_ow.hip); MAEST_OPT_GEMM_VARIANT = 3 keeps the 8-wave kernel (A/B, tests)
-            if (!x3 && in_dtype == MAEST_BF16 && variant != 3 && epi != MAEST_EPI_ROWDOT &&
+            if (!x3 && in_dtype == MAEST_BF16 && variant != 3 &&
                 !(epi == MAEST_EPI_RESIDUAL && out_dtype == MAEST_BF16) &&
                 !(epi == MAEST_EPI_GELU && aux_out != nullptr && out_dtype != MAEST_BF16))
                 return gemm_nt256o_launch(q, stream);

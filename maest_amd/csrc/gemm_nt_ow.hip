@@ -238,7 +238,7 @@ __device__ __forceinline__ void ow_step(OwCtx& c, const char* base, uint32_t (&v
 // hides a latency for free, so: the tile's 256 bias values sit in LDS (fetched into a register per lane at kernel start: a
 // global load per use was two thirds of this epilogue), a pass's LDS reads are issued as one batch, and the second operand of
 // the RESIDUAL / MUL forms is fetched into registers a pass ahead (AuxRegs), behind the previous pass's drain.
-// GMODE: 0 none, 1 GELU, 3 GELU + GELU' side output; MODE: 0 plain, 1 RESIDUAL (+ aux), 2 MUL (* aux)
+// GMODE: 0 none, 1 GELU, 3 GELU + GELU' side output; MODE: 0 plain, 1 RESIDUAL (+ aux), 2 MUL (* aux), 3 ROWDOT (plain + row-dot side output)
 template <int OSZ, int GMODE, int MODE, typename NEXT>
 __device__ __forceinline__ void ow_epilogue_run(char* smem0, OwCtx& c, const Gemm256Params& p, int m0, int n0, int wm, int wn,
                                                 int lane, int tid, NEXT&& request_next) {
@@ -335,6 +335,25 @@ __device__ __forceinline__ void ow_epilogue_run(char* smem0, OwCtx& c, const Gem
         for (int i = 0; i < NCH; ++i) {
             chunk16 o = v[i];
             if (aux != nullptr) o = apply_aux<OSZ, MODE>(o, aux[i]);
+            if constexpr (MODE == 3) {
+                // row-dot side output (gemm256.hip: drain256): the stored values times `other` over each 64-column group -- the
+                // 8 / 16 lanes that hold a group's chunks are neighbours
+                const chunk16 r = aux[i];
+                float d = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (OSZ == 4) d += u2f(o[e]) * u2f(r[e]);
+                    else d += u2f(o[e] << 16) * u2f(r[e] << 16) + u2f(o[e] & 0xffff0000u) * u2f(r[e] & 0xffff0000u);
+                }
+                constexpr int GL = 64 * OSZ / 16;
+#pragma unroll
+                for (int m = 1; m < GL; m <<= 1) d += __shfl_xor(d, m, 64);
+                const int gm = m0 + r0 + ro0 + i * RS, gn = n0 + cc * E::EPC;
+                if ((cc & (GL - 1)) == 0 && gm < p.M) {
+                    const int item = (gm + p.row0) / p.ntok, q = gm + p.row0 - item * p.ntok;
+                    p.rowdot[((int64_t)item * (p.N >> 6) + (gn >> 6)) * p.ntok + q] = d;
+                }
+            }
             // streaming output: written once, re-read by a later kernel after > L2-size of other traffic
             if (full || m0 + r0 + ro0 + i * RS < p.M)
                 __builtin_nontemporal_store(o, reinterpret_cast<chunk16*>(dthr + (ro0 + i * RS) * drow));
@@ -637,6 +656,7 @@ int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream) {
     if (p.epi == MAEST_EPI_RESIDUAL && !bf) return launch256o<4, 0, 1>(p, stream);
     if (p.epi == MAEST_EPI_MUL) return bf ? launch256o<2, 0, 2>(p, stream) : launch256o<4, 0, 2>(p, stream);
     if (gelu && p.aux_out == nullptr) return bf ? launch256o<2, 1, 0>(p, stream) : launch256o<4, 1, 0>(p, stream);
+    if (p.epi == MAEST_EPI_ROWDOT) return bf ? launch256o<2, 0, 3>(p, stream) : launch256o<4, 0, 3>(p, stream);
     if (p.epi == MAEST_EPI_NONE) return bf ? launch256o<2, 0, 0>(p, stream) : launch256o<4, 0, 0>(p, stream);
     set_error("maest_gemm_nt(256o): epilogue %d with output dtype %d is not served by this kernel", p.epi, p.out_dtype);
     return MAEST_ERR_INVALID;

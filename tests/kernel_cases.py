@@ -126,6 +126,12 @@ def case_gemm_rowdot(dev, dtype, M, N, K, ntok, seed=7):
     assert rd.shape == (M // ntok, N // 64, ntok)
     want = (c.float().cpu() * other.float()).reshape(M // ntok, ntok, N // 64, 64).sum(-1).permute(0, 2, 1)
     close(rd, want, 1e-5, 1e-5 * math.sqrt(64) * float(c.float().abs().max()), "gemm rowdot: per-(row, group) dot products")
+    if dtype == torch.bfloat16:
+        # bf16: the call above took gemm_nt256o_kernel where the shape has 256-row tiles; the 8-wave kernel's row-dot epilogue does the
+        # same arithmetic in the same order
+        with ops.options(gemm_variant=3):
+            c3, rd3 = ops.gemm_nt_rowdot(a.to(dev), b.to(dev), other.to(dev), ntok, out_dtype=dtype, bias=bias.to(dev))
+        assert torch.equal(c, c3) and torch.equal(rd, rd3), "row-dot epilogue: one-wave-per-SIMD and 8-wave kernels differ"
 
 
 def case_gemm_tn(dev, dtype, K, M, N, seed=3, lda_pad=0, splits=(1, 3, 0)):
