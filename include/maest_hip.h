@@ -89,9 +89,10 @@ const char* maest_last_error(void);
 #define MAEST_OPT_TN_REDUCE 8 /* env MAEST_TN_REDUCE, default 0: split-K partials of the wgrad GEMM are combined with fp32 atomics; 1:
                                  maest_gemm_tn_ws uses the workspace it is given (partial tiles stored plainly, summed in split
                                  order by a second kernel: bit-reproducible dW; no measurable cost on the training step) */
-#define MAEST_OPT_GEMM_WGS 9 /* env MAEST_GEMM_WGS, default 256 (one per CU): workgroup cap of the persistent bf16 NT GEMM
-                               (gemm_nt_ow.hip; workgroup b walks tiles b, b + cap, ...); smaller values make a workgroup walk
-                               several tiles at test shapes */
+#define MAEST_OPT_GEMM_WGS 9 /* env MAEST_GEMM_WGS, default 0: the bf16 NT GEMM (gemm_nt_ow.hip) launches one workgroup per tile; n > 0:
+                               at most n workgroups, workgroup b walking tiles b, b + n, ... with the next tile's first operand units
+                               requested from inside the epilogue (256 = one per CU; small values make a workgroup walk several tiles
+                               at test shapes) */
 #define MAEST_OPT_LN_BWD_BLOCKS 4 /* env MAEST_LN_BWD_BLOCKS, default 1024: workgroup cap of the LayerNorm backward grid */
 int maest_set_option(int opt, int value, int restore_default);
 int maest_get_option(int opt, int* value);

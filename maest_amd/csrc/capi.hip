@@ -29,7 +29,7 @@ int check_launch(const char* what) {
 
 // ---- process-wide switches: environment read ONCE (first use), then lock-free atomics
 static constexpr int kNumOptions = 10;
-static const int kOptionDefault[kNumOptions] = {8192, 0, -1, 0, 1024, 1, 0, 0, 0, 256};
+static const int kOptionDefault[kNumOptions] = {8192, 0, -1, 0, 1024, 1, 0, 0, 0, 0};
 static const char* const kOptionEnv[kNumOptions] = {"MAEST_GEMM_MIN_M", "MAEST_GEMM_VARIANT", "MAEST_GEMM_EPILOGUE",
                                                   "MAEST_ATTN_BWD", "MAEST_LN_BWD_BLOCKS", "MAEST_GEMM_TAIL",
                                                   "MAEST_ATTN_FWD", "MAEST_ATTN_FWD_WAVES",

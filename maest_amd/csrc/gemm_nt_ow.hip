@@ -451,8 +451,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
             }
         }
     }
-    // The kernel is PERSISTENT: workgroup b (XCD b % 8) walks the virtual block ids b, b + gridDim.x, ... (gridDim.x a multiple of 8
-    // whenever there is more than one round), so that an XCD still works through its contiguous tile range round by round.
+    // The kernel can run PERSISTENT (gemm_nt256o_launch): workgroup b (XCD b % 8) walks the virtual block ids b, b + gridDim.x, ...
+    // (gridDim.x a multiple of 8 whenever there is more than one round), so that an XCD still works through its contiguous tile range
+    // round by round.
     auto tile_of = [&](int v, int& tm0, int& tn0) {
         const int wg = xcd_remap(v, nwg);
         const int tile_m = wg / p.tiles_n;
@@ -644,8 +645,12 @@ static int launch256o(Gemm256Params& p, hipStream_t stream) {
     static DeviceOnce once;
     ensure_dynamic_lds(once, &gemm_nt256o_kernel<OSZ, GMODE, MODE>, OW_SMEM);
     const int tiles = p.tiles_m * p.tiles_n;
-    int cap = option(MAEST_OPT_GEMM_WGS);             // one workgroup per CU (tests: fewer, so that a workgroup walks several tiles)
-    cap = cap < 1 ? 1 : (cap > 8 ? cap & ~7 : cap);   // more than one XCD's worth: a multiple of 8 (the tile -> XCD map)
+    // Workgroups: one per tile by default -- the tile loop then runs once and the hardware deals the tiles out as CUs come free, which
+    // matters when something else holds a few CUs (the gradient all-reduce's kernels during the backward: with a fixed tile list per
+    // workgroup the ones that start late would double the kernel's time).  MAEST_OPT_GEMM_WGS = n > 0: at most n workgroups, each
+    // walking tiles b, b + n, ... (256 = one per CU: 2-4 % faster stand-alone on the K = 768 shapes, equal in the single-GPU step).
+    int cap = option(MAEST_OPT_GEMM_WGS);
+    cap = cap < 1 ? tiles : (cap > 8 ? cap & ~7 : cap);   // more than one XCD's worth: a multiple of 8 (the tile -> XCD map)
     hipLaunchKernelGGL((gemm_nt256o_kernel<OSZ, GMODE, MODE>), dim3(tiles < cap ? tiles : cap), dim3(256), OW_SMEM, stream, p);
     return check_launch("maest_gemm_nt(256o)");
 }
