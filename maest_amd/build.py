@@ -12,7 +12,7 @@ SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "gemm_nt_ow.hip", "gemm_tn_ow.
 
 
 # sources whose inline asm owns fixed registers: {file: (first, last owned arch VGPR)}; all accumulator registers are owned too
-AUDITED = {"attn_fwd_pw.hip": (96, 245), "gemm_nt_ow.hip": (188, 255, True), "gemm_tn_ow.hip": (176, 255)}
+AUDITED = {"attn_fwd_pw.hip": (96, 245), "gemm_nt_ow.hip": (188, 255, True), "gemm_tn_ow.hip": (176, 255, True)}
 
 
 def _hipcc():

@@ -43,6 +43,11 @@ constexpr int TW_V_LO = 176, TW_V_HI = 255;   // (the audited range)
 #define TW_ABLATE 0       // timing experiments only (results wrong on purpose): bit 0 no LDS-DMA requests, 1 no barrier / vmcnt wait,
 #endif                    // 2 no MFMAs, 3 no fragment reads, 4 no epilogue
 
+// The owned arch VGPRs (TW_FRAGS, on every main-loop statement) and the whole accumulator half (TW_ACCS, on the waits and barriers) as
+// clobber lists: hipcc cannot keep a value in them across the main loop (gemm_nt_ow.hip has the story), and may use v176 .. v255 behind it.
+#define TW_FRAGS "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+#define TW_ACCS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+
 struct TwCtx {
     uint32_t pa[4], pb[4];       // LDS byte offsets of this lane's transpose-read piece of A block a / B block b (k-step 0, first read)
     uint32_t lds0;
@@ -60,7 +65,7 @@ __device__ __forceinline__ void tw_read(TwCtx& c, uint32_t addr) {
 #if TW_DEV
     constexpr int V = TW_V_F + 32 * SET + (ISB ? 16 : 0) + 4 * T + 2 * HF;
     if (!(TW_ABLATE & 8))
-        asm volatile("ds_read_b64_tr_b16 v[%c1:%c2], %0 offset:%c3" : : "v"(addr), "i"(V), "i"(V + 1), "i"(KS * 8192 + HF * 2048));
+        asm volatile("ds_read_b64_tr_b16 v[%c1:%c2], %0 offset:%c3" : : "v"(addr), "i"(V), "i"(V + 1), "i"(KS * 8192 + HF * 2048) : TW_FRAGS);
 #else
     typedef short v4i16_t __attribute__((ext_vector_type(4)));
     const v4i16_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)(c.lds + addr + KS * 8192 + HF * 2048));
@@ -78,10 +83,10 @@ __device__ __forceinline__ void tw_mfma(TwCtx& c) {
     if (TW_ABLATE & 4) return;
     if constexpr (ZERO)
         asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], 0"
-                     : : "i"(D), "i"(D + 15), "i"(FA), "i"(FA + 3), "i"(FB), "i"(FB + 3));
+                     : : "i"(D), "i"(D + 15), "i"(FA), "i"(FA + 3), "i"(FB), "i"(FB + 3) : TW_FRAGS);
     else
         asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], a[%c0:%c1]"
-                     : : "i"(D), "i"(D + 15), "i"(FA), "i"(FA + 3), "i"(FB), "i"(FB + 3));
+                     : : "i"(D), "i"(D + 15), "i"(FA), "i"(FA + 3), "i"(FB), "i"(FB + 3) : TW_FRAGS);
 #else
     if (ZERO) {
 #pragma unroll
@@ -96,7 +101,7 @@ __device__ __forceinline__ void tw_dma(const char* base, uint32_t& voff, uint32_
     if (TW_ABLATE & 1) return;
     const uint32_t lds = __builtin_amdgcn_readfirstlane(dst);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tv_add_u32 %0, %3, %0"
-                 : "+v"(voff) : "s"(base), "s"(lds), "s"(step) : "memory");
+                 : "+v"(voff) : "s"(base), "s"(lds), "s"(step) : "memory", TW_FRAGS);
 #else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff),
                                      (__attribute__((address_space(3))) void*)(c.lds + dst), 16, 0, 0);
@@ -107,19 +112,19 @@ template <int VM, int LGKM>
 __device__ __forceinline__ void tw_wait() {          // VM / LGKM < 0: that counter is not waited for
 #if TW_DEV
     if constexpr (VM >= 0 && LGKM >= 0) {
-        if (TW_ABLATE & 2) asm volatile("s_waitcnt lgkmcnt(%c0)" : : "i"(LGKM) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(%c1)" : : "i"(VM), "i"(LGKM) : "memory");
+        if (TW_ABLATE & 2) asm volatile("s_waitcnt lgkmcnt(%c0)" : : "i"(LGKM) : "memory", TW_FRAGS, TW_ACCS);
+        else asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(%c1)" : : "i"(VM), "i"(LGKM) : "memory", TW_FRAGS, TW_ACCS);
     } else if constexpr (VM >= 0) {
-        if (!(TW_ABLATE & 2)) asm volatile("s_waitcnt vmcnt(%c0)" : : "i"(VM) : "memory");
+        if (!(TW_ABLATE & 2)) asm volatile("s_waitcnt vmcnt(%c0)" : : "i"(VM) : "memory", TW_FRAGS, TW_ACCS);
     } else {
-        asm volatile("s_waitcnt lgkmcnt(%c0)" : : "i"(LGKM) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(%c0)" : : "i"(LGKM) : "memory", TW_FRAGS, TW_ACCS);
     }
 #endif
 }
 __device__ __forceinline__ void tw_barrier() {
 #if TW_DEV
     if (TW_ABLATE & 2) return;
-    asm volatile("s_barrier" : : : "memory");
+    asm volatile("s_barrier" : : : "memory", TW_FRAGS, TW_ACCS);
 #else
     __syncthreads();
 #endif
@@ -394,20 +399,25 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256o_kernel(GemmTn256Params p) 
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");      // the last MFMAs' results are in the accumulator registers
 #endif
     // split-K partial -> C by fp32 atomics, as the accumulator layout has them (a half-wave = 32 consecutive columns of one row)
-    auto flush = [&](auto a_tag, auto b_tag) {
+    auto flush = [&](auto a_tag, auto b_tag, float* cbase) {
         constexpr int A = decltype(a_tag)::value, B = decltype(b_tag)::value;
         const f32x16_t t = tw_acc_read<A, B>(c);
         const int col = j0 + wn * 128 + B * 32 + (lane & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = i0 + wm * 128 + A * 32 + frag_row(r, lane);
-            unsafeAtomicAdd(p.C + (int64_t)row * p.ldc + col, t[r]);
+            unsafeAtomicAdd(cbase + (int64_t)row * p.ldc + col, t[r]);
         }
     };
+    // (the 256 addresses are formed row by row from a pointer hipcc cannot see through: hoisted as a whole they spill)
     auto flush_row = [&](auto a_tag) {
         using std::integral_constant;
-        flush(a_tag, integral_constant<int, 0>{}); flush(a_tag, integral_constant<int, 1>{});
-        flush(a_tag, integral_constant<int, 2>{}); flush(a_tag, integral_constant<int, 3>{});
+        float* cb = p.C;
+#if TW_DEV
+        asm volatile("" : "+s"(cb));
+#endif
+        flush(a_tag, integral_constant<int, 0>{}, cb); flush(a_tag, integral_constant<int, 1>{}, cb);
+        flush(a_tag, integral_constant<int, 2>{}, cb); flush(a_tag, integral_constant<int, 3>{}, cb);
     };
     flush_row(std::integral_constant<int, 0>{});
     flush_row(std::integral_constant<int, 1>{});
