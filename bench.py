@@ -309,7 +309,6 @@ def check_ranks(net, world, dev):
     import torch.distributed as dist
     flat = torch.cat([p.detach().reshape(-1).float() for p in net.parameters()])
     bits = flat.view(torch.int32)
-    x = bits[0].clone()
     # xor-fold of all bit patterns (exact, order-independent)
     n = 1 << (bits.numel() - 1).bit_length()
     pad = torch.zeros(n, dtype=torch.int32, device=dev)

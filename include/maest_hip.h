@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MAEST_ABI_VERSION 5
+#define MAEST_ABI_VERSION 6
 
 #define MAEST_OK 0
 #define MAEST_ERR_INVALID 1 /* bad argument (shape / alignment / dtype) */
@@ -40,6 +40,12 @@ extern "C" {
                          of maest_gemm_nt / maest_gemm_tn and as the dtype of maest_attn_fwd / maest_attn_bwd only (the
                          other entry points take MAEST_F32 for the same tensors); ~2^-16 per-product error on the
                          full-rate bf16 matrix pipe */
+
+#define MAEST_BF16_QS 4 /* bf16 qkv tensor whose q columns hold q' = scale * log2(e) * q (the factor folded into the q rows of the qkv
+                           projection's operand copy by maest_cast_weights_multi: q' is rounded once, forward and backward read the
+                           same operand): accepted as the dtype of maest_attn_fwd(_rows) / maest_attn_bwd(_rows) only.  `scale` stays
+                           the TRUE softmax scale; dQ comes out as the gradient with respect to the true q (so the projection's
+                           dgrad / wgrad run on the unscaled weights), lse and the output are those of MAEST_BF16 up to rounding. */
 
 /* GEMM epilogues */
 #define MAEST_F16 3 /* IEEE half: accepted as the INPUT dtype of maest_patch_im2col only (the loader's float16 mel batches,
@@ -55,15 +61,25 @@ extern "C" {
 int maest_version(void);
 const char* maest_last_error(void);
 
+/* Which of the hand-scheduled kernels that own fixed registers are in this build.  maest_amd/build.py audits their code objects
+ * (maest_amd/pw_audit.py); a kernel whose audit fails under some other hipcc is left out and the dispatch keeps the kernel it
+ * replaced (same results: the forms are bit-equal for the GEMMs, equal to rounding for the attention forward).  *mask = OR of: */
+#define MAEST_FORM_GEMM_NT_OW 1  /* gemm_nt_ow.hip: bf16 NT GEMM, one wave per SIMD (else the eight-wave kernel)            */
+#define MAEST_FORM_GEMM_TN_OW 2  /* gemm_tn_ow.hip: bf16 wgrad GEMM, one wave per SIMD (else the eight-wave kernel)         */
+#define MAEST_FORM_ATTN_FWD_PW 4 /* attn_fwd_pw.hip: persistent bf16 attention forward for N > 320 (else four-wave LDS-DMA) */
+int maest_kernel_forms(int* mask);
+
 /* ---- process-wide tuning / test switches.  Thread-safe (atomics); the defaults are taken from the environment
  * variables named below, which are read ONCE, at the first use of any switch.  restore_default != 0 ignores `value`.
  *   MAEST_OPT_GEMM_MIN_M    (env MAEST_GEMM_MIN_M,    default 8192): smallest M routed to the 256-row-tile GEMMs
- *   MAEST_OPT_GEMM_VARIANT  (env MAEST_GEMM_VARIANT,  default 0):    0 = full-line 256x256 kernels (bf16 operands: four waves,
- *                            one per SIMD, 128 x 128 outputs each -- gemm_nt_ow.hip; fp32 / split-bf16 / row-dot: eight waves),
- *                            1 = 64-byte-slice 256x256, 2 = 256x128 two-per-CU, 3 = as 0 with the eight-wave kernel for bf16 too
+ *   MAEST_OPT_GEMM_VARIANT  (env MAEST_GEMM_VARIANT,  default 0):    0 = full-line 256x256 kernels (bf16 operands, every epilogue
+ *                            form incl. row-dot: four waves, one per SIMD, 128 x 128 outputs each -- gemm_nt_ow.hip / gemm_tn_ow.hip;
+ *                            fp32 / split-bf16 operands and the 128-row tail tiles: eight waves -- gemm256.hip),
+ *                            1 = 64-byte-slice 256x256, 2 = 256x128 two-per-CU, 3 = as 0 with the eight-wave kernels for bf16 too
  *                            (A/B, tests), 4 = 256-tile TN kernel at any qualifying shape
  *   MAEST_OPT_GEMM_EPILOGUE (env MAEST_GEMM_EPILOGUE, default -1):   -1 = per-epilogue choice, 0/1/2 force a C-tile
- *                            epilogue form of the full-line kernel */
+ *                            epilogue form of the eight-wave full-line kernel (ignored by the one-wave-per-SIMD kernel, i.e. for
+ *                            bf16 operands under MAEST_OPT_GEMM_VARIANT = 0) */
 #define MAEST_OPT_GEMM_MIN_M 0
 #define MAEST_OPT_GEMM_VARIANT 1
 #define MAEST_OPT_GEMM_EPILOGUE 2
@@ -154,9 +170,12 @@ int maest_cast_weights(const float* src, void* dst, void* dst_t, int rows, int c
                        void* stream);
 /* The same for n parameters in one launch (HOST arrays of n device pointers / shapes; dst[i] or dst_t[i] may
  * be NULL): the operand-copy refresh after an optimizer step (autocast's per-call weight casts in the
- * reference, ex_maest.py:51 precision="16-mixed"). */
+ * reference, ex_maest.py:51 precision="16-mixed").  scaled_rows (HOST array of n, or NULL): rows [0, scaled_rows[i]) of dst[i] --
+ * not of dst_t[i] -- are multiplied by row_scale before the rounding: the q rows of a qkv projection's forward operand copy carry
+ * scale * log2(e) for MAEST_BF16_QS attention (the transposed copy, which serves the dgrad, stays unscaled). */
 int maest_cast_weights_multi(int n, const float* const* src, void* const* dst, void* const* dst_t,
-                             const int* rows, const int* cols, int dtype, void* stream);
+                             const int* rows, const int* cols, const int* scaled_rows, float row_scale, int dtype,
+                             void* stream);
 
 /* ---- K7 LayerNorm over the last dim (nn.LayerNorm: models/maest.py:395,405,499,553,571) ---------
  * x: fp32 [rows, cols] (ldx); y: y_dtype [rows, cols] (ldy); mean/rstd: fp32 [rows] or NULL.

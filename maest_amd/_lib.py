@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmaest_hip.so")
 F32 = 0
 BF16 = 1
 F16 = 3     # IEEE half, input of maest_patch_im2col only
+BF16_QS = 4 # bf16 qkv tensor with q columns pre-multiplied by scale * log2(e) (maest_attn_* dtype only)
 F32X3 = 2   # fp32 tensors, split-bf16 matrix products (maest_gemm_nt in_dtype / maest_attn_fwd dtype only)
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_MUL, EPI_ATOMIC = 0, 1, 2, 3, 4
 
@@ -31,7 +32,7 @@ SIGNATURES = {
     "maest_gemm_tn_ws": [_P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _P, _I, _P, _L, _P],
     "maest_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
     "maest_cast_weights": [_P, _P, _P, _I, _I, _I, _P],
-    "maest_cast_weights_multi": [_I, _P, _P, _P, _P, _P, _I, _P],
+    "maest_cast_weights_multi": [_I, _P, _P, _P, _P, _P, _P, _F, _I, _P],
     "maest_layernorm_fwd": [_P, _L, _P, _P, _P, _L, _I, _P, _P, _I, _I, _F, _P],
     "maest_add_layernorm_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
     "maest_layernorm_bwd": [_P, _L, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
@@ -62,9 +63,11 @@ SIGNATURES = {
     "maest_cast_rows": [_P, _L, _P, _L, _I, _I, _I, _P],
     "maest_set_option": [_I, _I, _I],
     "maest_get_option": [_I, _P],
+    "maest_kernel_forms": [_P],
 }
+FORM_GEMM_NT_OW, FORM_GEMM_TN_OW, FORM_ATTN_FWD_PW = 1, 2, 4
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "ln_bwd_blocks": 4, "gemm_tail": 5, "attn_fwd": 6, "attn_fwd_waves": 7,
            "tn_reduce": 8, "gemm_wgs": 9}
 
@@ -119,6 +122,13 @@ def _testing_restore():
 
 def host_emulation():
     return _host_emulation
+
+
+def kernel_forms():
+    """Bit mask of the owned-register kernels present in this build (include/maest_hip.h: MAEST_FORM_*)."""
+    m = c_int(0)
+    call("maest_kernel_forms", ctypes.byref(m))
+    return m.value
 
 
 def call(name, *args):

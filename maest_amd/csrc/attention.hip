@@ -151,8 +151,8 @@ template <int PITCH>
 __device__ __forceinline__ chunk16 frag_from_rows_bf16(const char* tile, int rho0, int s, int dblk, int lane) {
     const int h = lane >> 5, g16 = (lane >> 4) & 1, q = lane & 15;
     const char* p = tile + (rho0 + 16 * s + 4 * h + (q >> 2)) * PITCH + (dblk * 32 + 16 * g16 + 4 * (q & 3)) * 2;
-    const v4i16a_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16a_t*)(p));
-    const v4i16a_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16a_t*)(p + 8 * PITCH));
+    const v4i16a_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(lds_cast<v4i16a_t>(p));
+    const v4i16a_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(lds_cast<v4i16a_t>(p + 8 * PITCH));
     const chunk8 l2 = __builtin_bit_cast(chunk8, lo), h2 = __builtin_bit_cast(chunk8, hi);   // no repacking
     chunk16 c;
     c[0] = l2[0]; c[1] = l2[1]; c[2] = h2[0]; c[3] = h2[1];
@@ -231,7 +231,7 @@ template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(const T* __restrict__ qkv,
                                                                                 T* __restrict__ out,
                                                                                 float* __restrict__ lse, int B, int N,
-                                                                                float scale, int q_rows) {
+                                                                                float sc_c2, int q_rows) {
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[key][d], V[key][d] }
 
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(c
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
     float m_run = NEG_BIG, l_run = 0.0f;
-    const float c2 = scale * LOG2E;
+    const float c2 = sc_c2;
 
 #ifndef MAEST_ABLATE_FWD
 #define MAEST_ABLATE_FWD 0     // timing experiments only (scratch/attn_ablate.sh fwd; results wrong on purpose): bit 0 no softmax math,
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
-    const float* __restrict__ delta, T* __restrict__ dqkv, int B, int N, float scale) {
+    const float* __restrict__ delta, T* __restrict__ dqkv, int B, int N, float sc_c2, float sc_dk) {
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // 2 x { Q[q][d], dO[q][d], lse[64] (pre-multiplied by log2e), delta[64] }
@@ -406,14 +406,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
     row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
     const bool key_ok = key < N;
     const bool wave_active = blk.rb * 128 + wave * 32 < N;   // wave-uniform: all 32 keys of this wave are padding otherwise
-    const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
+    const f32x2_t c2v = {sc_c2, sc_c2};
 
     f32x16_t dk[2], dv[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[db][r] = 0.0f; dv[db][r] = 0.0f; }
-    const float c2 = scale * LOG2E;
+    const float c2 = sc_c2;
 
     const int ntiles = (N + 63) / 64;
     TileRegs<T> qr, dr;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
     }
     {
         T* row = dqkv + ((int64_t)b * N + key) * QKV_LD + head * HD;
-        store_dT_ok<T>(dk, row + NHEADS * HD, lane, scale, key_ok);
+        store_dT_ok<T>(dk, row + NHEADS * HD, lane, sc_dk, key_ok);
         store_dT_ok<T>(dv, row + 2 * NHEADS * HD, lane, 1.0f, key_ok);
     }
 }
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkdv_ker
 template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
-    const float* __restrict__ delta, T* __restrict__ dqkv, int B, int N, float scale) {
+    const float* __restrict__ delta, T* __restrict__ dqkv, int B, int N, float sc_c2, float sc_dq) {
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[key][d], V[key][d] }
 
@@ -512,14 +512,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
     const int qc = q_ok ? q : N - 1;
     const float lse_q = lse[((int64_t)b * NHEADS + head) * N + qc] * LOG2E;
     const float dl_q = delta[((int64_t)b * NHEADS + head) * N + qc];
-    const f32x2_t nlse = {-lse_q, -lse_q}, dlv = {dl_q, dl_q}, c2v = {scale * LOG2E, scale * LOG2E};
+    const f32x2_t nlse = {-lse_q, -lse_q}, dlv = {dl_q, dl_q}, c2v = {sc_c2, sc_c2};
 
     f32x16_t dq[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[db][r] = 0.0f;
-    const float c2 = scale * LOG2E;
+    const float c2 = sc_c2;
 
     const int ntiles = (N + 63) / 64;
     TileRegs<T> kr, vr;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
         }
         __syncthreads();
     }
-    store_dT_ok<T>(dq, dqkv + ((int64_t)b * N + q) * QKV_LD + head * HD, lane, scale, q_ok);
+    store_dT_ok<T>(dq, dqkv + ((int64_t)b * N + q) * QKV_LD + head * HD, lane, sc_dq, q_ok);
 }
 
 // =================================================================================== fused backward (bf16, N <= 320)
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
                                                                        const bf16_t* __restrict__ dout,
                                                                        const float* __restrict__ lse,
                                                                        bf16_t* __restrict__ dqkv, int B, int N,
-                                                                       float scale) {
+                                                                       float sc_c2, float sc_dq, float sc_dk) {
     using T = bf16_t;
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
     if (key_wave) {
         // =============================================================================== key waves
         const int key = wave * 32 + (lane & 31);
-        const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
+        const f32x2_t c2v = {sc_c2, sc_c2};
         chunk16 kf[C::STEPS], vf[C::STEPS];
         row_frags_load<T>(kf, kbase, QKV_LD, key, N, h);
         row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x16_t& a = tsel == 0 ? dk[db] : dv[db];
-                    const float m = tsel == 0 ? scale : 1.0f;
+                    const float m = tsel == 0 ? sc_dk : 1.0f;
                     chunk8 w;
                     w[0] = pack_bf2(a[4 * g] * m, a[4 * g + 1] * m);
                     w[1] = pack_bf2(a[4 * g + 2] * m, a[4 * g + 3] * m);
@@ -801,8 +801,8 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
                 T* row = dq_out + (uint32_t)(q * QKV_LD + aux * 32);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    store4<T>(row + 8 * g + 4 * h, acc[4 * g] * scale, acc[4 * g + 1] * scale, acc[4 * g + 2] * scale,
-                              acc[4 * g + 3] * scale);
+                    store4<T>(row + 8 * g + 4 * h, acc[4 * g] * sc_dq, acc[4 * g + 1] * sc_dq, acc[4 * g + 2] * sc_dq,
+                              acc[4 * g + 3] * sc_dq);
             }
         };
         Feed f0, f1;
@@ -865,8 +865,8 @@ __device__ __forceinline__ chunk16 frag_from_rows_swz(const char* tile, int rho0
     const int cb = (dblk * 32 + 16 * g16 + 4 * (q & 3)) * 2;          // byte column
     const char* p0 = tile + row * 128 + ((((cb >> 4) ^ swz128(row)) << 4) | (cb & 15));
     const char* p1 = tile + (row + 8) * 128 + ((((cb >> 4) ^ swz128(row + 8)) << 4) | (cb & 15));
-    const v4i16a_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16a_t*)(p0));
-    const v4i16a_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16a_t*)(p1));
+    const v4i16a_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(lds_cast<v4i16a_t>(p0));
+    const v4i16a_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(lds_cast<v4i16a_t>(p1));
     const chunk8 l2 = __builtin_bit_cast(chunk8, lo), h2 = __builtin_bit_cast(chunk8, hi);
     chunk16 c;
     c[0] = l2[0]; c[1] = l2[1]; c[2] = h2[0]; c[3] = h2[1];
@@ -905,7 +905,7 @@ template <int NW>
 struct FwdWgs { static constexpr int value = MAEST_FWD_RING == 3 ? (NW <= 5 ? 3 : 2) : (16 / NW); };
 template <int NW>
 __global__ __launch_bounds__(NW * 64, FwdWgs<NW>::value) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                              float* __restrict__ lse, int B, int N, float scale, int q_rows) {
+                                                              float* __restrict__ lse, int B, int N, float sc_c2, int q_rows) {
     using T = bf16_t;
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[64 keys][128 B], V[64 keys][128 B] }
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(NW * 64, FwdWgs<NW>::value) void attn_fwd_dma_kerne
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
     float m_run = NEG_BIG, l_run = 0.0f;
-    const float c2 = scale * LOG2E;
+    const float c2 = sc_c2;
     if (RING == 3 && ntiles > 1) __builtin_amdgcn_s_waitcnt(0x0F74);      // vmcnt(4): tile 0 and the Q fragments landed, tile 1 may fly
     else MAEST_ATTN_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(NW * 64, FwdWgs<NW>::value) void attn_fwd_dma_kerne
 // padded queries carry lse = +BIG and padded keys a masked score, so P = dS = 0 exactly against a finite operand).
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                   bf16_t* __restrict__ dqkv, int B, int N, float scale) {
+                                                                   bf16_t* __restrict__ dqkv, int B, int N, float sc_c2, float sc_dk) {
     using T = bf16_t;
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_dma_kernel(const bf16_t*
     row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
     const bool key_ok = key < N;
     const bool wave_active = blk.rb * 128 + wave * 32 < N;   // wave-uniform
-    const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
+    const f32x2_t c2v = {sc_c2, sc_c2};
     f32x16_t dk[2], dv[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -1131,13 +1131,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_dma_kernel(const bf16_t*
         __builtin_amdgcn_s_barrier();
     }
     T* row = dqkv + ((int64_t)b * N + (key_ok ? key : 0)) * QKV_LD + head * HD;
-    store_dT_ok<T>(dk, row + NHEADS * HD, lane, scale, key_ok);
+    store_dT_ok<T>(dk, row + NHEADS * HD, lane, sc_dk, key_ok);
     store_dT_ok<T>(dv, row + 2 * NHEADS * HD, lane, 1.0f, key_ok);
 }
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                 bf16_t* __restrict__ dqkv, int B, int N, float scale) {
+                                                                 bf16_t* __restrict__ dqkv, int B, int N, float sc_c2, float sc_dq) {
     using T = bf16_t;
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[key][128 B], V[key][128 B] }
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16_t* _
     const int qc = q_ok ? q : N - 1;
     const float lse_q = lse[((int64_t)b * NHEADS + head) * N + qc] * LOG2E;
     const float dl_q = delta[((int64_t)b * NHEADS + head) * N + qc];
-    const f32x2_t nlse = {-lse_q, -lse_q}, dlv = {dl_q, dl_q}, c2v = {scale * LOG2E, scale * LOG2E};
+    const f32x2_t nlse = {-lse_q, -lse_q}, dlv = {dl_q, dl_q}, c2v = {sc_c2, sc_c2};
     f32x16_t dq[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16_t* _
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
     }
-    store_dT_ok<T>(dq, dqkv + ((int64_t)b * N + (q_ok ? q : 0)) * QKV_LD + head * HD, lane, scale, q_ok);
+    store_dT_ok<T>(dq, dqkv + ((int64_t)b * N + (q_ok ? q : 0)) * QKV_LD + head * HD, lane, sc_dq, q_ok);
 }
 
 // MAEST_ATTN_PROF: timing instrumentation only (scratch/attn_prof.py builds a second library with it; never defined in
@@ -1233,7 +1233,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
                                                                         const float* __restrict__ lse,
                                                                         const float* __restrict__ delta,
                                                                         bf16_t* __restrict__ dqkv, int B, int N,
-                                                                        float scale, int q_rows) {
+                                                                        float sc_c2, float sc_dq, float sc_dk, int q_rows) {
     using T = bf16_t;
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1273,7 +1273,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
         // =============================================================================== key waves
         const int key = wave * 32 + (lane & 31);
         const bool key_ok = key < N;
-        const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
+        const f32x2_t c2v = {sc_c2, sc_c2};
         chunk16 kf[C::STEPS], vf[C::STEPS];
         row_frags_load<T>(kf, kbase, QKV_LD, key, N, h);
         row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x16_t& a = tsel == 0 ? dk[db] : dv[db];
-                    const float m = tsel == 0 ? scale : 1.0f;
+                    const float m = tsel == 0 ? sc_dk : 1.0f;
                     chunk8 w;
                     w[0] = pack_bf2(a[4 * g] * m, a[4 * g + 1] * m);
                     w[1] = pack_bf2(a[4 * g + 2] * m, a[4 * g + 3] * m);
@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
         auto dq_store = [&](const f32x16_t& acc, int t) {
             if (t < 0 || aux > 1) return;
             const int q = t * 32 + (lane & 31);
-            store_32d_rows16(acc, dq_out + (uint32_t)(q * QKV_LD + aux * 32), lane, scale, q < N);     // (wave-uniform t, aux: converged)
+            store_32d_rows16(acc, dq_out + (uint32_t)(q * QKV_LD + aux * 32), lane, sc_dq, q < N);     // (wave-uniform t, aux: converged)
         };
         // prologue: tiles 0 and 1 by DMA; statistics of tile 0 stored, of tile 1 in flight
         tile_dma(0);
@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused3_kernel(const bf1
                                                                         const float* __restrict__ lse,
                                                                         const float* __restrict__ delta,
                                                                         bf16_t* __restrict__ dqkv, int B, int N,
-                                                                        float scale) {
+                                                                        float sc_c2, float sc_dq, float sc_dk) {
     using T = bf16_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nkw = (N + 31) >> 5, nqt = nkw;      // key waves = key blocks = query tiles (9 or 10)
@@ -1550,7 +1550,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused3_kernel(const bf1
         // =============================================================================== key waves
         const int key = wave * 32 + (lane & 31);
         const bool key_ok = key < N;
-        const f32x2_t c2v = {scale * LOG2E, scale * LOG2E};
+        const f32x2_t c2v = {sc_c2, sc_c2};
         // this wave's piece of query tile t of item `it` -> ring slot (waves 0..3: 8 rows of Q, 4..7: 8 rows of dO)
         auto tile_piece = [&](int it, int t, int slot, int lv) {
             const bool isdo = wave >= 4;
@@ -1582,7 +1582,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused3_kernel(const bf1
 #endif                         // 1 no K / V prefetch, 2 no tile pieces, 3 no dQ product, 4 no dQ stores, 5 no softmax math, 6 no dV / dK products
             if (first && g > 0 && !(MAEST_ABLATE_F3 & 1)) {  // dK, dV of the item that ended a step ago
                 T* row = dq_of(it - stride) + (uint32_t)(key * QKV_LD + NHEADS * HD);
-                store_dT_rows16(dk, row, lane, scale, key_ok);
+                store_dT_rows16(dk, row, lane, sc_dk, key_ok);
                 store_dT_rows16(dv, row + NHEADS * HD, lane, 1.0f, key_ok);
             }
             // LDS-DMA of this step: the next item's K / V piece first, the tile piece second
@@ -1666,7 +1666,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused3_kernel(const bf1
         }
         {                                                  // dK, dV of the last item
             T* row = dq_of(it - stride) + (uint32_t)(key * QKV_LD + NHEADS * HD);
-            store_dT_rows16(dk, row, lane, scale, key_ok);
+            store_dT_rows16(dk, row, lane, sc_dk, key_ok);
             store_dT_rows16(dv, row + NHEADS * HD, lane, 1.0f, key_ok);
         }
     } else {
@@ -1720,7 +1720,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused3_kernel(const bf1
         };
         auto dq_store = [&](const f32x16_t& acc, T* out_item, int t) {
             const int q = t * 32 + (lane & 31);
-            store_32d_rows16(acc, out_item + (uint32_t)(q * QKV_LD + aux * 32), lane, scale, q < N);
+            store_32d_rows16(acc, out_item + (uint32_t)(q * QKV_LD + aux * 32), lane, sc_dq, q < N);
         };
         // prologue: statistics of tile 0 stored, of tile 1 in flight
         stat_store(stat_load(it0, 0), 0, 0);
@@ -1787,21 +1787,22 @@ static int attn_fwd_waves(int N, int q_rows) {
     return 4;                                     // measured best at every production shape (see attn_fwd_dma_kernel)
 }
 
-int attn_fwd_pw_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, hipStream_t st);   // attn_fwd_pw.hip
+int attn_fwd_pw_launch(const void* qkv, void* out, float* lse, int B, int N, AttnScale sc, bool q_prescaled, hipStream_t st);   // attn_fwd_pw.hip
+bool attn_fwd_pw_available();   // false in a build whose register audit failed (maest_amd/build.py)
 
 template <typename T, bool X3 = false>
-static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, int q_rows, hipStream_t st) {
+static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, AttnScale sc, bool q_prescaled, int q_rows, hipStream_t st) {
     using C = AttnCfg<T>;
     if constexpr (sizeof(T) == 2 && !X3) {
         const int afw = option(MAEST_OPT_ATTN_FWD);
         // the long token rows (10 s inference, 30 s shapes): the persistent one-wave-per-SIMD form; 3 forces it at any N (tests)
-        if (q_rows == N && ((afw == 0 && N > 320) || afw == 3)) return attn_fwd_pw_launch(qkv, out, lse, B, N, scale, st);
+        if (q_rows == N && ((afw == 0 && N > 320) || afw == 3) && attn_fwd_pw_available()) return attn_fwd_pw_launch(qkv, out, lse, B, N, sc, q_prescaled, st);
         if (afw == 0 || afw == 2 || afw == 3) {     // K / V tiles by LDS-DMA (unpadded, swizzled); 2 forces this form at any N
             const int nw = attn_fwd_waves(N, q_rows);
             const dim3 g(((N + nw * 32 - 1) / (nw * 32)) * NHEADS * B);
             const int lds = MAEST_FWD_RING * 2 * 64 * 128;
 #define MAEST_FWD_LAUNCH(NW_) hipLaunchKernelGGL(attn_fwd_dma_kernel<NW_>, g, dim3(NW_ * 64), lds, st, (const bf16_t*)qkv, \
-                                                 (bf16_t*)out, lse, B, N, scale, q_rows)
+                                                 (bf16_t*)out, lse, B, N, sc.c2, q_rows)
             if (nw == 5) MAEST_FWD_LAUNCH(5);
             else if (nw == 6) MAEST_FWD_LAUNCH(6);
             else if (nw == 8) MAEST_FWD_LAUNCH(8);
@@ -1814,14 +1815,14 @@ static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N,
     const int smem_bytes = 4 * C::TILE;
     static DeviceOnce once;
     ensure_dynamic_lds(once, &attn_fwd_kernel<T, X3>, smem_bytes);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, X3>), grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, B, N, scale,
+    hipLaunchKernelGGL((attn_fwd_kernel<T, X3>), grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, B, N, sc.c2,
                        q_rows);
     return check_launch("maest_attn_fwd");
 }
 
 template <typename T, bool X3 = false>
 static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
-                           void* dqkv, int B, int N, float scale, int q_rows, hipStream_t st) {
+                           void* dqkv, int B, int N, AttnScale sc, int q_rows, hipStream_t st) {
     using C = AttnCfg<T>;
     if constexpr (sizeof(T) == 2) {
         // bf16 and at most 10 key blocks (the 10 s training shapes, N = 281 / 290): one fused pass per (batch, head)
@@ -1838,7 +1839,7 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
                 const int ncu = 256, nitems = B * NHEADS;
                 hipLaunchKernelGGL(attn_bwd_fused3_kernel, dim3(nitems < ncu ? nitems : ncu), dim3((nkw + 2) * 64),
                                    attn_bwd_fused3_smem(N), st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
-                                   (const float*)delta, (bf16_t*)dqkv, B, N, scale);
+                                   (const float*)delta, (bf16_t*)dqkv, B, N, sc.c2, sc.dq, sc.dk);
                 return check_launch("maest_attn_bwd(fused, persistent)");
             }
             static DeviceOnce once_g;
@@ -1846,7 +1847,7 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
             const int waves = nkw + 2 < 8 ? 8 : nkw + 2;
             hipLaunchKernelGGL(attn_bwd_fused2_kernel, dim3(B * NHEADS), dim3(waves * 64), attn_bwd_fused2_smem(N), st,
                                (const bf16_t*)qkv, (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, B, N,
-                               scale, q_rows);
+                               sc.c2, sc.dq, sc.dk, q_rows);
             return check_launch("maest_attn_bwd(fused, dma)");
         }
     }
@@ -1864,7 +1865,7 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
             ensure_dynamic_lds(once_f, &attn_bwd_fused_kernel, attn_bwd_fused_smem(32 * (FB_MAXW - 2)));
             hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * NHEADS), dim3(waves * 64), smem_f, st,
                                (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N,
-                               scale);
+                               sc.c2, sc.dq, sc.dk);
             return check_launch("maest_attn_bwd(fused)");
         }
     }
@@ -1880,9 +1881,9 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
                                    (const T*)out, (const T*)dout, delta, B, N, N);
             dim3 grid(((N + 127) / 128) * NHEADS * B);
             hipLaunchKernelGGL(attn_bwd_dkdv_dma_kernel, grid, dim3(256), smem_da, st, (const bf16_t*)qkv, (const bf16_t*)dout,
-                               lse, (const float*)delta, (bf16_t*)dqkv, B, N, scale);
+                               lse, (const float*)delta, (bf16_t*)dqkv, B, N, sc.c2, sc.dk);
             hipLaunchKernelGGL(attn_bwd_dq_dma_kernel, grid, dim3(256), smem_db, st, (const bf16_t*)qkv, (const bf16_t*)dout,
-                               lse, (const float*)delta, (bf16_t*)dqkv, B, N, scale);
+                               lse, (const float*)delta, (bf16_t*)dqkv, B, N, sc.c2, sc.dq);
             return check_launch("maest_attn_bwd(dma tiles)");
         }
     }
@@ -1897,9 +1898,9 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
                            (const T*)out, (const T*)dout, delta, B, N, N);
     dim3 grid(((N + 127) / 128) * NHEADS * B);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, X3>), grid, dim3(256), smem_a, st, (const T*)qkv, (const T*)dout, lse,
-                       (const float*)delta, (T*)dqkv, B, N, scale);
+                       (const float*)delta, (T*)dqkv, B, N, sc.c2, sc.dk);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, X3>), grid, dim3(256), smem_b, st, (const T*)qkv, (const T*)dout, lse,
-                       (const float*)delta, (T*)dqkv, B, N, scale);
+                       (const float*)delta, (T*)dqkv, B, N, sc.c2, sc.dq);
     return check_launch("maest_attn_bwd");
 }
 
@@ -1918,11 +1919,14 @@ extern "C" int maest_attn_fwd_rows(const void* qkv, void* out, float* lse, int B
     MAEST_REQUIRE(qkv && out, "maest_attn_fwd: null pointer");
     MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_fwd: bad shape B=%d N=%d", B, N);
     MAEST_REQUIRE(q_rows > 0 && q_rows <= N, "maest_attn_fwd_rows: q_rows = %d outside 1..N", q_rows);
-    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3, "maest_attn_fwd: bad dtype %d", dtype);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3 || dtype == MAEST_BF16_QS,
+                  "maest_attn_fwd: bad dtype %d", dtype);
     MAEST_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "maest_attn_fwd: 16-byte alignment");
-    if (dtype == MAEST_F32X3) return attn_fwd_launch<float, true>(qkv, out, lse, B, N, scale, q_rows, (hipStream_t)stream);
-    return dtype == MAEST_BF16 ? attn_fwd_launch<bf16_t>(qkv, out, lse, B, N, scale, q_rows, (hipStream_t)stream)
-                               : attn_fwd_launch<float>(qkv, out, lse, B, N, scale, q_rows, (hipStream_t)stream);
+    const bool qs = dtype == MAEST_BF16_QS;
+    const AttnScale sc = attn_scale(scale, qs);
+    if (dtype == MAEST_F32X3) return attn_fwd_launch<float, true>(qkv, out, lse, B, N, sc, false, q_rows, (hipStream_t)stream);
+    return dtype == MAEST_F32 ? attn_fwd_launch<float>(qkv, out, lse, B, N, sc, false, q_rows, (hipStream_t)stream)
+                              : attn_fwd_launch<bf16_t>(qkv, out, lse, B, N, sc, qs, q_rows, (hipStream_t)stream);
 }
 
 extern "C" int maest_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int dtype, float scale,
@@ -1938,12 +1942,14 @@ extern "C" int maest_attn_bwd_rows(const void* qkv, const void* out, const void*
                   "maest_attn_bwd: out = NULL (delta given) is not served by the register-fed fused form (MAEST_OPT_ATTN_BWD = 2)");
     MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_bwd: bad shape B=%d N=%d", B, N);
     MAEST_REQUIRE(q_rows > 0 && q_rows <= N, "maest_attn_bwd_rows: q_rows = %d outside 1..N", q_rows);
-    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3, "maest_attn_bwd: bad dtype %d", dtype);
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3 || dtype == MAEST_BF16_QS,
+                  "maest_attn_bwd: bad dtype %d", dtype);
+    const AttnScale sc = attn_scale(scale, dtype == MAEST_BF16_QS);
     if (dtype == MAEST_F32X3)
-        return attn_bwd_launch<float, true>(qkv, out, dout, lse, delta, dqkv, B, N, scale, q_rows, (hipStream_t)stream);
-    return dtype == MAEST_BF16
-               ? attn_bwd_launch<bf16_t>(qkv, out, dout, lse, delta, dqkv, B, N, scale, q_rows, (hipStream_t)stream)
-               : attn_bwd_launch<float>(qkv, out, dout, lse, delta, dqkv, B, N, scale, q_rows, (hipStream_t)stream);
+        return attn_bwd_launch<float, true>(qkv, out, dout, lse, delta, dqkv, B, N, sc, q_rows, (hipStream_t)stream);
+    return dtype == MAEST_F32
+               ? attn_bwd_launch<float>(qkv, out, dout, lse, delta, dqkv, B, N, sc, q_rows, (hipStream_t)stream)
+               : attn_bwd_launch<bf16_t>(qkv, out, dout, lse, delta, dqkv, B, N, sc, q_rows, (hipStream_t)stream);
 }
 
 extern "C" int maest_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,

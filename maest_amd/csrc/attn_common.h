@@ -12,10 +12,39 @@ constexpr int OUT_LD = NHEADS * HD;      // 768
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;
+// The three places the softmax scale enters an attention kernel.  Raw q (every dtype): the score product q k^T is multiplied by
+// scale * log2(e) on its way into exp2, dQ = scale * dS K and dK = scale * dS^T q.  MAEST_BF16_QS (the bf16 training / inference
+// mode of maest_amd/maest.py): the q columns of the qkv tensor hold q' = scale * log2(e) * q -- the factor is folded into the q rows
+// of the qkv projection's operand copy (maest_cast_weights_multi), so q' is rounded to bf16 ONCE and forward and backward see the
+// same operand --: the product q' k^T is the exponent as it stands, dQ keeps its factor (the gradient with respect to the TRUE q:
+// dgrad and wgrad of the projection then run on the unscaled weights as before) and dK = ln 2 * dS^T q'.
+struct AttnScale {
+    float c2;    // exponent (log2 domain) per unit of the raw score product
+    float dq;    // factor of dS K
+    float dk;    // factor of dS^T q
+};
+inline AttnScale attn_scale(float scale, bool q_prescaled) {
+    return q_prescaled ? AttnScale{1.0f, scale, LN2} : AttnScale{scale * LOG2E, scale, scale};
+}
 // drain this wave's vector-memory queue (LDS-DMA included) without touching the LDS / scalar counters
 #define MAEST_ATTN_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 typedef short v4i16a_t __attribute__((ext_vector_type(4)));
+
+// A generic pointer into shared memory as an LDS pointer.  Device build: the low half of the flat address IS the LDS byte address; going
+// through the integer avoids the null test hipcc puts around a flat -> LDS address-space cast (on `smem + offset` that test has come out
+// as an illegal `v_cmp_ne_u32 0, src_shared_base` -- "Operand has incorrect register class" -- depending on unrelated code in the kernel).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+template <typename P>
+__device__ __forceinline__ __attribute__((address_space(3))) P* lds_cast(const void* p) {
+#if defined(__AMDGCN__)
+    return (__attribute__((address_space(3))) P*)(uint32_t)(uintptr_t)p;
+#else
+    return (__attribute__((address_space(3))) P*)(p);
+#endif
+}
+#pragma clang diagnostic pop
 
 __device__ __forceinline__ int swz128(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
 // One LDS-DMA instruction (global_load_lds_dwordx4: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS address `dst`),
@@ -27,7 +56,7 @@ __device__ __forceinline__ int swz128(int row) { return (((row >> 1) & 1) << 2) 
 // the builtin, which it executes synchronously.)
 __device__ __forceinline__ void dma16(const void* gsrc, char* dst) {
 #if defined(__AMDGCN__)
-    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst);
+    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst);   // (low half of the flat address = the LDS address)
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");

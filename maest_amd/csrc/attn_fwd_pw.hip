@@ -39,7 +39,21 @@
 
 #include "attn_common.h"
 
+#ifdef MAEST_OWNED_DISABLED
+// maest_amd/build.py compiles this file with MAEST_OWNED_DISABLED when the audit of the code object fails (a hipcc that allocates
+// registers differently from the validated one): the kernel is left out, attention.hip keeps the four-wave LDS-DMA form at every N.
 namespace maest {
+bool attn_fwd_pw_available() { return false; }
+int attn_fwd_pw_launch(const void*, void*, float*, int, int, AttnScale, bool, hipStream_t) {
+    set_error("maest_attn_fwd(persistent): the kernel was left out of this build (register audit failed)");
+    return MAEST_ERR_INVALID;
+}
+}  // namespace maest
+#else
+
+namespace maest {
+
+bool attn_fwd_pw_available() { return true; }
 
 constexpr int PW_QB = 3;                      // 32-row query blocks per wave
 constexpr int PW_NW = 2;                      // waves per workgroup
@@ -260,6 +274,18 @@ __device__ __forceinline__ void pw_q_write(PwCtx& c, const chunk16& q) {
     pw_acc_write<A + 3>(q[3]);
 #else
     c.qf[I][J] = q;
+#endif
+}
+
+// Q' fragment (I, J) straight out of LDS (MAEST_BF16_QS: the rows hold q' = scale * log2(e) * q already); `addr`: this lane's LDS byte
+// address of chunk J of its row in query block 0 of this wave's staging rows
+template <int I, int J>
+__device__ __forceinline__ void pw_q_read(PwCtx& c, uint32_t addr) {
+#if PW_DEV
+    constexpr int A = PW_A_Q + (4 * I + J) * 4;
+    asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" : : "v"(addr), "i"(A), "i"(A + 3), "i"(I * 4096));
+#else
+    c.qf[I][J] = *reinterpret_cast<const chunk16*>(c.lds + addr + I * 4096);
 #endif
 }
 
@@ -575,13 +601,12 @@ __device__ __forceinline__ void pw_region(PwCtx& c, int klim, const PwDma& dm, c
 }
 
 __global__ __launch_bounds__(PW_NW * 64, 1) void attn_fwd_pw_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                    float* __restrict__ lse, int B, int N, float scale, int nrb,
-                                                                    int total) {
+                                                                    float* __restrict__ lse, int B, int N, float c2, int q_prescaled,
+                                                                    int nrb, int total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = (N + 63) >> 6;
-    const float c2 = scale * LOG2E;
 #if PW_DEV
     // the accumulator registers this file owns (the clobber makes the kernel descriptor allocate them)
     asm volatile("" : : : "a0", "a95", "a143", "a175", "a207", "a239", "v96", "v245");
@@ -688,10 +713,25 @@ __global__ __launch_bounds__(PW_NW * 64, 1) void attn_fwd_pw_kernel(const bf16_t
         PW_Q_TAKE(2, 0); PW_Q_TAKE(2, 1); PW_Q_TAKE(2, 2); PW_Q_TAKE(2, 3);
 #undef PW_Q_TAKE
     };
+    // MAEST_BF16_QS: the rows are q' already -- 12 reads straight into the fragment registers (no scaling pass, no second rounding)
+    auto q_take_qs = [&]() {
+#if PW_DEV
+        const uint32_t qa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)q_lds + (uint32_t)((lane & 31) * 128);
+#else
+        const uint32_t qa = q_dst + (uint32_t)((lane & 31) * 128);
+#endif
+        const int q_swz = swz128(lane & 31);
+        const uint32_t a0 = qa + (uint32_t)(((0 | h) ^ q_swz) << 4), a1 = qa + (uint32_t)(((2 | h) ^ q_swz) << 4);
+        const uint32_t a2 = qa + (uint32_t)(((4 | h) ^ q_swz) << 4), a3 = qa + (uint32_t)(((6 | h) ^ q_swz) << 4);
+        pw_q_read<0, 0>(c, a0); pw_q_read<0, 1>(c, a1); pw_q_read<0, 2>(c, a2); pw_q_read<0, 3>(c, a3);
+        pw_q_read<1, 0>(c, a0); pw_q_read<1, 1>(c, a1); pw_q_read<1, 2>(c, a2); pw_q_read<1, 3>(c, a3);
+        pw_q_read<2, 0>(c, a0); pw_q_read<2, 1>(c, a1); pw_q_read<2, 2>(c, a2); pw_q_read<2, 3>(c, a3);
+        pw_wait_lds();
+    };
     q_fetch(first);
     pw_wait_all();                               // the first three tiles of the stream and the first item's Q rows have landed
     pw_barrier();
-    q_take();
+    if (q_prescaled) q_take_qs(); else q_take();
 
     for (int blk = first; blk < lim; blk += nslots) {
         const int bh = blk / nrb, rb = blk - bh * nrb, b = bh / NHEADS, head = bh - b * NHEADS;
@@ -784,7 +824,7 @@ __global__ __launch_bounds__(PW_NW * 64, 1) void attn_fwd_pw_kernel(const bf16_t
         pw_fence();
         pw_wait_q();
         PW_STAMP();
-        if (!(PW_ABLATE & 64)) q_take();
+        if (!(PW_ABLATE & 64)) { if (q_prescaled) q_take_qs(); else q_take(); }
         PW_STAMP();
         // normalise and store this wave's 96 rows (16-byte row pieces), log-sum-exp for the backward
 #if PW_DEV
@@ -825,7 +865,7 @@ __global__ __launch_bounds__(PW_NW * 64, 1) void attn_fwd_pw_kernel(const bf16_t
 extern "C" int maest_debug_pw_prof(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pw_prof), &p, sizeof(p)); }
 #endif
 
-int attn_fwd_pw_launch(const void* qkv, void* out, float* lse, int B, int N, float scale, hipStream_t st) {
+int attn_fwd_pw_launch(const void* qkv, void* out, float* lse, int B, int N, AttnScale sc, bool q_prescaled, hipStream_t st) {
     const int nrb = (N + PW_ROWS - 1) / PW_ROWS;
     const int total = nrb * NHEADS * B;
     const int per = (total + 7) / 8;
@@ -838,8 +878,9 @@ int attn_fwd_pw_launch(const void* qkv, void* out, float* lse, int B, int N, flo
 #endif
     ensure_dynamic_lds(once, &attn_fwd_pw_kernel, lds_bytes);
     hipLaunchKernelGGL(attn_fwd_pw_kernel, dim3(8 * nslots), dim3(PW_NW * 64), lds_bytes, st, (const bf16_t*)qkv, (bf16_t*)out, lse,
-                       B, N, scale, nrb, total);
+                       B, N, sc.c2, q_prescaled ? 1 : 0, nrb, total);
     return check_launch("maest_attn_fwd(persistent)");
 }
 
 }  // namespace maest
+#endif  // MAEST_OWNED_DISABLED

@@ -67,5 +67,17 @@ extern "C" int maest_get_option(int opt, int* value) {
     return MAEST_OK;
 }
 
+namespace maest {
+bool gemm_nt256o_available();   // gemm_nt_ow.hip
+bool gemm_tn256o_available();   // gemm_tn_ow.hip
+bool attn_fwd_pw_available();   // attn_fwd_pw.hip
+}  // namespace maest
+extern "C" int maest_kernel_forms(int* mask) {
+    MAEST_REQUIRE(mask, "maest_kernel_forms: null pointer");
+    *mask = (maest::gemm_nt256o_available() ? MAEST_FORM_GEMM_NT_OW : 0) | (maest::gemm_tn256o_available() ? MAEST_FORM_GEMM_TN_OW : 0) |
+            (maest::attn_fwd_pw_available() ? MAEST_FORM_ATTN_FWD_PW : 0);
+    return MAEST_OK;
+}
+
 extern "C" int maest_version(void) { return MAEST_ABI_VERSION; }
 extern "C" const char* maest_last_error(void) { return maest::g_error; }

@@ -1009,7 +1009,7 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
         const int ev = epi == MAEST_EPI_ROWDOT ? 0 : (eopt >= 0 ? eopt : (epi == MAEST_EPI_RESIDUAL ? 1 : 0));
         auto full = [&](Gemm256Params& q) {
             // bf16 operands: the one-wave-per-SIMD kernel (gemm_nt_ow.hip); MAEST_OPT_GEMM_VARIANT = 3 keeps the 8-wave kernel (A/B, tests)
-            if (!x3 && in_dtype == MAEST_BF16 && variant != 3 &&
+            if (!x3 && in_dtype == MAEST_BF16 && variant != 3 && gemm_nt256o_available() &&
                 !(epi == MAEST_EPI_RESIDUAL && out_dtype == MAEST_BF16) &&
                 !(epi == MAEST_EPI_GELU && aux_out != nullptr && out_dtype != MAEST_BF16))
                 return gemm_nt256o_launch(q, stream);
@@ -1430,7 +1430,7 @@ int gemm_tn256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int d
     p.ws = use_ws ? (float*)ws : nullptr;
     // bf16 operands, atomic combine: the one-wave-per-SIMD kernel (gemm_tn_ow.hip; 32-bit slice offsets); MAEST_OPT_GEMM_VARIANT = 3
     // keeps the 8-wave kernel (A/B, tests)
-    if (!x3 && dtype == MAEST_BF16 && !use_ws && option(MAEST_OPT_GEMM_VARIANT) != 3 &&
+    if (!x3 && dtype == MAEST_BF16 && !use_ws && option(MAEST_OPT_GEMM_VARIANT) != 3 && gemm_tn256o_available() &&
         (int64_t)K * lda * 2 < ((int64_t)1 << 31) && (int64_t)K * ldb * 2 < ((int64_t)1 << 31))
         return gemm_tn256o_launch(p, split_k, stream);
     if (x3) return launch_tn256<float, true>(p, split_k, stream);

@@ -161,9 +161,11 @@ struct GemmTn256Params {
 };
 // gemm_tn_ow.hip: the one-wave-per-SIMD 256 x 256 wgrad kernel (bf16 operands, atomic split-K combine: p.ws == NULL)
 int gemm_tn256o_launch(GemmTn256Params& p, int split_k, hipStream_t stream);
+bool gemm_tn256o_available();   // false in a build whose register audit failed (maest_amd/build.py): the 8-wave kernel serves
 
 // gemm_nt_ow.hip: the one-wave-per-SIMD 256 x 256 kernel (bf16 operands; N % 256 == 0, K % 64 == 0, fp32 output for RESIDUAL, bf16
 // output for the GELU + GELU' pair)
 int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream);
+bool gemm_nt256o_available();
 
 }  // namespace maest

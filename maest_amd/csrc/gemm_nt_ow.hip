@@ -28,7 +28,21 @@
 #include "common.h"
 #include "gemm256_epi.h"
 
+#ifdef MAEST_OWNED_DISABLED
+// maest_amd/build.py compiles this file with MAEST_OWNED_DISABLED when the audit of the code object fails (a hipcc that allocates
+// registers differently from the validated one): the kernel is left out, the dispatch in gemm256.hip keeps the 8-wave kernel.
 namespace maest {
+bool gemm_nt256o_available() { return false; }
+int gemm_nt256o_launch(Gemm256Params&, hipStream_t) {
+    set_error("maest_gemm_nt(256o): the one-wave-per-SIMD kernel was left out of this build (register audit failed)");
+    return MAEST_ERR_INVALID;
+}
+}  // namespace maest
+#else
+
+namespace maest {
+
+bool gemm_nt256o_available() { return true; }
 
 constexpr int OW_UNIT = 256 * 128;            // one operand unit: 256 rows x 128 B
 constexpr int OW_NBUF = 5;
@@ -668,3 +682,4 @@ int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream) {
 }
 
 }  // namespace maest
+#endif  // MAEST_OWNED_DISABLED

@@ -67,7 +67,9 @@ struct CastTable {
     void* dst[CAST_MAX_ITEMS];
     void* dst_t[CAST_MAX_ITEMS];
     int rows[CAST_MAX_ITEMS], cols[CAST_MAX_ITEMS];
+    int scaled_rows[CAST_MAX_ITEMS];      // rows [0, scaled_rows) of dst (NOT of dst_t) are multiplied by row_scale before the rounding
     int tile_begin[CAST_MAX_ITEMS + 1];   // prefix sum of 64x64 tiles
+    float row_scale;
     int n;
 };
 template <typename T>
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void cast_weights_multi_kernel(const CastTable
     float* tile = reinterpret_cast<float*>(smem);  // [64][65]
     int it = 0;
     while (it + 1 < tab.n && (int)blockIdx.x >= tab.tile_begin[it + 1]) ++it;   // block-uniform scalar search
-    const int rows = tab.rows[it], cols = tab.cols[it];
+    const int rows = tab.rows[it], cols = tab.cols[it], srows = tab.scaled_rows[it];
     const float* __restrict__ src = tab.src[it];
     T* __restrict__ dst = reinterpret_cast<T*>(tab.dst[it]);
     T* __restrict__ dst_t = reinterpret_cast<T*>(tab.dst_t[it]);
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void cast_weights_multi_kernel(const CastTable
         float v = 0.0f;
         if (r < rows && c < cols) {
             v = src[(int64_t)r * cols + c];
-            if (dst != nullptr) dst[(int64_t)r * cols + c] = elem_traits<T>::from_f32(v);
+            if (dst != nullptr) dst[(int64_t)r * cols + c] = elem_traits<T>::from_f32(r < srows ? v * tab.row_scale : v);
         }
         tile[(i * 4 + ty) * 65 + tx] = v;
     }
@@ -318,7 +320,8 @@ extern "C" int maest_cast_weights(const float* src, void* dst, void* dst_t, int 
 }
 
 extern "C" int maest_cast_weights_multi(int n, const float* const* src, void* const* dst, void* const* dst_t,
-                                        const int* rows, const int* cols, int dtype, void* stream) {
+                                        const int* rows, const int* cols, const int* scaled_rows, float row_scale, int dtype,
+                                        void* stream) {
     MAEST_REQUIRE(n > 0 && src && dst && dst_t && rows && cols, "maest_cast_weights_multi: null pointer / n <= 0");
     MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_cast_weights_multi: bad dtype");
     for (int base = 0; base < n; base += CAST_MAX_ITEMS) {
@@ -331,10 +334,12 @@ extern "C" int maest_cast_weights_multi(int n, const float* const* src, void* co
                           "maest_cast_weights_multi: bad item %d", k);
             tab.src[i] = src[k]; tab.dst[i] = dst[k]; tab.dst_t[i] = dst_t[k];
             tab.rows[i] = rows[k]; tab.cols[i] = cols[k];
+            tab.scaled_rows[i] = scaled_rows ? scaled_rows[k] : 0;
             tab.tile_begin[i] = tiles;
             tiles += ((rows[k] + 63) / 64) * ((cols[k] + 63) / 64);
         }
         tab.tile_begin[tab.n] = tiles;
+        tab.row_scale = row_scale;
         if (dtype == MAEST_BF16)
             hipLaunchKernelGGL(cast_weights_multi_kernel<bf16_t>, dim3(tiles), dim3(256), 64 * 65 * 4,
                                (hipStream_t)stream, tab);

@@ -44,6 +44,8 @@ from . import ops
 from .labels import discogs_400labels, discogs_519labels
 from .melspectrogram import MelSpectrogram
 
+LOG2E = 1.4426950408889634      # softmax exponent base change (csrc/attn_common.h)
+
 _logger = logging.getLogger("MAEST")
 
 EMBED_DIM = 768
@@ -119,6 +121,13 @@ class _Weights:
     def __init__(self):
         self._cache = {}
         self.epoch = 0          # bumped whenever every copy is dropped (part of the hipGraph cache key)
+        # {id(parameter): rows}: parameters whose PLAIN low-precision copy carries `row_scale` on its first `rows` rows (the q rows of
+        # the qkv projections in bf16 mode: include/maest_hip.h MAEST_BF16_QS); the transposed copies (dgrad) stay unscaled
+        self.scaled_rows = {}
+        self.row_scale = 1.0
+
+    def _srows(self, p, dtype):
+        return self.scaled_rows.get(id(p), 0) if dtype != torch.float32 else 0
 
     def get(self, p: torch.Tensor, dtype, transposed=False, pad_cols_to: int = 0):
         key = (id(p), dtype, transposed, pad_cols_to)
@@ -131,6 +140,9 @@ class _Weights:
         if not transposed:
             if dtype == torch.float32:
                 out = w2
+            elif self._srows(p, dtype):
+                out = ops.cast_weights_multi([w2], dtype, want=True, want_t=False, scaled_rows=[self._srows(p, dtype)],
+                                             row_scale=self.row_scale)[0][0]
             else:
                 out, _ = ops.cast_weights(w2, dtype, want=True, want_t=False)
         else:
@@ -162,12 +174,24 @@ class _Weights:
                     break
         if not stale:
             return
-        outs = ops.cast_weights_multi([p.detach() for p in stale], dtype, want=dtype != torch.float32, want_t=with_t)
+        outs = ops.cast_weights_multi([p.detach() for p in stale], dtype, want=dtype != torch.float32, want_t=with_t,
+                                      scaled_rows=[self._srows(p, dtype) for p in stale], row_scale=self.row_scale)
         for p, (o, ot) in zip(stale, outs):
             if o is not None:
                 self._cache[(id(p), dtype, False, 0)] = (p._version, o, weakref.ref(p))
             if ot is not None:
                 self._cache[(id(p), dtype, True, 0)] = (p._version, ot, weakref.ref(p))
+
+    def scaled_biases(self, biases, rows: int):
+        """fp32 copies of `biases` with the first `rows` entries multiplied by row_scale (the q part of the qkv biases beside the
+        row-scaled weight copies), all in one launch; cached like the weight copies."""
+        stale = [b for b in biases if self._fresh((id(b), "scaled-bias", False, rows), b) is None]
+        if stale:
+            outs = ops.cast_weights_multi([b.detach().reshape(-1, 1) for b in stale], torch.float32, want=True, want_t=False,
+                                          scaled_rows=[rows] * len(stale), row_scale=self.row_scale)
+            for b, (o, _) in zip(stale, outs):
+                self._cache[(id(b), "scaled-bias", False, rows)] = (b._version, o.reshape(-1), weakref.ref(b))
+        return [self._cache[(id(b), "scaled-bias", False, rows)][1] for b in biases]
 
     def clear(self):
         self._cache.clear()
@@ -205,6 +229,10 @@ class _Engine:
         # the attention backward's delta = rowsum(dO * O) comes out of the epilogue of the proj dgrad GEMM (which produces
         # dO) instead of a separate pass over dO and O (ops.gemm_nt_rowdot)
         self.fold_delta = True
+        # bf16 mode: scale * log2(e) of the softmax rides in the q rows of the qkv projections' forward operand copies (and in the q part
+        # of a copy of their biases), so the attention kernels read q' = scale * log2(e) * q rounded ONCE (MAEST_BF16_QS: the forward
+        # takes its fragments straight from the rows, forward and backward exponentiate the same operand product)
+        self.fold_qscale = True
         self._weights_dirty = False
         self._side = {}
 
@@ -256,7 +284,14 @@ class _Engine:
         mats += [m.patch_embed.proj.weight, m.head[1].weight]
         if m.distilled_type == "separated":
             mats.append(m.head_dist.weight)
+        scale = m.blocks[0].attn.scale
+        qs = bool(self.fold_qscale) and dt == torch.bfloat16
+        want_rows = {id(blk.attn.qkv.weight): EMBED_DIM for blk in m.blocks} if qs else {}
+        if want_rows != W.scaled_rows or (qs and W.row_scale != scale * LOG2E):
+            W.clear()
+            W.scaled_rows, W.row_scale = want_rows, scale * LOG2E
         W.refresh(mats, dt, with_t=save)
+        qkv_bias = W.scaled_biases([blk.attn.qkv.bias for blk in m.blocks], EMBED_DIM) if qs else [blk.attn.qkv.bias for blk in m.blocks]
 
         t_str, f_str = stripes if stripes is not None else (None, None)
         cols = ops.patch_im2col(x3, tok_ft, dt, perm=perm, lam=lam, t_stripes=t_str, f_stripes=f_str)
@@ -270,7 +305,7 @@ class _Engine:
         if save:
             ctx["cols"] = cols
             ctx["blocks"] = []
-        scale = m.blocks[0].attn.scale
+            ctx["qs"] = qs
         nblocks = len(m.blocks) if stop_block < 0 else stop_block + 1
         # bf16 perf mode: the proj / fc2 GEMMs emit their output (bias included) in bf16 and the residual add rides in
         # the LayerNorm that follows (ops.add_layernorm_fwd) -- the fp32 stream is read and rewritten by a streaming
@@ -288,12 +323,12 @@ class _Engine:
             else:
                 r = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, dt, save_stats=save)
                 ln1, mean1, rstd1 = r if save else (r, None, None)
-            qkv = gemm_nt(ln1, W.get(blk.attn.qkv.weight, dt), blk.attn.qkv.bias, out_dtype=dt)
+            qkv = gemm_nt(ln1, W.get(blk.attn.qkv.weight, dt), qkv_bias[i], out_dtype=dt)
             tail = self.head_tail and stop_block < 0 and i == nblocks - 1
             # (training needs the backward kernel that honours the restriction; otherwise the attention stays complete
             # and only the per-token part of the block is restricted)
             q_rows = HEAD_TOKENS if tail and (not save or ops.attn_bwd_rows_supported(dt, N)) else None
-            r = ops.attn_fwd(qkv, B, N, scale, save_lse=save, q_rows=q_rows, x3=x3m)
+            r = ops.attn_fwd(qkv, B, N, scale, save_lse=save, q_rows=q_rows, x3=x3m, q_prescaled=qs)
             ao, lse = r if save else (r, None)
             ao_full, x_full, Mb = ao, x, M
             if tail:      # from here on the block lives on [B * 2, 768]
@@ -362,6 +397,7 @@ class _Engine:
         complete, so the RCCL all-reduce of a bucket overlaps with the rest of the backward."""
         m, W = self.m, self.w
         x3m = ctx["x3m"]
+        qs = ctx["qs"]
         gemm_nt = partial(ops.gemm_nt, x3=x3m)
         dt, B, N = ctx["dt"], ctx["B"], ctx["N"]
         Fp = m.freq_new_pos_embed.shape[2]
@@ -493,14 +529,14 @@ class _Engine:
                 # back to the token-major layout: the head tokens' rows, zeros for the queries the kernel still visits
                 # (its first 32-row tile when it honours q_rows, every row otherwise)
                 dao = ops.scatter_head_rows(dao, B, N, HEAD_TOKENS, min(32, N) if s["q_rows"] else N)
-                dqkv = ops.attn_bwd(s["qkv"], s["ao_full"], dao, s["lse"], B, N, blk.attn.scale, q_rows=s["q_rows"], x3=x3m)
+                dqkv = ops.attn_bwd(s["qkv"], s["ao_full"], dao, s["lse"], B, N, blk.attn.scale, q_rows=s["q_rows"], x3=x3m, q_prescaled=qs)
             elif self.fold_delta and ops.get_option("attn_bwd") != 2:
                 # delta = rowsum(dO * O) per (clip, head, query) out of the C-tile pass of the GEMM that produces dO
                 dao, delta = ops.gemm_nt_rowdot(dx1_lp, wt_proj, s["ao_full"], N, out_dtype=dt, x3=x3m)
-                dqkv = ops.attn_bwd(s["qkv"], None, dao, s["lse"], B, N, blk.attn.scale, x3=x3m, delta=delta)
+                dqkv = ops.attn_bwd(s["qkv"], None, dao, s["lse"], B, N, blk.attn.scale, x3=x3m, delta=delta, q_prescaled=qs)
             else:
                 dao = gemm_nt(dx1_lp, wt_proj, None, out_dtype=dt)
-                dqkv = ops.attn_bwd(s["qkv"], s["ao_full"], dao, s["lse"], B, N, blk.attn.scale, x3=x3m)
+                dqkv = ops.attn_bwd(s["qkv"], s["ao_full"], dao, s["lse"], B, N, blk.attn.scale, x3=x3m, q_prescaled=qs)
             wgrad(p + "attn.qkv.weight", p + "attn.qkv.bias", dqkv, s["ln1"], 3 * EMBED_DIM, EMBED_DIM)
             dln1 = gemm_nt(dqkv, W.get(blk.attn.qkv.weight, dt, transposed=True), None, out_dtype=dt)
             gw, gb = buf(p + "norm1.weight", EMBED_DIM), buf(p + "norm1.bias", EMBED_DIM)

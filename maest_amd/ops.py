@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_ATOMIC, EPI_MUL, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F16, F32, F32X3, call
+from ._lib import BF16, BF16_QS, EPI_ATOMIC, EPI_MUL, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F16, F32, F32X3, call
 
 DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -204,8 +204,10 @@ def cast_weights(src: torch.Tensor, dtype, want=True, want_t=False):
     return dst, dst_t
 
 
-def cast_weights_multi(srcs, dtype, want=True, want_t=False):
-    """Many fp32 parameters -> operand copies in ONE launch.  Returns a list of (copy | None, transposed | None)."""
+def cast_weights_multi(srcs, dtype, want=True, want_t=False, scaled_rows=None, row_scale=1.0):
+    """Many fp32 parameters -> operand copies in ONE launch.  Returns a list of (copy | None, transposed | None).
+    scaled_rows[i] > 0: the first scaled_rows[i] rows of the i-th plain copy (not of its transpose) are multiplied by row_scale before
+    the rounding (the q rows of a qkv projection for MAEST_BF16_QS attention)."""
     _chk(*srcs)
     n = len(srcs)
     w2 = [s.reshape(s.shape[0], -1) for s in srcs]
@@ -224,9 +226,10 @@ def cast_weights_multi(srcs, dtype, want=True, want_t=False):
     a_dt = vp(*[ptr(o[1]) for o in outs])
     a_r = ip(*[w.shape[0] for w in w2])
     a_c = ip(*[w.shape[1] for w in w2])
+    a_s = ip(*([0] * n if scaled_rows is None else [int(v) for v in scaled_rows]))
     _timed_call("maest_cast_weights_multi", 0.0, n, ctypes.cast(a_src, ctypes.c_void_p), ctypes.cast(a_dst, ctypes.c_void_p),
                 ctypes.cast(a_dt, ctypes.c_void_p), ctypes.cast(a_r, ctypes.c_void_p), ctypes.cast(a_c, ctypes.c_void_p),
-                DT[dtype], _s(srcs[0]))
+                ctypes.cast(a_s, ctypes.c_void_p), float(row_scale), DT[dtype], _s(srcs[0]))
     return outs
 
 
@@ -279,15 +282,17 @@ def _attn_flops(B, N, q_rows, per_pair):
     return per_pair * B * HEADS * nq * N * HEAD_DIM
 
 
-def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False, q_rows=None, x3: bool = False):
+def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False, q_rows=None, x3: bool = False, q_prescaled=False):
     """q_rows: only the first q_rows queries of every clip are wanted (rows beyond the 32-row tile that holds them are
-    left unwritten in `out` / `lse`)."""
+    left unwritten in `out` / `lse`).  q_prescaled (bf16 only): the q columns hold scale * log2(e) * q (MAEST_BF16_QS)."""
     _chk(qkv)
+    assert not q_prescaled or (qkv.dtype == torch.bfloat16 and not x3)
     assert qkv.shape == (B * N, 3 * EMBED)
     out = torch.empty((B * N, EMBED), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device) if save_lse else None
     _timed_call("maest_attn_fwd", _attn_flops(B, N, q_rows, 4.0), _p(qkv), _p(out), _p(lse), B, N,
-                _mm_code(qkv.dtype, x3), scale, N if q_rows is None else q_rows, _s(qkv), _entry="maest_attn_fwd_rows")
+                BF16_QS if q_prescaled else _mm_code(qkv.dtype, x3), scale, N if q_rows is None else q_rows, _s(qkv),
+                _entry="maest_attn_fwd_rows")
     return (out, lse) if save_lse else out
 
 
@@ -296,9 +301,11 @@ def attn_bwd_rows_supported(dtype, N: int) -> bool:
     return dtype == torch.bfloat16 and -(-N // 32) + 2 <= 12 and get_option("attn_bwd") in (0, 3)
 
 
-def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float, q_rows=None, x3: bool = False, delta=None):
-    """`delta` (fp32 [B, 12, N] = rowsum(dO * O), from gemm_nt_rowdot) given: `out` is not needed (pass None)."""
+def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float, q_rows=None, x3: bool = False, delta=None, q_prescaled=False):
+    """`delta` (fp32 [B, 12, N] = rowsum(dO * O), from gemm_nt_rowdot) given: `out` is not needed (pass None).
+    q_prescaled (bf16 only): the q columns of `qkv` hold scale * log2(e) * q (MAEST_BF16_QS); dQ is still d / d(true q)."""
     _chk(qkv, out, dout, lse, delta)
+    assert not q_prescaled or (qkv.dtype == torch.bfloat16 and not x3)
     assert dout.dtype == qkv.dtype and (out is None or out.dtype == qkv.dtype)
     if delta is None:
         assert out is not None
@@ -308,7 +315,8 @@ def attn_bwd(qkv, out, dout, lse, B: int, N: int, scale: float, q_rows=None, x3:
         out = None
     dqkv = torch.empty_like(qkv)
     _timed_call("maest_attn_bwd", _attn_flops(B, N, q_rows, 10.0), _p(qkv), _p(out), _p(dout), _p(lse),
-                _p(delta), _p(dqkv), B, N, _mm_code(qkv.dtype, x3), scale, N if q_rows is None else q_rows, _s(qkv),
+                _p(delta), _p(dqkv), B, N, BF16_QS if q_prescaled else _mm_code(qkv.dtype, x3), scale,
+                N if q_rows is None else q_rows, _s(qkv),
                 _entry="maest_attn_bwd_rows")
     return dqkv
 

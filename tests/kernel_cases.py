@@ -9,6 +9,7 @@ import math
 
 import numpy as np
 import torch
+from functools import partial
 import torch.nn.functional as F
 
 from maest_amd import _lib, ops
@@ -254,7 +255,11 @@ def _attn_ref(qkv, B, N, scale):
     return (att @ v).transpose(1, 2).reshape(B * N, 768), torch.logsumexp((q @ k.transpose(-2, -1)) * scale, -1)
 
 
-def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2, fwd_tol=2e-2):
+def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2, fwd_tol=2e-2, qs=False):
+    """qs (bf16 only): the MAEST_BF16_QS contract -- the q columns of the tensor handed to the kernels hold q' = scale * log2(e) * q
+    (rounded once); the oracle runs on q = q' / (scale * log2(e)) and dQ is compared as the gradient with respect to that q."""
+    assert not qs or dtype == torch.bfloat16
+    attn_fwd, attn_bwd = partial(ops.attn_fwd, q_prescaled=qs), partial(ops.attn_bwd, q_prescaled=qs)
     qkv = rnd((B * N, 2304), seed, 1.0).to(dtype)
     if spike:  # force a large running-max jump at a late key tile (online-softmax rescale branch)
         qf = qkv.float().clone()
@@ -262,8 +267,14 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2, fwd_to
         qf[key, 768:768 + 64] = qf[3, 0:64] * 6.0
         qkv = qf.to(dtype)
     scale = 0.125
-    out, lse = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
-    x = qkv.float().requires_grad_(True)
+    x = qkv.float()
+    if qs:
+        c = scale * 1.4426950408889634
+        qp = (qkv[:, :768].float() * c).to(dtype)          # what the row-scaled projection writes
+        qkv = torch.cat([qp, qkv[:, 768:]], dim=1).contiguous()
+        x = torch.cat([qp.float() / c, x[:, 768:]], dim=1)
+    out, lse = attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
+    x = x.requires_grad_(True)
     ref, ref_lse = _attn_ref(x, B, N, scale)
     rt, at = (2e-5, 2e-5) if dtype == torch.float32 else (fwd_tol, fwd_tol)
     close(out, ref, rt, at, "attention fwd")
@@ -275,15 +286,15 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2, fwd_to
         # persistent form (3) at this N whatever it is (its Q is pre-scaled by scale * log2 e and rounded to bf16 once more, its
         # row sums are those of the rounded probabilities: close, not equal)
         with ops.options(attn_fwd=2):
-            out2, lse2 = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
+            out2, lse2 = attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
         close(out2, ref, rt, at, "attention fwd (four-wave workgroups, LDS-DMA tiles)")
         with ops.options(attn_fwd=1):
-            out1, lse1 = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
+            out1, lse1 = attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
         close(out1, ref, rt, at, "attention fwd (register-staged tiles)")
         assert torch.equal(out1, out2) and torch.equal(lse1, lse2), "DMA-fed and register-staged attention forward differ"
         with ops.options(attn_fwd=3):
-            out3, lse3 = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
-            out3b, lse3b = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
+            out3, lse3 = attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
+            out3b, lse3b = attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
         close(out3, ref, rt, at, "attention fwd (persistent)")
         close(lse3, ref_lse, 1e-4, fwd_tol, "attention lse (persistent)")
         assert torch.equal(out3, out3b) and torch.equal(lse3, lse3b), "the persistent attention forward does not repeat bit for bit"
@@ -291,13 +302,13 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2, fwd_to
         # takes seconds per launch and the CPU suite has to stay short)
         for nw in (() if _lib.host_emulation() else (5, 6, 8)):
             with ops.options(attn_fwd=2, attn_fwd_waves=nw):
-                outw, lsew = ops.attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
+                outw, lsew = attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
             assert torch.equal(outw, out2) and torch.equal(lsew, lse2), f"attention forward with {nw} waves per workgroup differs"
     # backward (the oracle's autograd on the same rounded operands)
     dout = rnd((B * N, 768), seed + 1).to(dtype)
     ref.backward(dout.float())
     out_ref_lp = ref.detach().to(dtype)
-    dqkv = ops.attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
+    dqkv = attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
     rt, at = (1e-4, 1e-4) if dtype == torch.float32 else (bf16_tol, bf16_tol)
     g = x.grad
     close(dqkv[:, 1536:], g[:, 1536:], rt, at, "attention dV")
@@ -308,28 +319,40 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2, fwd_to
         # (attn_bwd = 4) run the same products in the same order: bit for bit, ragged last tiles included
         args = (qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
         with ops.options(attn_bwd=1):
-            dq_dma = ops.attn_bwd(*args)
+            dq_dma = attn_bwd(*args)
         with ops.options(attn_bwd=4):
-            dq_reg = ops.attn_bwd(*args)
+            dq_reg = attn_bwd(*args)
         close(dq_dma, g, rt, at, "attention backward (two-kernel, DMA-fed tiles)")
         assert torch.equal(dq_dma, dq_reg), "DMA-fed and register-staged two-kernel attention backward differ"
+    if dtype == torch.bfloat16:
+        # the pairing the model runs: the backward fed with the out / lse its OWN forward wrote (above: the oracle's), for the
+        # four-wave form and for the persistent form -- whose lse is the log-sum of its rounded probabilities, so that the P the
+        # backward recomputes does not sum to exactly 1 per row: inside the same tolerance against autograd
+        for form, what in ((2, "four-wave"), (3, "persistent")):
+            with ops.options(attn_fwd=form):
+                o_f, lse_f = attn_fwd(qkv.to(dev), B, N, scale, save_lse=True)
+            dq_f = attn_bwd(qkv.to(dev), o_f, dout.to(dev), lse_f, B, N, scale)
+            # (raw q through the persistent forward: that kernel rounds scale * log2(e) * q to bf16 a second time, the backward does
+            # not -- on a forced spike the two disagree by ~1.5e-2 on the dominating exponent; the model feeds pre-scaled q, `qs`)
+            k = 2.0 if (form == 3 and spike and not qs) else 1.0
+            close(dq_f, g, k * rt, k * at, f"attention backward on the {what} forward's own out / lse")
     if dtype == torch.bfloat16 and N <= 320:
         # the call above took the fused one-pass kernel (bf16, <= 10 key blocks); the two-kernel dK/dV + dQ form must
         # agree with the oracle too, and the two with each other to bf16 rounding of the same quantities
         with ops.options(attn_bwd=1):
-            dq2 = ops.attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
+            dq2 = attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
         close(dq2[:, 1536:], g[:, 1536:], rt, at, "attention dV (two-kernel)")
         close(dq2[:, 768:1536], g[:, 768:1536], rt, at, "attention dK (two-kernel)")
         close(dq2[:, :768], g[:, :768], rt, at, "attention dQ (two-kernel)")
         close(dqkv, dq2.float(), 2e-2, 2e-2, "fused vs two-kernel attention backward")
         with ops.options(attn_bwd=2):     # the fused form with register-fed tiles (delta computed in flight)
-            dq3 = ops.attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
+            dq3 = attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
         close(dq3, g, rt, at, "attention backward (fused, register-fed)")
         if N > 256:
             # the default call above took the PERSISTENT form (one workgroup per CU walking its (batch, head) items); the
             # one-workgroup-per-item form against the oracle as well, and the two bit for bit (same sums in the same order)
             with ops.options(attn_bwd=3):
-                dq4 = ops.attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
+                dq4 = attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
             close(dq4, g, rt, at, "attention backward (fused, one workgroup per item)")
             assert torch.equal(dq4, dqkv), "persistent and per-item fused attention backward differ"
 

@@ -44,6 +44,15 @@ def test_emu_gemm_256_tile_full_line_stages(emu, dtype, gemm_options):
     KC.case_gemm(emu, dtype, 512, 256, 192 if dtype == torch.float32 else 384, identity=False)   # 6 stages > 5 buffers
 
 
+def test_emu_gemm_256_tile_full_line_stages_fp32_instantiation(emu, gemm_options):
+    """One small case of the fp32 instantiation of gemm_nt256w_kernel / gemm_tn256_kernel (the production path of precision "fp32"
+    and, with three bf16 MFMAs per product, of the default "bf16x3" inference) so that a CPU-only run exercises that template too:
+    K = 64 fp32 = two 128-byte stages; one 256 x 256 wgrad tile over 64 tokens."""
+    gemm_options(gemm_min_m=512)
+    KC.case_gemm(emu, torch.float32, 512, 256, 64, identity=False)
+    gemm_options(gemm_variant=4)
+    KC.case_gemm_tn(emu, torch.float32, 64, 256, 256)
+
 
 def test_emu_gemm_one_wave_per_simd_kernel(emu, gemm_options):
     """gemm_nt256o_kernel's host twin (the C++ form of every owned-register primitive of gemm_nt_ow.hip): 1, 2, 3 and 7 K stages
@@ -116,6 +125,12 @@ def test_emu_layernorm(emu, dtype):
 def test_emu_attention(emu, dtype):
     # bf16: two key tiles; fp32 (4x the emulated MFMAs): one tile here, its multi-tile path is the spike case below
     KC.case_attention(emu, dtype, 1, 75 if dtype == torch.bfloat16 else 40)
+
+
+def test_emu_attention_prescaled_q(emu):
+    """MAEST_BF16_QS: q columns pre-multiplied by scale * log2(e); every bf16 form (the persistent forward reads its Q fragments
+    straight from the rows) against the oracle on the true q; two key tiles, ragged."""
+    KC.case_attention(emu, torch.bfloat16, 1, 75, qs=True)
 
 
 def test_emu_attention_multi_tile_spike(emu):

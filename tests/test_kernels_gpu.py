@@ -121,6 +121,13 @@ def test_attention(dtype, BN):
     KC.case_attention(DEV, dtype, *BN)
 
 
+@pytest.mark.parametrize("BN", [(2, 560), (3, 281), (1, 875), (1, 64), (13, 875), (24, 290), (2, 321), (1, 1685)])
+def test_attention_prescaled_q(BN):
+    """MAEST_BF16_QS (what the bf16 model runs): q columns pre-multiplied by scale * log2(e) -- every forward / backward form against the
+    fp32 oracle on q = q' / (scale * log2 e); the persistent forward takes its Q fragments straight from the rows."""
+    KC.case_attention(DEV, torch.bfloat16, *BN, qs=True)
+
+
 @pytest.mark.parametrize("BN", [(1, 1685), (13, 875), (45, 560), (2, 321), (30, 551)])
 def test_attention_persistent_forward_walks_items(BN):
     """attn_fwd_pw_kernel (bf16, N > 320): 9 / 5 / 3 / 2 work items of 192 query rows per (batch, head); with B * 12 * items > 512 the
@@ -151,6 +158,10 @@ def test_attention_rescale_branch():
     # running maximum of ~4).  Its Q is rounded once more after the scale * log2(e) pre-scaling: at |score| ~ 70 (log2 units) that is
     # ~1.5e-2 on the log-sum-exp (the reference's own 16-bit autocast rounds such a score to 3e-2)
     KC.case_attention(DEV, torch.bfloat16, 2, 560, spike=True, bf16_tol=8e-2, fwd_tol=4e-2)
+    # with the factor folded into the operand (MAEST_BF16_QS) q' is rounded once and the backward exponentiates the very product the
+    # forward did: the ordinary forward tolerance holds on the spike as well
+    KC.case_attention(DEV, torch.bfloat16, 1, 290, spike=True, bf16_tol=8e-2, qs=True)
+    KC.case_attention(DEV, torch.bfloat16, 2, 560, spike=True, bf16_tol=8e-2, qs=True)
 
 
 @pytest.mark.parametrize("dtype", DT)
