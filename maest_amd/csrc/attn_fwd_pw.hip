@@ -74,6 +74,12 @@ constexpr float PW_COLD = 1.0e-30f;           // ... and, on an item's first til
 #ifndef PW_DMAPOS
 #define PW_DMAPOS 0       // where a tile's eight LDS-DMA requests ride (timing variants)
 #endif
+#ifndef PW_ORDER
+#define PW_ORDER 0        // MFMAs of a pipeline region: 0 = the eight P V products, then the eight S' products; 1 = alternating (P V in the even
+#endif                    // slots, S' in the odd ones: four MFMAs between two on the same accumulator): equal time (r05_attn_fwd_pw_variants.txt)
+#ifndef PW_TAILNOP
+#define PW_TAILNOP 0      // 1: the 12 wait states behind a unit's last S' MFMA also inside the pipeline regions (timing variant; see pw_s_mfma)
+#endif
 #ifndef PW_ABLATE
 #define PW_ABLATE 0       // timing experiments only (scratch/pw_ablate.sh; results wrong on purpose): bit 0 no LDS-DMA requests, 1 no
 #endif                    // barrier / vmcnt wait, 2 no softmax slices, 3 no MFMAs, 4 no fragment reads, 5 no stores, 6 no Q take, 8 v_mov for v_exp
@@ -351,8 +357,12 @@ __device__ __forceinline__ void pw_read_v(PwCtx& c) { pw_read_v_all(c, std::make
 // (S', -m) are owned arch VGPRs -- the VALU reads S' in place --, A / B the fragment registers.  TILE0: the item's first key
 // tile, m = 0: C is the inline constant.  Wait states hipcc does not insert for an asm MFMA: s_nop 1 in front of the group (a
 // v_accvgpr_write / VALU result as operand), 12 states behind its last one before a VALU may read D (the readers are a
-// pipeline region away in program order; the nops make that a guarantee).
-template <int I, int BUF, int SET, int K, bool TILE0>
+// pipeline region away in program order; the nops make that a guarantee).  NOPS = false (inside a pipeline region whose successor
+// region opens with a P V MFMA): the first reader -- slice 0 of the next region, S' registers 0 / 1 of key block 0, last written by MFMA
+// K = 6 -- then sits behind MFMA K = 7, the region's closing statements and that P V MFMA: two matrix-pipe occupancies (>= 64 cycles) and
+// more than 20 issued instructions behind its producer, no nops needed; key block 1's registers are first read eight slots later.
+// (-2.5 % on the kernel: profiles/r05_attn_fwd_pw_variants.txt)
+template <int I, int BUF, int SET, int K, bool TILE0, bool NOPS = true>
 __device__ __forceinline__ void pw_s_mfma(PwCtx& c) {
     constexpr int KB = PW_CHAIN ? K >> 2 : K & 1, J = PW_CHAIN ? K & 3 : K >> 1;
 #if PW_DEV
@@ -370,7 +380,7 @@ __device__ __forceinline__ void pw_s_mfma(PwCtx& c) {
         else
             asm volatile("v_mfma_f32_32x32x16_bf16 v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]"
                          : : "i"(S), "i"(S + 15), "i"(KF), "i"(KF + 3), "i"(Q), "i"(Q + 3), "i"(NM), "i"(NM + 15));
-    } else if constexpr (K == 7) {
+    } else if constexpr (K == 7 && (NOPS || PW_TAILNOP)) {
         asm volatile("v_mfma_f32_32x32x16_bf16 v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]\n\ts_nop 7\n\ts_nop 3"
                      : : "i"(S), "i"(S + 15), "i"(KF), "i"(KF + 3), "i"(Q), "i"(Q + 3));
     } else {
@@ -562,15 +572,24 @@ __device__ __forceinline__ void pw_dma_piece(const PwDma& d, char* smem, int wav
 template <int I, int PAR, bool MASK, bool PV, bool PV0, bool SN, bool SN0, bool KN, int K>
 __device__ __forceinline__ void pw_slot(PwCtx& c, int klim, const PwDma& dm, char* smem, int wave) {
     constexpr int BUF = (PAR + I) & 1;
-    if constexpr (K < 8) {
+    if constexpr (PW_ORDER == 1) {
+        if constexpr ((K & 1) == 0) {
+            if constexpr (PV) pw_pv_mfma<(I + 2) % 3, BUF ^ 1, K / 2, PV0>(c);
+        } else {
+            if constexpr (K == 1 && I == 2 && SN) pw_wait_lds();
+            if constexpr (SN) pw_s_mfma<(I + 1) % 3, BUF ^ 1, (I == 2 ? PAR ^ 1 : PAR), K / 2, SN0, false>(c);
+        }
+    } else if constexpr (K < 8) {
         if constexpr (PV) pw_pv_mfma<(I + 2) % 3, BUF ^ 1, K, PV0>(c);
     } else {
         if constexpr (K == 8 && I == 2 && SN) pw_wait_lds();
-        if constexpr (SN) pw_s_mfma<(I + 1) % 3, BUF ^ 1, (I == 2 ? PAR ^ 1 : PAR), K - 8, SN0>(c);
+        if constexpr (SN) pw_s_mfma<(I + 1) % 3, BUF ^ 1, (I == 2 ? PAR ^ 1 : PAR), K - 8, SN0, false>(c);
     }
     pw_sm_exp<BUF, K, MASK, false>(c, klim, 0.0f);
     if constexpr (I == 1 && KN && K < 8) pw_k_read<PAR ^ 1, K>(c);          // the next tile's K fragments, into the other set
-    if constexpr (I == 0 && K >= 8 && K < 12) {                            // this tile's V^T fragments, two pieces a slot
+    if constexpr (PW_ORDER == 1) {                                         // fragment K / 2 right behind the (previous tile's) product that read it
+        if constexpr (I == 0 && (K & 1)) pw_v_read<K / 2>(c);
+    } else if constexpr (I == 0 && K >= 8 && K < 12) {                     // this tile's V^T fragments, two pieces a slot
         pw_v_read<2 * (K - 8)>(c);
         pw_v_read<2 * (K - 8) + 1>(c);
     }
