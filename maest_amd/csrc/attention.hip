@@ -1056,19 +1056,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_dma_kernel(const bf16_t*
         dma_rows128(base, qbase, QKV_LD, qt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
         dma_rows128(base + TILE128, dobase, OUT_LD, qt * 64, 2 * wave, 2 * wave + 2, 1, N, lane);
     };
+    // The statistics of the next tile are REQUESTED here and first touched in stat_store, behind the tile's products: a use right behind
+    // the load (the scaling, the padding select) makes hipcc put its counted vmcnt wait there -- in front of the products -- and that wait
+    // also covers the four LDS-DMA pieces of the next tile requested just before (hidden from the compiler, not from the counter): the whole
+    // prefetch would be waited for before the tile it should overlap with (round 5: profiles/r05_attn_bwd_two_kernel.txt).
     float lse_r = 0.0f, dl_r = 0.0f;
     auto stat_load = [&](int qt) {
         if (tid < 64) {
-            const int qq = qt * 64 + tid;
-            lse_r = qq < N ? lse_b[qq] * LOG2E : -NEG_BIG;   // padded rows: P = 2^(-BIG) = 0
-            dl_r = qq < N ? dl_b[qq] : 0.0f;
+            const int qq = qt * 64 + tid, qc = qq < N ? qq : N - 1;
+            lse_r = lse_b[qc];
+            dl_r = dl_b[qc];
         }
     };
     auto stat_store = [&](int qt) {
         if (tid < 64) {
+            pin_loaded(lse_r);
+            pin_loaded(dl_r);
+            const int qq = qt * 64 + tid;
             float* st = reinterpret_cast<float*>(smem + (qt & 1) * BUF + 2 * TILE128);
-            st[tid] = lse_r;
-            st[64 + tid] = dl_r;
+            st[tid] = qq < N ? lse_r * LOG2E : -NEG_BIG;     // padded rows: P = 2^(-BIG) = 0
+            st[64 + tid] = qq < N ? dl_r : 0.0f;
         }
     };
     tile_dma(0);
@@ -1076,6 +1083,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_dma_kernel(const bf16_t*
     chunk16 kf[C::STEPS], vf[C::STEPS];
     row_frags_load<T>(kf, kbase, QKV_LD, key, N, h);
     row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
+#pragma unroll
+    for (int s = 0; s < C::STEPS; ++s) { pin_loaded(kf[s]); pin_loaded(vf[s]); }       // (see pin_loaded)
     const bool key_ok = key < N;
     const bool wave_active = blk.rb * 128 + wave * 32 < N;   // wave-uniform
     const f32x2_t c2v = {sc_c2, sc_c2};
@@ -1166,8 +1175,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16_t* _
     const bool q_ok = q < N;
     const bool wave_active = blk.rb * 128 + wave * 32 < N;   // wave-uniform
     const int qc = q_ok ? q : N - 1;
-    const float lse_q = lse[((int64_t)b * NHEADS + head) * N + qc] * LOG2E;
-    const float dl_q = delta[((int64_t)b * NHEADS + head) * N + qc];
+    float lse_q = lse[((int64_t)b * NHEADS + head) * N + qc] * LOG2E;
+    float dl_q = delta[((int64_t)b * NHEADS + head) * N + qc];
+#pragma unroll
+    for (int s = 0; s < C::STEPS; ++s) { pin_loaded(qf[s]); pin_loaded(dof[s]); }     // (see pin_loaded: no counted vmcnt waits inside the loop)
+    pin_loaded(lse_q);
+    pin_loaded(dl_q);
     const f32x2_t nlse = {-lse_q, -lse_q}, dlv = {dl_q, dl_q}, c2v = {sc_c2, sc_c2};
     f32x16_t dq[2];
 #pragma unroll

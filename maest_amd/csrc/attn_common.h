@@ -34,6 +34,21 @@ typedef short v4i16a_t __attribute__((ext_vector_type(4)));
 // A generic pointer into shared memory as an LDS pointer.  Device build: the low half of the flat address IS the LDS byte address; going
 // through the integer avoids the null test hipcc puts around a flat -> LDS address-space cast (on `smem + offset` that test has come out
 // as an illegal `v_cmp_ne_u32 0, src_shared_base` -- "Operand has incorrect register class" -- depending on unrelated code in the kernel).
+// Make the compiler finish a register-fragment load HERE (an empty asm statement that reads and "writes" the registers): hipcc otherwise sinks
+// loads whose first use sits inside the tile loop below the hand-placed `s_waitcnt vmcnt(0)` in front of the loop, and then keeps counted
+// vmcnt waits for them INSIDE the loop body -- which, on every later iteration, wait for the LDS-DMA pieces of the NEXT tile instead (the
+// DMA is hidden from the compiler but not from the counter): the prefetch then overlaps with a quarter of an iteration instead of a whole one.
+__device__ __forceinline__ void pin_loaded(chunk16& c) {
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(c));
+#endif
+}
+__device__ __forceinline__ void pin_loaded(float& x) {
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(x));
+#endif
+}
+
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 template <typename P>

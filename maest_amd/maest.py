@@ -30,6 +30,7 @@ Numeric modes (``model.precision``):
 from __future__ import annotations
 
 import logging
+import contextlib
 import math
 import warnings
 import weakref
@@ -233,6 +234,7 @@ class _Engine:
         # of a copy of their biases), so the attention kernels read q' = scale * log2(e) * q rounded ONCE (MAEST_BF16_QS: the forward
         # takes its fragments straight from the rows, forward and backward exponentiate the same operand product)
         self.fold_qscale = True
+        self.persistent_gemm = True      # see _gemm_form
         self._weights_dirty = False
         self._side = {}
 
@@ -258,9 +260,23 @@ class _Engine:
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
 
+    def _gemm_form(self, shared: bool):
+        """The bf16 NT GEMM's launch form for a pass (csrc/gemm_nt_ow.hip): persistent -- one workgroup per CU walking its tiles, the next
+        tile's first operand units requested from inside the epilogue: +0.5 % (training step) ... +0.8 % (inference) same-box,
+        profiles/r05_ab_gemm_persistent.txt -- when nothing else wants CUs during the pass; one workgroup per tile when the gradient
+        all-reduce's kernels run beside it (`shared`: a fixed tile list per workgroup cannot be re-dealt around them).  An explicit
+        MAEST_GEMM_WGS / set_option("gemm_wgs") is left alone."""
+        if not self.persistent_gemm or shared or ops.get_option("gemm_wgs") != 0:
+            return contextlib.nullcontext()
+        return ops.options(gemm_wgs=256)
+
     # ---- forward ----------------------------------------------------------------------------
-    def forward(self, x3: torch.Tensor, dt, *, toffset: int, tok_ft: torch.Tensor, perm, lam, stripes=None,
-                stop_block: int = -1, return_self_attention: bool = False, save: bool = False, x3m=None):
+    def forward(self, *args, **kw):
+        with self._gemm_form(shared=False):
+            return self._forward(*args, **kw)
+
+    def _forward(self, x3: torch.Tensor, dt, *, toffset: int, tok_ft: torch.Tensor, perm, lam, stripes=None,
+                 stop_block: int = -1, return_self_attention: bool = False, save: bool = False, x3m=None):
         """x3: fp32 [B, F, T] on the device; tok_ft: int32 [P, 2] kept patch tokens.  Returns (outputs, ctx).
         x3m: split-bf16 products on the fp32 tensors (the model's resolved mode; None: model.precision == "bf16x3")."""
         m, W = self.m, self.w
@@ -391,6 +407,10 @@ class _Engine:
 
     # ---- backward ---------------------------------------------------------------------------
     def backward(self, ctx, grads_out, sink=None):
+        with self._gemm_form(shared=sink is not None):
+            return self._backward(ctx, grads_out, sink)
+
+    def _backward(self, ctx, grads_out, sink=None):
         """grads_out: gradients w.r.t. the forward outputs (same tuple structure, entries may be None).
         Returns {parameter name: fp32 gradient}.  With a `sink` (maest_amd.dist.GradReducer) every
         gradient is written straight into the sink's flat bucket view and reported as soon as it is
