@@ -47,6 +47,17 @@ extern "C" {
                            the TRUE softmax scale; dQ comes out as the gradient with respect to the true q (so the projection's
                            dgrad / wgrad run on the unscaled weights), lse and the output are those of MAEST_BF16 up to rounding. */
 
+/* The split-bf16 ("bf16 x 3") product as ONE bf16 GEMM of three times the depth (round 5): an fp32 value x is hi + lo with hi = bf16(x),
+ * lo = bf16(x - hi); a row of K values is stored as 3 K bf16 values -- activations [ hi | hi | lo ] (MAEST_SPLIT3_A), weights
+ * [ hi | lo | hi ] (MAEST_SPLIT3_B) -- so that the plain bf16 GEMM over K' = 3 K accumulates hi*hi + hi*lo + lo*hi, the three terms of
+ * MAEST_F32X3, on the fast bf16 kernels (gemm_nt_ow.hip).  MAEST_SPLIT3_A: accepted as y_dtype of maest_layernorm_fwd /
+ * maest_add_layernorm_fwd (y: bf16 [rows, 3 * 768], ldy = 2304); MAEST_SPLIT3_B as the dtype of maest_cast_weights_multi (dst: bf16
+ * [rows, 3 * cols]; dst_t must be NULL); MAEST_F32X3_A3 as the dtype of maest_attn_fwd(_rows): MAEST_F32X3 with `out` written as
+ * MAEST_SPLIT3_A rows (bf16 [B * N, 3 * 768]). */
+#define MAEST_SPLIT3_A 5
+#define MAEST_SPLIT3_B 6
+#define MAEST_F32X3_A3 7
+
 /* GEMM epilogues */
 #define MAEST_F16 3 /* IEEE half: accepted as the INPUT dtype of maest_patch_im2col only (the loader's float16 mel batches,
                        discogs/dataset.py:58-67) */

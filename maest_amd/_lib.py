@@ -18,6 +18,7 @@ F32 = 0
 BF16 = 1
 F16 = 3     # IEEE half, input of maest_patch_im2col only
 BF16_QS = 4 # bf16 qkv tensor with q columns pre-multiplied by scale * log2(e) (maest_attn_* dtype only)
+SPLIT3_A, SPLIT3_B, F32X3_A3 = 5, 6, 7   # the split-bf16 product as one bf16 GEMM of 3 K (include/maest_hip.h)
 F32X3 = 2   # fp32 tensors, split-bf16 matrix products (maest_gemm_nt in_dtype / maest_attn_fwd dtype only)
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_MUL, EPI_ATOMIC = 0, 1, 2, 3, 4
 

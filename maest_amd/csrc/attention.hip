@@ -214,6 +214,24 @@ __device__ __forceinline__ void store_dT(const f32x16_t (&acc)[2], T* row_ptr, i
                       acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
 }
 
+// the same accumulator pair as MAEST_SPLIT3_A thirds of a bf16 [.., 3 * 768] row (`row_ptr`: the head's first column in the first third)
+__device__ __forceinline__ void store_dT_split3(const f32x16_t (&acc)[2], bf16_t* row_ptr, int lane, float mul) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t h0, l0, h1, l1;
+            split_bf2(acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul, h0, l0);
+            split_bf2(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul, h1, l1);
+            const chunk8 hi = {h0, h1}, lo = {l0, l1};
+            bf16_t* p = row_ptr + db * 32 + 8 * g + 4 * h;
+            *reinterpret_cast<chunk8*>(p) = hi;
+            *reinterpret_cast<chunk8*>(p + OUT_LD) = hi;
+            *reinterpret_cast<chunk8*>(p + 2 * OUT_LD) = lo;
+        }
+}
+
 __device__ __forceinline__ void store_dT_rows16(const f32x16_t (&acc)[2], bf16_t* row_ptr, int lane, float mul, bool ok) {
     store_32d_rows16(acc[0], row_ptr, lane, mul, ok);
     store_32d_rows16(acc[1], row_ptr + 32, lane, mul, ok);
@@ -231,7 +249,8 @@ template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(const T* __restrict__ qkv,
                                                                                 T* __restrict__ out,
                                                                                 float* __restrict__ lse, int B, int N,
-                                                                                float sc_c2, int q_rows) {
+                                                                                float sc_c2, int q_rows, int out_a3) {
+    // out_a3 (fp32 operands only): `out` is a bf16 [B * N, 3 * 768] tensor of MAEST_SPLIT3_A rows (hi | hi | lo of the fp32 result)
     using C = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K[key][d], V[key][d] }
 
@@ -345,7 +364,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(c
         // (staging O through LDS for whole-row stores was measured: no gain at N = 290, -16 % at N = 560;
         // profiles/r03_attn_fwd_ablation.txt.  The 16-byte pieces of store_dT_ok need no LDS and no barrier.)
         const bool ok = q < N && (!(MAEST_ABLATE_FWD & 16) || l_tot == 12345.0f);
-        store_dT_ok<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv, ok);
+        if (sizeof(T) == 4 && out_a3) {
+            if (ok) store_dT_split3(o, reinterpret_cast<bf16_t*>(out) + ((int64_t)b * N + q) * (3 * OUT_LD) + head * HD, lane, inv);
+        } else {
+            store_dT_ok<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv, ok);
+        }
         if (ok && lse != nullptr && h == 0) lse[((int64_t)b * NHEADS + head) * N + q] = m_run * LN2 + logf(l_tot);
     }
 }
@@ -1804,7 +1827,8 @@ int attn_fwd_pw_launch(const void* qkv, void* out, float* lse, int B, int N, Att
 bool attn_fwd_pw_available();   // false in a build whose register audit failed (maest_amd/build.py)
 
 template <typename T, bool X3 = false>
-static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, AttnScale sc, bool q_prescaled, int q_rows, hipStream_t st) {
+static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, AttnScale sc, bool q_prescaled, int q_rows, hipStream_t st,
+                           bool out_a3 = false) {
     using C = AttnCfg<T>;
     if constexpr (sizeof(T) == 2 && !X3) {
         const int afw = option(MAEST_OPT_ATTN_FWD);
@@ -1829,7 +1853,7 @@ static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N,
     static DeviceOnce once;
     ensure_dynamic_lds(once, &attn_fwd_kernel<T, X3>, smem_bytes);
     hipLaunchKernelGGL((attn_fwd_kernel<T, X3>), grid, dim3(256), smem_bytes, st, (const T*)qkv, (T*)out, lse, B, N, sc.c2,
-                       q_rows);
+                       q_rows, out_a3 ? 1 : 0);
     return check_launch("maest_attn_fwd");
 }
 
@@ -1932,12 +1956,13 @@ extern "C" int maest_attn_fwd_rows(const void* qkv, void* out, float* lse, int B
     MAEST_REQUIRE(qkv && out, "maest_attn_fwd: null pointer");
     MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_fwd: bad shape B=%d N=%d", B, N);
     MAEST_REQUIRE(q_rows > 0 && q_rows <= N, "maest_attn_fwd_rows: q_rows = %d outside 1..N", q_rows);
-    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3 || dtype == MAEST_BF16_QS,
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3 || dtype == MAEST_BF16_QS || dtype == MAEST_F32X3_A3,
                   "maest_attn_fwd: bad dtype %d", dtype);
     MAEST_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "maest_attn_fwd: 16-byte alignment");
     const bool qs = dtype == MAEST_BF16_QS;
     const AttnScale sc = attn_scale(scale, qs);
-    if (dtype == MAEST_F32X3) return attn_fwd_launch<float, true>(qkv, out, lse, B, N, sc, false, q_rows, (hipStream_t)stream);
+    if (dtype == MAEST_F32X3 || dtype == MAEST_F32X3_A3)
+        return attn_fwd_launch<float, true>(qkv, out, lse, B, N, sc, false, q_rows, (hipStream_t)stream, dtype == MAEST_F32X3_A3);
     return dtype == MAEST_F32 ? attn_fwd_launch<float>(qkv, out, lse, B, N, sc, false, q_rows, (hipStream_t)stream)
                               : attn_fwd_launch<bf16_t>(qkv, out, lse, B, N, sc, qs, q_rows, (hipStream_t)stream);
 }

@@ -108,6 +108,11 @@ __device__ __forceinline__ void split_bf16x8(const chunk16& c0, const chunk16& c
     hi = __builtin_bit_cast(bf16x8_t, h);
     lo = __builtin_bit_cast(bf16x8_t, l);
 }
+// (a, b) -> the packed bf16 pair of their hi parts and the pair of their lo parts (the split of split_bf16x8)
+__device__ __forceinline__ void split_bf2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf2(a, b);
+    lo = pack_bf2(a - u2f(hi << 16), b - u2f(hi & 0xffff0000u));
+}
 template <typename T, bool X3>
 __device__ __forceinline__ void mma_chunk2(f32x16_t& acc, const chunk16& a0, const chunk16& a1, const chunk16& b0,
                                            const chunk16& b1) {

@@ -70,6 +70,7 @@ struct CastTable {
     int scaled_rows[CAST_MAX_ITEMS];      // rows [0, scaled_rows) of dst (NOT of dst_t) are multiplied by row_scale before the rounding
     int tile_begin[CAST_MAX_ITEMS + 1];   // prefix sum of 64x64 tiles
     float row_scale;
+    int split3b;                          // dst rows are [ hi | lo | hi ] bf16 thirds of 3 x cols (MAEST_SPLIT3_B); dst_t unused
     int n;
 };
 template <typename T>
@@ -92,6 +93,14 @@ __global__ __launch_bounds__(256) void cast_weights_multi_kernel(const CastTable
         float v = 0.0f;
         if (r < rows && c < cols) {
             v = src[(int64_t)r * cols + c];
+            if constexpr (sizeof(T) == 2) {
+                if (tab.split3b) {
+                    const bf16_t hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+                    bf16_t* d3 = reinterpret_cast<bf16_t*>(tab.dst[it]) + (int64_t)r * 3 * cols + c;
+                    d3[0] = hi; d3[cols] = lo; d3[2 * cols] = hi;
+                    continue;
+                }
+            }
             if (dst != nullptr) dst[(int64_t)r * cols + c] = elem_traits<T>::from_f32(r < srows ? v * tab.row_scale : v);
         }
         tile[(i * 4 + ty) * 65 + tx] = v;
@@ -323,7 +332,7 @@ extern "C" int maest_cast_weights_multi(int n, const float* const* src, void* co
                                         const int* rows, const int* cols, const int* scaled_rows, float row_scale, int dtype,
                                         void* stream) {
     MAEST_REQUIRE(n > 0 && src && dst && dst_t && rows && cols, "maest_cast_weights_multi: null pointer / n <= 0");
-    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_cast_weights_multi: bad dtype");
+    MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_SPLIT3_B, "maest_cast_weights_multi: bad dtype");
     for (int base = 0; base < n; base += CAST_MAX_ITEMS) {
         CastTable tab;
         tab.n = n - base < CAST_MAX_ITEMS ? n - base : CAST_MAX_ITEMS;
@@ -340,7 +349,11 @@ extern "C" int maest_cast_weights_multi(int n, const float* const* src, void* co
         }
         tab.tile_begin[tab.n] = tiles;
         tab.row_scale = row_scale;
-        if (dtype == MAEST_BF16)
+        tab.split3b = dtype == MAEST_SPLIT3_B ? 1 : 0;
+        if (tab.split3b)
+            for (int i = 0; i < tab.n; ++i)
+                MAEST_REQUIRE(tab.dst[i] && !tab.dst_t[i], "maest_cast_weights_multi: MAEST_SPLIT3_B wants dst and no dst_t (item %d)", base + i);
+        if (dtype == MAEST_BF16 || dtype == MAEST_SPLIT3_B)
             hipLaunchKernelGGL(cast_weights_multi_kernel<bf16_t>, dim3(tiles), dim3(256), 64 * 65 * 4,
                                (hipStream_t)stream, tab);
         else

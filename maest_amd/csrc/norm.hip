@@ -31,7 +31,16 @@ __device__ __forceinline__ void ln_stats(const float (&v)[12], float eps, float&
     rs = 1.0f / sqrtf(var + eps);
 }
 __device__ __forceinline__ void store_row4(void* y, int dtype, int64_t off, float a, float b, float c, float d) {
-    if (dtype == MAEST_BF16) {
+    if (dtype == MAEST_SPLIT3_A) {        // [ hi | hi | lo ] thirds of a 3 x 768 bf16 row (`off` = row * ldy + column)
+        uint32_t h0, l0, h1, l1;
+        split_bf2(a, b, h0, l0);
+        split_bf2(c, d, h1, l1);
+        const chunk8 hi = {h0, h1}, lo = {l0, l1};
+        bf16_t* yp = reinterpret_cast<bf16_t*>(y) + off;
+        *reinterpret_cast<chunk8*>(yp) = hi;
+        *reinterpret_cast<chunk8*>(yp + LN_COLS) = hi;
+        *reinterpret_cast<chunk8*>(yp + 2 * LN_COLS) = lo;
+    } else if (dtype == MAEST_BF16) {
         chunk8 o;
         o[0] = pack_bf2(a, b);
         o[1] = pack_bf2(c, d);
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
         const int c = i * 256 + lane * 4;
         const float4 g = *reinterpret_cast<const float4*>(gamma + c);
         const float4 bt = *reinterpret_cast<const float4*>(beta + c);
-        store_row4(y, y_dtype, (int64_t)row * LN_COLS + c, (v[4 * i] - mu) * rs * g.x + bt.x,
+        store_row4(y, y_dtype, (int64_t)row * (y_dtype == MAEST_SPLIT3_A ? 3 * LN_COLS : LN_COLS) + c, (v[4 * i] - mu) * rs * g.x + bt.x,
                    (v[4 * i + 1] - mu) * rs * g.y + bt.y, (v[4 * i + 2] - mu) * rs * g.z + bt.z,
                    (v[4 * i + 3] - mu) * rs * g.w + bt.w);
     }
@@ -341,7 +350,8 @@ extern "C" int maest_layernorm_fwd(const float* x, int64_t ldx, const float* gam
     MAEST_REQUIRE(cols == LN_COLS, "maest_layernorm_fwd: cols must be 768, got %d", cols);
     MAEST_REQUIRE(rows > 0, "maest_layernorm_fwd: rows=%d", rows);
     MAEST_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "maest_layernorm_fwd: leading dims must be multiples of 4");
-    MAEST_REQUIRE(y_dtype == MAEST_F32 || y_dtype == MAEST_BF16, "maest_layernorm_fwd: bad dtype");
+    MAEST_REQUIRE(y_dtype == MAEST_F32 || y_dtype == MAEST_BF16 || y_dtype == MAEST_SPLIT3_A, "maest_layernorm_fwd: bad dtype");
+    MAEST_REQUIRE(y_dtype != MAEST_SPLIT3_A || ldy >= 3 * LN_COLS, "maest_layernorm_fwd: MAEST_SPLIT3_A rows are 3 x 768 wide (ldy = %lld)", (long long)ldy);
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma,
                        beta, y, ldy, y_dtype, mean, rstd, rows, eps);
     return check_launch("maest_layernorm_fwd");
@@ -353,7 +363,7 @@ extern "C" int maest_add_layernorm_fwd(const float* x, const void* delta, int de
     MAEST_REQUIRE(x && delta && x_out && gamma && beta && y, "maest_add_layernorm_fwd: null pointer");
     MAEST_REQUIRE(cols == LN_COLS, "maest_add_layernorm_fwd: cols must be 768, got %d", cols);
     MAEST_REQUIRE(rows > 0, "maest_add_layernorm_fwd: rows=%d", rows);
-    MAEST_REQUIRE((y_dtype == MAEST_F32 || y_dtype == MAEST_BF16) && (delta_dtype == MAEST_F32 || delta_dtype == MAEST_BF16),
+    MAEST_REQUIRE((y_dtype == MAEST_F32 || y_dtype == MAEST_BF16 || y_dtype == MAEST_SPLIT3_A) && (delta_dtype == MAEST_F32 || delta_dtype == MAEST_BF16),
                   "maest_add_layernorm_fwd: bad dtype");
     hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, delta,
                        delta_dtype, x_out, gamma, beta, y, y_dtype, mean, rstd, rows, eps);

@@ -183,6 +183,17 @@ class _Weights:
             if ot is not None:
                 self._cache[(id(p), dtype, True, 0)] = (p._version, ot, weakref.ref(p))
 
+    def split3(self, params):
+        """MAEST_SPLIT3_B copies (bf16 [out, 3 * in]: hi | lo | hi) of fp32 weight matrices, stale ones rebuilt in one launch; cached
+        like the other operand copies.  Returns them in order."""
+        key = lambda p: (id(p), "split3b", False, 0)
+        stale = [p for p in params if self._fresh(key(p), p) is None]
+        if stale:
+            outs = ops.cast_weights_multi([p.detach() for p in stale], ops.SPLIT3, want=True, want_t=False)
+            for p, (o, _) in zip(stale, outs):
+                self._cache[key(p)] = (p._version, o, weakref.ref(p))
+        return [self._cache[key(p)][1] for p in params]
+
     def scaled_biases(self, biases, rows: int):
         """fp32 copies of `biases` with the first `rows` entries multiplied by row_scale (the q part of the qkv biases beside the
         row-scaled weight copies), all in one launch; cached like the weight copies."""
@@ -235,6 +246,12 @@ class _Engine:
         # takes its fragments straight from the rows, forward and backward exponentiate the same operand product)
         self.fold_qscale = True
         self.persistent_gemm = True      # see _gemm_form
+        # "bf16x3" forwards that record no graph (the default evaluation mode): the three-term split product of the qkv / proj / fc1
+        # linears runs as ONE bf16 GEMM over 3 K on the fast bf16 kernel -- LayerNorm and the attention forward write their fp32
+        # results as [ hi | hi | lo ] bf16 rows (MAEST_SPLIT3_A), the weights are kept as [ hi | lo | hi ] rows (MAEST_SPLIT3_B):
+        # the same three products per k as MAEST_F32X3, accumulated in fp32 (fc2, whose operand comes out of a GEMM epilogue,
+        # and the last block's head-token rows stay on the eight-wave split kernel)
+        self.x3_fast = True
         self._weights_dirty = False
         self._side = {}
 
@@ -308,6 +325,10 @@ class _Engine:
             W.scaled_rows, W.row_scale = want_rows, scale * LOG2E
         W.refresh(mats, dt, with_t=save)
         qkv_bias = W.scaled_biases([blk.attn.qkv.bias for blk in m.blocks], EMBED_DIM) if qs else [blk.attn.qkv.bias for blk in m.blocks]
+        fast3 = bool(self.x3_fast) and x3m and not save
+        if fast3:
+            w3 = W.split3([lin.weight for blk in m.blocks for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1)])
+            w3 = {(i, n): w3[3 * i + j] for i in range(len(m.blocks)) for j, n in enumerate(("qkv", "proj", "fc1"))}
 
         t_str, f_str = stripes if stripes is not None else (None, None)
         cols = ops.patch_im2col(x3, tok_ft, dt, perm=perm, lam=lam, t_stripes=t_str, f_stripes=f_str)
@@ -337,14 +358,18 @@ class _Engine:
                 mean1, rstd1 = (r[2], r[3]) if save else (None, None)
                 pending = None
             else:
-                r = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, dt, save_stats=save)
+                r = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, ops.SPLIT3 if fast3 else dt, save_stats=save)
                 ln1, mean1, rstd1 = r if save else (r, None, None)
-            qkv = gemm_nt(ln1, W.get(blk.attn.qkv.weight, dt), qkv_bias[i], out_dtype=dt)
+            if fast3:
+                qkv = ops.gemm_nt(ln1, w3[(i, "qkv")], qkv_bias[i], out_dtype=torch.float32)
+            else:
+                qkv = gemm_nt(ln1, W.get(blk.attn.qkv.weight, dt), qkv_bias[i], out_dtype=dt)
             tail = self.head_tail and stop_block < 0 and i == nblocks - 1
             # (training needs the backward kernel that honours the restriction; otherwise the attention stays complete
             # and only the per-token part of the block is restricted)
             q_rows = HEAD_TOKENS if tail and (not save or ops.attn_bwd_rows_supported(dt, N)) else None
-            r = ops.attn_fwd(qkv, B, N, scale, save_lse=save, q_rows=q_rows, x3=x3m, q_prescaled=qs)
+            fast_blk = fast3 and not tail and not (i == stop_block and return_self_attention)
+            r = ops.attn_fwd(qkv, B, N, scale, save_lse=save, q_rows=q_rows, x3=x3m, q_prescaled=qs, out_split3=fast_blk)
             ao, lse = r if save else (r, None)
             ao_full, x_full, Mb = ao, x, M
             if tail:      # from here on the block lives on [B * 2, 768]
@@ -360,13 +385,20 @@ class _Engine:
                 r = ops.add_layernorm_fwd(x, d1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save_stats=save)
                 x1, ln2 = r[0], r[1]
                 mean2, rstd2 = (r[2], r[3]) if save else (None, None)
+            elif fast_blk:
+                x1 = ops.gemm_nt(ao, w3[(i, "proj")], blk.attn.proj.bias, out_dtype=torch.float32, epi=ops.EPI_RESIDUAL, aux_in=x)
+                ln2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, ops.SPLIT3)
+                mean2 = rstd2 = None
             else:
                 x1 = gemm_nt(ao, W.get(blk.attn.proj.weight, dt), blk.attn.proj.bias, out_dtype=torch.float32,
                                  epi=ops.EPI_RESIDUAL, aux_in=x)
                 r = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save_stats=save)
                 ln2, mean2, rstd2 = r if save else (r, None, None)
             h = torch.empty((Mb, blk.mlp.fc1.out_features), dtype=dt, device=x.device) if save else None
-            g = gemm_nt(ln2, W.get(blk.mlp.fc1.weight, dt), blk.mlp.fc1.bias, out_dtype=dt, epi=ops.EPI_GELU,
+            if fast_blk:
+                g = ops.gemm_nt(ln2, w3[(i, "fc1")], blk.mlp.fc1.bias, out_dtype=torch.float32, epi=ops.EPI_GELU)
+            else:
+                g = gemm_nt(ln2, W.get(blk.mlp.fc1.weight, dt), blk.mlp.fc1.bias, out_dtype=dt, epi=ops.EPI_GELU,
                             aux_out=h)
             if save:
                 ctx["blocks"].append(dict(x=x_full, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse, x1=x1,

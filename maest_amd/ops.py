@@ -9,9 +9,11 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, BF16_QS, EPI_ATOMIC, EPI_MUL, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F16, F32, F32X3, call
+from ._lib import BF16, BF16_QS, F32X3_A3, SPLIT3_A, SPLIT3_B, EPI_ATOMIC, EPI_MUL, EPI_GELU, EPI_NONE, EPI_RESIDUAL, F16, F32, F32X3, call
 
 DT = {torch.float32: F32, torch.bfloat16: BF16}
+SPLIT3 = "split3"     # output "dtype" of the LayerNorm / attention-forward wrappers and of cast_weights_multi: the split-bf16 operand rows of
+                      # include/maest_hip.h (MAEST_SPLIT3_A / _B): bf16 [rows, 3 * cols], one bf16 GEMM over 3 K = the bf16x3 product
 
 def _mm_code(dtype, x3: bool):
     """dtype code of a matrix-product operand.  `x3` ("bf16x3" precision mode): tensors stay fp32, but the product runs
@@ -213,10 +215,12 @@ def cast_weights_multi(srcs, dtype, want=True, want_t=False, scaled_rows=None, r
     w2 = [s.reshape(s.shape[0], -1) for s in srcs]
     dev = srcs[0].device
     outs = []
+    s3 = dtype == SPLIT3              # rows of [ hi | lo | hi ] bf16 thirds (MAEST_SPLIT3_B); no transposed copy
+    assert not (s3 and want_t)
     for w in w2:
         assert w.dtype == torch.float32 and w.is_contiguous()
         r, c = w.shape
-        outs.append((torch.empty((r, c), dtype=dtype, device=dev) if want else None,
+        outs.append((torch.empty((r, 3 * c if s3 else c), dtype=torch.bfloat16 if s3 else dtype, device=dev) if want else None,
                      torch.empty((c, r), dtype=dtype, device=dev) if want_t else None))
     vp = ctypes.c_void_p * n
     ip = ctypes.c_int * n
@@ -229,7 +233,7 @@ def cast_weights_multi(srcs, dtype, want=True, want_t=False, scaled_rows=None, r
     a_s = ip(*([0] * n if scaled_rows is None else [int(v) for v in scaled_rows]))
     _timed_call("maest_cast_weights_multi", 0.0, n, ctypes.cast(a_src, ctypes.c_void_p), ctypes.cast(a_dst, ctypes.c_void_p),
                 ctypes.cast(a_dt, ctypes.c_void_p), ctypes.cast(a_r, ctypes.c_void_p), ctypes.cast(a_c, ctypes.c_void_p),
-                ctypes.cast(a_s, ctypes.c_void_p), float(row_scale), DT[dtype], _s(srcs[0]))
+                ctypes.cast(a_s, ctypes.c_void_p), float(row_scale), SPLIT3_B if s3 else DT[dtype], _s(srcs[0]))
     return outs
 
 
@@ -238,11 +242,12 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype, save_stat
     _chk(x, gamma, beta)
     assert x.dtype == torch.float32 and x.dim() == 2
     rows, cols = x.shape
-    y = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
+    s3 = out_dtype == SPLIT3
+    y = torch.empty((rows, 3 * cols if s3 else cols), dtype=torch.bfloat16 if s3 else out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
-    _timed_call("maest_layernorm_fwd", 0.0, _p(x), x.stride(0), _p(gamma), _p(beta), _p(y), cols, DT[out_dtype], _p(mean),
-         _p(rstd), rows, cols, eps, _s(x))
+    _timed_call("maest_layernorm_fwd", 0.0, _p(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), SPLIT3_A if s3 else DT[out_dtype],
+                _p(mean), _p(rstd), rows, cols, eps, _s(x))
     return (y, mean, rstd) if save_stats else y
 
 
@@ -252,11 +257,12 @@ def add_layernorm_fwd(x: torch.Tensor, delta: torch.Tensor, gamma, beta, eps: fl
     assert x.dtype == torch.float32 and x.dim() == 2 and delta.shape == x.shape
     rows, cols = x.shape
     x_new = torch.empty_like(x)
-    y = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
+    s3 = out_dtype == SPLIT3
+    y = torch.empty((rows, 3 * cols if s3 else cols), dtype=torch.bfloat16 if s3 else out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     _timed_call("maest_layernorm_fwd", 0.0, _p(x), _p(delta), DT[delta.dtype], _p(x_new), _p(gamma), _p(beta), _p(y),
-                DT[out_dtype], _p(mean), _p(rstd), rows, cols, eps, _s(x), _entry="maest_add_layernorm_fwd")
+                SPLIT3_A if s3 else DT[out_dtype], _p(mean), _p(rstd), rows, cols, eps, _s(x), _entry="maest_add_layernorm_fwd")
     return (x_new, y, mean, rstd) if save_stats else (x_new, y)
 
 
@@ -282,17 +288,21 @@ def _attn_flops(B, N, q_rows, per_pair):
     return per_pair * B * HEADS * nq * N * HEAD_DIM
 
 
-def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False, q_rows=None, x3: bool = False, q_prescaled=False):
+def attn_fwd(qkv: torch.Tensor, B: int, N: int, scale: float, save_lse=False, q_rows=None, x3: bool = False, q_prescaled=False,
+             out_split3=False):
     """q_rows: only the first q_rows queries of every clip are wanted (rows beyond the 32-row tile that holds them are
     left unwritten in `out` / `lse`).  q_prescaled (bf16 only): the q columns hold scale * log2(e) * q (MAEST_BF16_QS)."""
     _chk(qkv)
     assert not q_prescaled or (qkv.dtype == torch.bfloat16 and not x3)
     assert qkv.shape == (B * N, 3 * EMBED)
-    out = torch.empty((B * N, EMBED), dtype=qkv.dtype, device=qkv.device)
+    # out_split3 (x3 mode): the fp32 result leaves as MAEST_SPLIT3_A rows, bf16 [B * N, 3 * 768] -- the A operand of the proj GEMM
+    assert not out_split3 or (x3 and qkv.dtype == torch.float32)
+    out = (torch.empty((B * N, 3 * EMBED), dtype=torch.bfloat16, device=qkv.device) if out_split3
+           else torch.empty((B * N, EMBED), dtype=qkv.dtype, device=qkv.device))
     lse = torch.empty((B, HEADS, N), dtype=torch.float32, device=qkv.device) if save_lse else None
     _timed_call("maest_attn_fwd", _attn_flops(B, N, q_rows, 4.0), _p(qkv), _p(out), _p(lse), B, N,
-                BF16_QS if q_prescaled else _mm_code(qkv.dtype, x3), scale, N if q_rows is None else q_rows, _s(qkv),
-                _entry="maest_attn_fwd_rows")
+                F32X3_A3 if out_split3 else (BF16_QS if q_prescaled else _mm_code(qkv.dtype, x3)), scale,
+                N if q_rows is None else q_rows, _s(qkv), _entry="maest_attn_fwd_rows")
     return (out, lse) if save_lse else out
 
 

@@ -215,6 +215,19 @@ def case_layernorm(dev, dtype, rows):
     assert torch.equal(xn.cpu(), x + delta.float()), "fused residual add must be the exact fp32 sum"
     y3, mean3, rstd3 = ops.layernorm_fwd(xn, g.to(dev), b.to(dev), 1e-6, dtype, save_stats=True)
     assert torch.equal(y2, y3) and torch.equal(mean2, mean3) and torch.equal(rstd2, rstd3)
+    if dtype == torch.float32:
+        # MAEST_SPLIT3_A output (the A operand of the split-bf16 product run as one bf16 GEMM over 3 K): rows [ hi | hi | lo ] with
+        # hi = bf16(y), lo = bf16(y - hi) of the fp32 result, from both kernels
+        s3 = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev), 1e-6, ops.SPLIT3).cpu()
+        yf = y.cpu()
+        hi = yf.bfloat16()
+        lo = (yf - hi.float()).bfloat16()
+        assert s3.shape == (rows, 2304) and s3.dtype == torch.bfloat16
+        assert torch.equal(s3[:, :768], hi) and torch.equal(s3[:, 768:1536], hi) and torch.equal(s3[:, 1536:], lo), "layernorm split3 rows"
+        xn3, s3b = ops.add_layernorm_fwd(x.to(dev), delta.to(dev), g.to(dev), b.to(dev), 1e-6, ops.SPLIT3)
+        y2f = y2.cpu()
+        hi2 = y2f.bfloat16()
+        assert torch.equal(xn3, xn) and torch.equal(s3b.cpu(), torch.cat([hi2, hi2, (y2f - hi2.float()).bfloat16()], 1)), "add + layernorm split3 rows"
     # backward
     dy = rnd((rows, 768), 10).to(dtype)
     dres = rnd((rows, 768), 11)
@@ -675,6 +688,21 @@ def case_split_precision(dev, M=512, N=256, K=192, B=1, Ntok=75):
                           epi=ops.EPI_RESIDUAL, aux_in=res.to(dev))
     e16 = (c16.double().cpu() - ref).abs().max().item() / scale
     assert e16 > 10 * e, f"plain bf16 operands ({e16:.2e}) should be far coarser than the split ({e:.2e})"
+    # the same three-term product as ONE bf16 GEMM over 3 K (MAEST_SPLIT3_A x MAEST_SPLIT3_B rows; the bf16 kernels, fp32 output): the weight
+    # rows come from maest_cast_weights_multi, the activation rows are built here as the LayerNorm / attention kernels write them
+    b3 = ops.cast_weights_multi([b.to(dev)], ops.SPLIT3)[0][0]
+    bh = b.bfloat16()
+    assert torch.equal(b3.cpu(), torch.cat([bh, (b - bh.float()).bfloat16(), bh], 1)), "split3 weight rows"
+    ah = a.bfloat16()
+    a3 = torch.cat([ah, ah, (a - ah.float()).bfloat16()], 1).contiguous()
+    with ops.options(gemm_min_m=512):
+        c3 = ops.gemm_nt(a3.to(dev), b3, bias.to(dev), out_dtype=torch.float32, epi=ops.EPI_RESIDUAL, aux_in=res.to(dev))
+    e3 = (c3.double().cpu() - ref).abs().max().item() / scale
+    assert e3 < 1e-4, f"split-bf16 GEMM as one bf16 GEMM over 3 K: {e3:.2e} of the output scale"
+    o3 = ops.attn_fwd(qkv.to(dev), B, Ntok, 0.125, x3=True, out_split3=True).cpu()
+    of = out.cpu()
+    oh = of.bfloat16()
+    assert torch.equal(o3, torch.cat([oh, oh, (of - oh.float()).bfloat16()], 1)), "attention forward split3 rows"
     oref, lref = oref.detach(), lref.detach()
     eo = (out.double().cpu() - oref).abs().max().item() / oref.abs().max().item()
     el = (lse.double().cpu() - lref).abs().max().item()
