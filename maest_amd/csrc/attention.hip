@@ -214,22 +214,11 @@ __device__ __forceinline__ void store_dT(const f32x16_t (&acc)[2], T* row_ptr, i
                       acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
 }
 
-// the same accumulator pair as MAEST_SPLIT3_A thirds of a bf16 [.., 3 * 768] row (`row_ptr`: the head's first column in the first third)
-__device__ __forceinline__ void store_dT_split3(const f32x16_t (&acc)[2], bf16_t* row_ptr, int lane, float mul) {
-    const int h = lane >> 5;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint32_t h0, l0, h1, l1;
-            split_bf2(acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul, h0, l0);
-            split_bf2(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul, h1, l1);
-            const chunk8 hi = {h0, h1}, lo = {l0, l1};
-            bf16_t* p = row_ptr + db * 32 + 8 * g + 4 * h;
-            *reinterpret_cast<chunk8*>(p) = hi;
-            *reinterpret_cast<chunk8*>(p + OUT_LD) = hi;
-            *reinterpret_cast<chunk8*>(p + 2 * OUT_LD) = lo;
-        }
+// the same accumulator pair as MAEST_SPLIT3_A thirds of a bf16 [.., 3 * 768] row (`row_ptr`: the head's first column in the first third);
+// call it from converged code (store_32d_words16)
+__device__ __forceinline__ void store_dT_split3(const f32x16_t (&acc)[2], bf16_t* row_ptr, int lane, float mul, bool ok) {
+    store_32d_split3(acc[0], row_ptr, lane, mul, ok, OUT_LD);
+    store_32d_split3(acc[1], row_ptr + 32, lane, mul, ok, OUT_LD);
 }
 
 __device__ __forceinline__ void store_dT_rows16(const f32x16_t (&acc)[2], bf16_t* row_ptr, int lane, float mul, bool ok) {
@@ -365,7 +354,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void attn_fwd_kernel(c
         // profiles/r03_attn_fwd_ablation.txt.  The 16-byte pieces of store_dT_ok need no LDS and no barrier.)
         const bool ok = q < N && (!(MAEST_ABLATE_FWD & 16) || l_tot == 12345.0f);
         if (sizeof(T) == 4 && out_a3) {
-            if (ok) store_dT_split3(o, reinterpret_cast<bf16_t*>(out) + ((int64_t)b * N + q) * (3 * OUT_LD) + head * HD, lane, inv);
+            store_dT_split3(o, reinterpret_cast<bf16_t*>(out) + ((int64_t)b * N + (ok ? q : 0)) * (3 * OUT_LD) + head * HD, lane, inv, ok);
         } else {
             store_dT_ok<T>(o, out + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv, ok);
         }

@@ -85,14 +85,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* dst) {
 // pieces of the row -- half the store instructions of store_dT at the same bytes and addresses (a row-per-lane store tail is bound by
 // store ISSUE, not bandwidth: cdna_hip_programming.md T21).  Call it from converged code (the exchange is a wave operation); `ok`
 // predicates the store per lane: the two half-waves exchange one 8-byte quarter so that lane (key, h) owns d = 32 db + 8 (pair + 2 h) .. + 7
-__device__ __forceinline__ void store_32d_rows16(const f32x16_t& acc, bf16_t* row_ptr, int lane, float mul, bool ok) {
+// (the exchange + store of four packed quarters `pk` of a lane's 32 d: lane (row, h) ends up with d = 8 (pair + 2 h) .. + 7; stored at
+// row_ptr and, REP > 1, again at row_ptr + k * rep_stride)
+template <int REP = 1>
+__device__ __forceinline__ void store_32d_words16(const uint32_t (&pk)[4][2], bf16_t* row_ptr, int lane, bool ok, int rep_stride = 0) {
     const int h = lane >> 5;
-    uint32_t pk[4][2];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        pk[g][0] = pack_bf2(acc[4 * g] * mul, acc[4 * g + 1] * mul);
-        pk[g][1] = pack_bf2(acc[4 * g + 2] * mul, acc[4 * g + 3] * mul);
-    }
 #pragma unroll
     for (int pair = 0; pair < 2; ++pair) {
         // v_permlane32_swap(vdst, src): lanes 32-63 of vdst <-> lanes 0-31 of src.  vdst = group `pair`, src = group `pair + 2`:
@@ -104,8 +101,31 @@ __device__ __forceinline__ void store_32d_rows16(const f32x16_t& acc, bf16_t* ro
         c[1] = y[0];
         c[2] = x[1];
         c[3] = y[1];
-        if (ok) *reinterpret_cast<chunk16*>(row_ptr + 8 * (pair + 2 * h)) = c;
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < REP; ++k) *reinterpret_cast<chunk16*>(row_ptr + k * rep_stride + 8 * (pair + 2 * h)) = c;
+        }
     }
+}
+__device__ __forceinline__ void store_32d_rows16(const f32x16_t& acc, bf16_t* row_ptr, int lane, float mul, bool ok) {
+    uint32_t pk[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        pk[g][0] = pack_bf2(acc[4 * g] * mul, acc[4 * g + 1] * mul);
+        pk[g][1] = pack_bf2(acc[4 * g + 2] * mul, acc[4 * g + 3] * mul);
+    }
+    store_32d_words16(pk, row_ptr, lane, ok);
+}
+// the same 32 d of an fp32 result as MAEST_SPLIT3_A thirds of a bf16 row of 3 * `third` columns: [ hi | hi | lo ], 16-byte pieces
+__device__ __forceinline__ void store_32d_split3(const f32x16_t& acc, bf16_t* row_ptr, int lane, float mul, bool ok, int third) {
+    uint32_t hi[4][2], lo[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        split_bf2(acc[4 * g] * mul, acc[4 * g + 1] * mul, hi[g][0], lo[g][0]);
+        split_bf2(acc[4 * g + 2] * mul, acc[4 * g + 3] * mul, hi[g][1], lo[g][1]);
+    }
+    store_32d_words16<2>(hi, row_ptr, lane, ok, third);
+    store_32d_words16(lo, row_ptr + 2 * third, lane, ok);
 }
 
 }  // namespace maest

@@ -582,7 +582,12 @@ extern "C" int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     // split-bf16 products exist in the big-tile kernel; shapes it does not take run the exact fp32 kernel (a superset)
     const bool x3 = in_dtype == MAEST_F32X3;
     if (x3) in_dtype = MAEST_F32;
-    MAEST_REQUIRE(out_dtype == MAEST_F32 || out_dtype == MAEST_BF16, "maest_gemm_nt: bad out_dtype %d", out_dtype);
+    // MAEST_SPLIT3_A output: gelu(acc + bias) written as [ hi | hi | lo ] bf16 thirds of a [M, 3 N] tensor (ldc >= 3 N) -- the A operand of
+    // the next split product run as one bf16 GEMM over 3 K; lives in the epilogue of the one-wave-per-SIMD kernel only
+    const bool split_out = out_dtype == MAEST_SPLIT3_A;
+    MAEST_REQUIRE(out_dtype == MAEST_F32 || out_dtype == MAEST_BF16 || split_out, "maest_gemm_nt: bad out_dtype %d", out_dtype);
+    MAEST_REQUIRE(!split_out || (in_dtype == MAEST_BF16 && !x3 && epi == MAEST_EPI_GELU && !aux_in && !aux_out && ldc >= 3 * (int64_t)N && split_k == 1),
+                  "maest_gemm_nt: MAEST_SPLIT3_A output needs bf16 operands, the GELU epilogue without side output and ldc >= 3 N");
     const int elt = in_dtype == MAEST_BF16 ? 2 : 4;
     const int ks = GEMM_ROWB / elt;
     MAEST_REQUIRE(K % ks == 0, "maest_gemm_nt: K=%d must be a multiple of %d (pad the operands)", K, ks);
@@ -600,7 +605,7 @@ extern "C" int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux;
     p.M = M; p.N = N; p.K = K;
     p.out_dtype = out_dtype; p.epi = epi;
-    const int osz = out_dtype == MAEST_BF16 ? 2 : 4;
+    const int osz = out_dtype == MAEST_F32 ? 4 : 2;
     const int epc = 16 / osz;
     bool vec = (N % epc == 0) && (N % 4 == 0) && (ldc % epc == 0) && ((uintptr_t)C % 16 == 0);
     if (bias) vec = vec && ((uintptr_t)bias % 16 == 0);
@@ -615,6 +620,8 @@ extern "C" int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
                                       aux_in, aux_out, ld_aux, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
+    MAEST_REQUIRE(!split_out, "maest_gemm_nt: MAEST_SPLIT3_A output is served by the 256-row-tile one-wave-per-SIMD kernel only "
+                  "(M >= MAEST_GEMM_MIN_M, N %% 256 == 0, K %% 64 == 0, aligned operands, maest_kernel_forms() & MAEST_FORM_GEMM_NT_OW)");
     p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
     p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
     const int total = K / ks;

@@ -989,6 +989,8 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
     if (M < (min_m > 512 ? min_m : 512) || N < 128 || (N % 128) != 0) return -1;
     if ((K * (in_dtype == MAEST_BF16 ? 2 : 4)) % G2_ROWB != 0) return -1;
     const int variant = option(MAEST_OPT_GEMM_VARIANT);   // experiment switch (A/B timing, tests)
+    if (out_dtype == MAEST_SPLIT3_A &&                    // (the split-row output exists in gemm_nt256o_kernel's epilogue only)
+        (variant == 1 || variant == 2 || variant == 3 || !gemm_nt256o_available() || (N % 256) != 0 || (K * 2) % W2_ROWB != 0)) return -1;
     Gemm256Params p;
     p.A = (const char*)A; p.B = (const char*)B; p.C = C;
     p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
@@ -1029,7 +1031,7 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
         // go to one launch and the remaining rows to a second one in 128-row tiles (twice the workgroups, about half the
         // time each): 3 + ~0.6 instead of 4 rounds.  MAEST_OPT_GEMM_TAIL: 0 off, 1 (default) automatic, 2 every tile a
         // 128-row tile (tests).
-        const int tail = option(MAEST_OPT_GEMM_TAIL);
+        const int tail = out_dtype == MAEST_SPLIT3_A ? 0 : option(MAEST_OPT_GEMM_TAIL);      // (the 128-row tiles have no split-row epilogue)
         if (tail == 2) return half(p);
         const int ncu = 256;
         const int tiles = p.tiles_m * p.tiles_n;

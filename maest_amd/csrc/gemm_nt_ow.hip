@@ -252,12 +252,15 @@ __device__ __forceinline__ void ow_step(OwCtx& c, const char* base, uint32_t (&v
 // hides a latency for free, so: the tile's 256 bias values sit in LDS (fetched into a register per lane at kernel start: a
 // global load per use was two thirds of this epilogue), a pass's LDS reads are issued as one batch, and the second operand of
 // the RESIDUAL / MUL forms is fetched into registers a pass ahead (AuxRegs), behind the previous pass's drain.
-// GMODE: 0 none, 1 GELU, 3 GELU + GELU' side output; MODE: 0 plain, 1 RESIDUAL (+ aux), 2 MUL (* aux), 3 ROWDOT (plain + row-dot side output)
+// GMODE: 0 none, 1 GELU, 3 GELU + GELU' side output, 4 GELU written as MAEST_SPLIT3_A rows (hi and lo parts staged as the two regions of the
+// pair form; C is bf16 [M, 3 N]: hi -> columns n and N + n, lo -> 2 N + n); MODE: 0 plain, 1 RESIDUAL (+ aux), 2 MUL (* aux), 3 ROWDOT (plain + row-dot side output)
 template <int OSZ, int GMODE, int MODE, typename NEXT>
 __device__ __forceinline__ void ow_epilogue_run(char* smem0, OwCtx& c, const Gemm256Params& p, int m0, int n0, int wm, int wn,
                                                 int lane, int tid, NEXT&& request_next) {
     using E = EpiT<OSZ, 256>;
-    constexpr bool PAIR = GMODE == 3;
+    constexpr bool SPLIT = GMODE == 4;
+    constexpr bool PAIR = GMODE == 3 || SPLIT;
+    static_assert(!SPLIT || (OSZ == 2 && MODE == 0), "split rows: bf16 thirds, no second operand");
     constexpr int REGION = 64 * E::PITCH;                       // one 64-row staging region: 33792 / 66560
     constexpr int BUF = (PAIR ? 2 : 1) * REGION;
     constexpr int BIAS0 = OW_BIAS0;                             // 256 floats behind the (largest) staging buffer, stored by the caller
@@ -292,6 +295,16 @@ __device__ __forceinline__ void ow_epilogue_run(char* smem0, OwCtx& c, const Gem
                 if (PAIR) *reinterpret_cast<float4*>(dst + REGION) = make_float4(d[0], d[1], d[2], d[3]);
             } else {
                 chunk8 o;
+                if (SPLIT) {
+                    uint32_t h0, l0, h1, l1;
+                    split_bf2(v[0], v[1], h0, l0);
+                    split_bf2(v[2], v[3], h1, l1);
+                    o[0] = h0; o[1] = h1;
+                    *reinterpret_cast<chunk8*>(dst) = o;
+                    const chunk8 q = {l0, l1};
+                    *reinterpret_cast<chunk8*>(dst + REGION) = q;
+                    continue;
+                }
                 o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
                 *reinterpret_cast<chunk8*>(dst) = o;
                 if (PAIR) {
@@ -378,7 +391,10 @@ __device__ __forceinline__ void ow_epilogue_run(char* smem0, OwCtx& c, const Gem
         for (int half = 0; half < 2; ++half) {                  // the two 32-row groups of a pass are 128 rows apart
             const char* src = buf + half * 32 * E::PITCH;
             drain_one(src, c_thr, c_row, MODE != 0 ? ax[half] : nullptr, half * 128 + ps * 32);
-            if (PAIR) drain_one(src + REGION, o_thr, x_row, nullptr, half * 128 + ps * 32);
+            if (SPLIT) {
+                drain_one(src, c_thr + (int64_t)p.N * 2, c_row, nullptr, half * 128 + ps * 32);
+                drain_one(src + REGION, c_thr + (int64_t)p.N * 4, c_row, nullptr, half * 128 + ps * 32);
+            } else if (PAIR) drain_one(src + REGION, o_thr, x_row, nullptr, half * 128 + ps * 32);
         }
     };
     // One staging buffer: a pass is  stage -> barrier -> drain (its LDS reads, then the stores) -> barrier.  The barriers are raw
@@ -671,6 +687,7 @@ static int launch256o(Gemm256Params& p, hipStream_t stream) {
 
 int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream) {
     const bool bf = p.out_dtype == MAEST_BF16, gelu = p.epi == MAEST_EPI_GELU;
+    if (gelu && p.aux_out == nullptr && p.out_dtype == MAEST_SPLIT3_A) return launch256o<2, 4, 0>(p, stream);
     if (gelu && p.aux_out != nullptr && bf) return launch256o<2, 3, 0>(p, stream);
     if (p.epi == MAEST_EPI_RESIDUAL && !bf) return launch256o<4, 0, 1>(p, stream);
     if (p.epi == MAEST_EPI_MUL) return bf ? launch256o<2, 0, 2>(p, stream) : launch256o<4, 0, 2>(p, stream);

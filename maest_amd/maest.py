@@ -249,9 +249,15 @@ class _Engine:
         # "bf16x3" forwards that record no graph (the default evaluation mode): the three-term split product of the qkv / proj / fc1
         # linears runs as ONE bf16 GEMM over 3 K on the fast bf16 kernel -- LayerNorm and the attention forward write their fp32
         # results as [ hi | hi | lo ] bf16 rows (MAEST_SPLIT3_A), the weights are kept as [ hi | lo | hi ] rows (MAEST_SPLIT3_B):
-        # the same three products per k as MAEST_F32X3, accumulated in fp32 (fc2, whose operand comes out of a GEMM epilogue,
-        # and the last block's head-token rows stay on the eight-wave split kernel)
+        # the same three products per k as MAEST_F32X3, accumulated in fp32; the fc1 GEMM writes gelu(.) in that row form from its
+        # epilogue (large M: the one-wave-per-SIMD kernel), so fc2 follows suit.  The last block's head-token rows (and small M) stay
+        # on the per-chunk split kernels.  Same-box at configs[1]: profiles/r05_ab_x3_fast.txt
         self.x3_fast = True
+        # (A/B switches of the three engine-level choices above: MAEST_FOLD_QSCALE / MAEST_PERSISTENT_GEMM / MAEST_X3_FAST = 0 turn one off)
+        import os
+        self.fold_qscale = os.environ.get("MAEST_FOLD_QSCALE", "1") != "0"
+        self.persistent_gemm = os.environ.get("MAEST_PERSISTENT_GEMM", "1") != "0"
+        self.x3_fast = os.environ.get("MAEST_X3_FAST", "1") != "0"
         self._weights_dirty = False
         self._side = {}
 
@@ -327,8 +333,8 @@ class _Engine:
         qkv_bias = W.scaled_biases([blk.attn.qkv.bias for blk in m.blocks], EMBED_DIM) if qs else [blk.attn.qkv.bias for blk in m.blocks]
         fast3 = bool(self.x3_fast) and x3m and not save
         if fast3:
-            w3 = W.split3([lin.weight for blk in m.blocks for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1)])
-            w3 = {(i, n): w3[3 * i + j] for i in range(len(m.blocks)) for j, n in enumerate(("qkv", "proj", "fc1"))}
+            w3 = W.split3([lin.weight for blk in m.blocks for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)])
+            w3 = {(i, n): w3[4 * i + j] for i in range(len(m.blocks)) for j, n in enumerate(("qkv", "proj", "fc1", "fc2"))}
 
         t_str, f_str = stripes if stripes is not None else (None, None)
         cols = ops.patch_im2col(x3, tok_ft, dt, perm=perm, lam=lam, t_stripes=t_str, f_stripes=f_str)
@@ -361,7 +367,7 @@ class _Engine:
                 r = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, ops.SPLIT3 if fast3 else dt, save_stats=save)
                 ln1, mean1, rstd1 = r if save else (r, None, None)
             if fast3:
-                qkv = ops.gemm_nt(ln1, w3[(i, "qkv")], qkv_bias[i], out_dtype=torch.float32)
+                qkv = ops.gemm_nt(ln1, w3[(i, "qkv")], qkv_bias[i], out_dtype=torch.float32, split3=True)
             else:
                 qkv = gemm_nt(ln1, W.get(blk.attn.qkv.weight, dt), qkv_bias[i], out_dtype=dt)
             tail = self.head_tail and stop_block < 0 and i == nblocks - 1
@@ -386,7 +392,7 @@ class _Engine:
                 x1, ln2 = r[0], r[1]
                 mean2, rstd2 = (r[2], r[3]) if save else (None, None)
             elif fast_blk:
-                x1 = ops.gemm_nt(ao, w3[(i, "proj")], blk.attn.proj.bias, out_dtype=torch.float32, epi=ops.EPI_RESIDUAL, aux_in=x)
+                x1 = ops.gemm_nt(ao, w3[(i, "proj")], blk.attn.proj.bias, out_dtype=torch.float32, epi=ops.EPI_RESIDUAL, aux_in=x, split3=True)
                 ln2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, ops.SPLIT3)
                 mean2 = rstd2 = None
             else:
@@ -395,8 +401,11 @@ class _Engine:
                 r = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save_stats=save)
                 ln2, mean2, rstd2 = r if save else (r, None, None)
             h = torch.empty((Mb, blk.mlp.fc1.out_features), dtype=dt, device=x.device) if save else None
-            if fast_blk:
-                g = ops.gemm_nt(ln2, w3[(i, "fc1")], blk.mlp.fc1.bias, out_dtype=torch.float32, epi=ops.EPI_GELU)
+            fast_fc2 = fast_blk and ops.gemm_split3_out_supported(Mb, blk.mlp.fc1.out_features, 3 * EMBED_DIM)
+            if fast_fc2:      # gelu(fc1) leaves the GEMM epilogue as [ hi | hi | lo ] rows: fc2 takes the 3 K bf16 GEMM as well
+                g = ops.gemm_nt(ln2, w3[(i, "fc1")], blk.mlp.fc1.bias, out_dtype=ops.SPLIT3, epi=ops.EPI_GELU, split3=True)
+            elif fast_blk:
+                g = ops.gemm_nt(ln2, w3[(i, "fc1")], blk.mlp.fc1.bias, out_dtype=torch.float32, epi=ops.EPI_GELU, split3=True)
             else:
                 g = gemm_nt(ln2, W.get(blk.mlp.fc1.weight, dt), blk.mlp.fc1.bias, out_dtype=dt, epi=ops.EPI_GELU,
                             aux_out=h)
@@ -407,6 +416,8 @@ class _Engine:
             if split_add and i + 1 < nblocks:
                 pending = gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=dt)
                 x = x1
+            elif fast3 and g.dtype == torch.bfloat16:     # (split rows from the fc1 epilogue)
+                x = ops.gemm_nt(g, w3[(i, "fc2")], blk.mlp.fc2.bias, out_dtype=torch.float32, epi=ops.EPI_RESIDUAL, aux_in=x1, split3=True)
             else:             # last block of this pass: nothing follows that could carry the add
                 x = gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=torch.float32,
                                 epi=ops.EPI_RESIDUAL, aux_in=x1)

@@ -101,16 +101,19 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
             out: Optional[torch.Tensor] = None, out_dtype=None, epi: int = EPI_NONE,
             aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
             split_k: int = 1, M: Optional[int] = None, N: Optional[int] = None,
-            K: Optional[int] = None, x3: bool = False) -> torch.Tensor:
+            K: Optional[int] = None, x3: bool = False, split3: bool = False) -> torch.Tensor:
     """out[M,N] = epi(a[M,K] @ b[N,K]^T + bias).  a/b may carry padded leading dims (2-D views of
-    bigger buffers): lda/ldb are taken from stride(0)."""
+    bigger buffers): lda/ldb are taken from stride(0).  split3: a / b are MAEST_SPLIT3_A / _B rows (K = 3 x the logical depth;
+    only the timing bucket's flop count cares: 2 M N K / 3, the algorithmic work of the split product)."""
     assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype
     assert a.stride(1) == 1 and b.stride(1) == 1
     M = a.shape[0] if M is None else M
     N = b.shape[0] if N is None else N
     K = a.shape[1] if K is None else K
+    s3out = out_dtype == SPLIT3       # gelu(acc + bias) as MAEST_SPLIT3_A rows, bf16 [M, 3 N] (the one-wave-per-SIMD kernel's epilogue only)
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
+        out = (torch.empty((M, 3 * N), dtype=torch.bfloat16, device=a.device) if s3out
+               else torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device))
     assert out.stride(1) == 1
     ld_aux = 0
     for x in (aux_in, aux_out):
@@ -123,10 +126,17 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     _chk(bias)
     # timing bucket: the token-major GEMMs of the blocks apart from the few small ones (head, patch-embed remainder, the
     # last block's head-token rows), which run the 128x128 kernel and would blur the dominant kernel's figures
-    _timed_call("maest_gemm_nt" if M >= 4096 else "maest_gemm_nt_small", 2.0 * M * N * K, _p(a), a.stride(0), _p(b),
-                b.stride(0), _mm_code(a.dtype, x3), _p(out), out.stride(0), DT[out.dtype], M, N, K, _p(bias), epi, _p(aux_in),
-                _p(aux_out), ld_aux, split_k, _s(a), _entry="maest_gemm_nt")
+    _timed_call("maest_gemm_nt" if M >= 4096 else "maest_gemm_nt_small", 2.0 * M * N * K / (3 if split3 else 1), _p(a), a.stride(0), _p(b),
+                b.stride(0), _mm_code(a.dtype, x3), _p(out), out.stride(0), SPLIT3_A if s3out else DT[out.dtype], M, N, K, _p(bias), epi,
+                _p(aux_in), _p(aux_out), ld_aux, split_k, _s(a), _entry="maest_gemm_nt")
     return out
+
+
+def gemm_split3_out_supported(M: int, N: int, K: int) -> bool:
+    """Whether maest_gemm_nt serves out_dtype = SPLIT3 for a bf16 [M, K] x [N, K] product with the GELU epilogue (the 256-row-tile
+    one-wave-per-SIMD kernel only: include/maest_hip.h)."""
+    return (M >= max(512, get_option("gemm_min_m")) and N % 256 == 0 and K % 64 == 0 and get_option("gemm_variant") == 0
+            and bool(_lib.kernel_forms() & _lib.FORM_GEMM_NT_OW))
 
 
 def gemm_nt_rowdot(a: torch.Tensor, b: torch.Tensor, other: torch.Tensor, rows_per_item: int, *, out_dtype=None,

@@ -105,6 +105,14 @@ def test_g1_eval_bf16x3_meets_the_parity_gate():
     assert np.abs(act - g["activations"]).max() < 1e-4
     assert (np.argsort(-act)[:10] == g["top10"]).all(), "top-10 label indices must be bit-exact"
     assert (np.argsort(-act) == np.argsort(-g["activations"])).all()
+    # the evaluation forward above ran the split product of qkv / proj / fc1 as ONE bf16 GEMM over 3 K (engine.x3_fast: LayerNorm and the
+    # attention forward write [ hi | hi | lo ] rows, the weights are [ hi | lo | hi ] rows); the per-k-chunk form (three MFMAs per chunk
+    # inside the fp32-operand kernel) computes the same three products in another order: both inside the gate, and close to each other
+    m._engine.x3_fast = False
+    logits_b, feats_b = m(x.clone())
+    m._engine.x3_fast = True
+    assert rel_err(logits_b, g["logits"]) < 1e-3 and rel_err(feats_b, g["features"]) < 1e-3
+    assert rel_err(logits, logits_b) < 2e-5 and rel_err(feats, feats_b) < 2e-5
     # and the training step through the same mode (dgrad GEMMs split, wgrad / attention backward exact fp32)
     g5 = np.load(os.path.join(GOLD, "g5_train_step.npz"))
     net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision="bf16x3").train()
