@@ -1033,6 +1033,192 @@ __global__ __launch_bounds__(NW * 64, FwdWgs<NW>::value) void attn_fwd_dma_kerne
     }
 }
 
+// =================================================================================== forward, split-bf16 on pre-split tiles (fp32 tensors)
+// attn_fwd_kernel<float, X3> splits every fp32 operand chunk into its bf16 hi / lo parts at the point of use: every wave of a workgroup
+// re-splits the same K and V tile data, the K rows / V^T fragments come out of fp32 tiles (V^T: four ds_read_b32 per chunk), and the
+// VALU work of the splits sits between the MFMAs.  Here (round 5; complete passes, q_rows = N) a K / V tile is split ONCE while it is
+// staged -- 16 fp32 values per thread and tensor -> K_hi, K_lo, V_hi, V_lo as unpadded bank-swizzled bf16 tiles, the layout of the bf16
+// kernels above -- so the products read 16-byte bf16 row chunks and transpose-read fragments exactly like attn_fwd_dma_kernel, three MFMAs
+// per chunk step (lo*hi, hi*lo, hi*hi: small terms first, as mma_chunk2<float, X3>), Q is split once per workgroup, and only the
+// probabilities are split per tile.  Same contract as the X3 kernel (1e-4 of the output scale against fp64; not bit-equal: the k order
+// inside a chunk step differs).  out_a3: the result leaves as MAEST_SPLIT3_A rows.
+__device__ __forceinline__ void x3_split4(const chunk16& f, chunk8& hi, chunk8& lo) {     // four fp32 -> their bf16 hi and lo parts
+    uint32_t h0, l0, h1, l1;
+    split_bf2(u2f(f[0]), u2f(f[1]), h0, l0);
+    split_bf2(u2f(f[2]), u2f(f[3]), h1, l1);
+    hi[0] = h0; hi[1] = h1;
+    lo[0] = l0; lo[1] = l1;
+}
+struct X3TileRegs { chunk16 c[4]; };
+// rows [r0, r0 + 64) of a head's fp32 slice: thread t holds the four fp32 of 16-byte column t & 15 of rows (t >> 4) + 16 p
+__device__ __forceinline__ void x3_tile_load(X3TileRegs& t, const float* base, int r0, int nrows, int tid) {
+    const int c = tid & 15, rr = tid >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int r = r0 + rr + 16 * p;
+        r = r < nrows ? r : nrows - 1;            // (rows beyond N repeat the last one: masked scores, P = 0 against a finite V row)
+        t.c[p] = *reinterpret_cast<const chunk16*>(base + (int64_t)r * QKV_LD + c * 4);
+    }
+}
+// ... split and stored as two bf16 tiles (64 rows x 128 B, 16-byte chunk ^= swz128(row))
+__device__ __forceinline__ void x3_tile_store(const X3TileRegs& t, char* hi_tile, char* lo_tile, int tid) {
+    const int c = tid & 15, rr = tid >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = rr + 16 * p;
+        chunk8 hi, lo;
+        x3_split4(t.c[p], hi, lo);
+        const int off = row * 128 + ((((c >> 1) ^ swz128(row)) << 4) | ((c & 1) << 3));
+        *reinterpret_cast<chunk8*>(hi_tile + off) = hi;
+        *reinterpret_cast<chunk8*>(lo_tile + off) = lo;
+    }
+}
+__global__ __launch_bounds__(256, 2) void attn_fwd_x3s_kernel(const float* __restrict__ qkv, void* __restrict__ out, float* __restrict__ lse,
+                                                              int B, int N, float sc_c2, int out_a3) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x { K_hi, K_lo, V_hi, V_lo }: 64 KiB
+    constexpr int TILE128 = 64 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const AttnBlock blk = attn_block((N + 127) / 128, B);
+    const int head = blk.head, b = blk.b;
+    const int q0 = blk.rb * 128 + wave * 32;
+    const int q = q0 + (lane & 31);
+    const bool wave_active = q0 < N;              // wave-uniform
+    const float* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
+    const float* kbase = qbase + NHEADS * HD;
+    const float* vbase = qbase + 2 * NHEADS * HD;
+
+    const int ntiles = (N + 63) / 64;
+    X3TileRegs kr, vr;
+    x3_tile_load(kr, kbase, 0, N, tid);
+    x3_tile_load(vr, vbase, 0, N, tid);
+    // Q: chunk step s of the bf16 layout = d 16 s + 8 h ..+7 of this lane's row, split once
+    chunk16 qh[4], ql[4];
+    {
+        const float* qp = qbase + (int64_t)(q < N ? q : N - 1) * QKV_LD;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const chunk16 f0 = *reinterpret_cast<const chunk16*>(qp + 16 * st + 8 * h);
+            const chunk16 f1 = *reinterpret_cast<const chunk16*>(qp + 16 * st + 8 * h + 4);
+            chunk8 h0, l0, h1, l1;
+            x3_split4(f0, h0, l0);
+            x3_split4(f1, h1, l1);
+            qh[st][0] = h0[0]; qh[st][1] = h0[1]; qh[st][2] = h1[0]; qh[st][3] = h1[1];
+            ql[st][0] = l0[0]; ql[st][1] = l0[1]; ql[st][2] = l1[0]; ql[st][3] = l1[1];
+        }
+    }
+    x3_tile_store(kr, smem, smem + TILE128, tid);
+    x3_tile_store(vr, smem + 2 * TILE128, smem + 3 * TILE128, tid);
+    f32x16_t o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
+    float m_run = NEG_BIG, l_run = 0.0f;
+    const float c2 = sc_c2;
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const char* buf = smem + (kt & 1) * 4 * TILE128;
+        const char *khi = buf, *klo = buf + TILE128, *vhi = buf + 2 * TILE128, *vlo = buf + 3 * TILE128;
+        const bool more = kt + 1 < ntiles;
+        if (more) {
+            x3_tile_load(kr, kbase, (kt + 1) * 64, N, tid);
+            x3_tile_load(vr, vbase, (kt + 1) * 64, N, tid);
+        }
+        if (wave_active) {   // waves whose 32 queries are all padding only help staging the tiles
+            // S^T[key][q] = K Q^T: per 16-d chunk step lo*hi, hi*lo, hi*hi
+            f32x16_t s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+                const int row = kb * 32 + (lane & 31), f = swz128(row);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int off = row * 128 + (((2 * st + h) ^ f) << 4);
+                    const chunk16 ah = *reinterpret_cast<const chunk16*>(khi + off);
+                    const chunk16 al = *reinterpret_cast<const chunk16*>(klo + off);
+                    mma_chunk<bf16_t>(s[kb], al, qh[st]);
+                    mma_chunk<bf16_t>(s[kb], ah, ql[st]);
+                    mma_chunk<bf16_t>(s[kb], ah, qh[st]);
+                }
+            }
+            if (kt == ntiles - 1 && (N & 63) != 0) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt * 64 + kb * 32 + frag_row(r, lane) >= N) s[kb][r] = NEG_BIG;
+            }
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx * c2);
+            const float alpha = fast_exp2<float>(m_run - m_new);
+            m_run = m_new;
+            const f32x2_t c2v = {c2, c2}, nm = {-m_new, -m_new};
+            f32x2_t ps = {0.0f, 0.0f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2_t sv = {s[kb][r], s[kb][r + 1]};
+                    const f32x2_t e = __builtin_elementwise_fma(sv, c2v, nm);
+                    const f32x2_t pv = {fast_exp2<float>(e[0]), fast_exp2<float>(e[1])};
+                    s[kb][r] = pv[0];
+                    s[kb][r + 1] = pv[1];
+                    ps += pv;
+                }
+            l_run = l_run * alpha + (ps[0] + ps[1]);  // per half-wave partial; halves are merged at the end
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            // O^T[d][q] += V^T[d][key] P^T[key][q]: P split per 16-key step (the register -> key map of acc_to_chunk)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    chunk16 bh, bl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        uint32_t hw, lw;
+                        split_bf2(s[kb][8 * st + 2 * j], s[kb][8 * st + 2 * j + 1], hw, lw);
+                        bh[j] = hw;
+                        bl[j] = lw;
+                    }
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const chunk16 ah = frag_from_rows_swz(vhi, kb * 32, st, db, lane);
+                        const chunk16 al = frag_from_rows_swz(vlo, kb * 32, st, db, lane);
+                        mma_chunk<bf16_t>(o[db], al, bh);
+                        mma_chunk<bf16_t>(o[db], ah, bl);
+                        mma_chunk<bf16_t>(o[db], ah, bh);
+                    }
+                }
+        }
+        if (more) {
+            char* nb = smem + ((kt + 1) & 1) * 4 * TILE128;
+            x3_tile_store(kr, nb, nb + TILE128, tid);
+            x3_tile_store(vr, nb + 2 * TILE128, nb + 3 * TILE128, tid);
+        }
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (wave_active) {      // (wave-uniform)
+        const bool ok = q < N;
+        if (out_a3) {
+            store_dT_split3(o, reinterpret_cast<bf16_t*>(out) + ((int64_t)b * N + (ok ? q : 0)) * (3 * OUT_LD) + head * HD, lane, inv, ok);
+        } else if (ok) {
+            store_dT<float>(o, reinterpret_cast<float*>(out) + ((int64_t)b * N + q) * OUT_LD + head * HD, lane, inv);
+        }
+        if (ok && lse != nullptr && h == 0) lse[((int64_t)b * NHEADS + head) * N + q] = m_run * LN2 + logf(l_tot);
+    }
+}
+
 // =================================================================================== two-kernel backward, DMA-fed tiles (bf16)
 // attn_bwd_dkdv_kernel / attn_bwd_dq_kernel (the forms that serve N > 320: the 30 s shapes) with their streamed tiles on the
 // staging path of attn_fwd_dma_kernel: UNPADDED 128-byte-row tiles filled by LDS-DMA (two pieces of each of the two tiles per
@@ -1838,6 +2024,16 @@ static int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N,
         }
     }
     dim3 grid(((N + 127) / 128) * NHEADS * B);
+    if constexpr (X3) {
+        // split-bf16, complete passes: the kernel on pre-split tiles (MAEST_OPT_ATTN_FWD = 1 keeps the per-use split form: A/B, tests)
+        if (q_rows == N && option(MAEST_OPT_ATTN_FWD) != 1) {
+            static DeviceOnce once_x;
+            ensure_dynamic_lds(once_x, &attn_fwd_x3s_kernel, 8 * 64 * 128);
+            hipLaunchKernelGGL(attn_fwd_x3s_kernel, dim3(((N + 127) / 128) * NHEADS * B), dim3(256), 8 * 64 * 128, st, (const float*)qkv, out, lse,
+                               B, N, sc.c2, out_a3 ? 1 : 0);
+            return check_launch("maest_attn_fwd(x3, split tiles)");
+        }
+    }
     const int smem_bytes = 4 * C::TILE;
     static DeviceOnce once;
     ensure_dynamic_lds(once, &attn_fwd_kernel<T, X3>, smem_bytes);

@@ -716,4 +716,9 @@ def case_split_precision(dev, M=512, N=256, K=192, B=1, Ntok=75):
     eo = (out.double().cpu() - oref).abs().max().item() / oref.abs().max().item()
     el = (lse.double().cpu() - lref).abs().max().item()
     assert eo < 1e-4 and el < 1e-4, f"split-bf16 attention forward: out {eo:.2e}, lse {el:.2e}"
+    # (the call above took the kernel that splits the K / V tiles once while staging them; the per-use split form behind attn_fwd = 1)
+    with ops.options(attn_fwd=1):
+        out1, lse1 = ops.attn_fwd(qkv.to(dev), B, Ntok, 0.125, save_lse=True, x3=True)
+    eo1 = (out1.double().cpu() - oref).abs().max().item() / oref.abs().max().item()
+    assert eo1 < 1e-4 and (lse1.double().cpu() - lref).abs().max().item() < 1e-4, f"split-bf16 attention forward (per-use split): {eo1:.2e}"
     return e, eo
