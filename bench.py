@@ -400,10 +400,13 @@ def kernel_report(case, timer, steps, precision, with_traffic, live_traffic=None
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12
         # bf16x3 spends 3 bf16 MFMAs per product: its algorithmic rate is priced against a third of the bf16 peak
         peak = {"bf16": PEAK_BF16_TFLOPS, "bf16x3": round(PEAK_BF16_TFLOPS / 3, 1)}.get(precision, 157.3)
-        out["roofline"] = {"bound": "mfma", "kernel": ("maest_gemm_nt (gemm_nt256o_kernel, bf16, one wave per SIMD -- plus gemm_nt256w_kernel<bf16, 2> for the 128-row tail tiles: every token-major GEMM of the blocks; the head and the last block's head-token rows, M <= 512, run gemm_nt_kernel and are listed as maest_gemm_nt_small)"
+        from maest_amd import _lib as _L
+        ow = bool(_L.kernel_forms() & _L.FORM_GEMM_NT_OW)      # (False: a build whose register audit failed keeps the eight-wave kernel)
+        out["roofline"] = {"bound": "mfma", "kernel": (("maest_gemm_nt (gemm_nt256o_kernel, bf16, one wave per SIMD -- plus gemm_nt256w_kernel<bf16, 2> for the 128-row tail tiles: every token-major GEMM of the blocks; the head and the last block's head-token rows, M <= 512, run gemm_nt_kernel and are listed as maest_gemm_nt_small)"
+                                                       if ow else "maest_gemm_nt (gemm_nt256w_kernel<bf16>, eight waves: this build left the one-wave-per-SIMD kernel out -- maest_kernel_forms())")
                                                       if precision == "bf16" else
-                                                      ("maest_gemm_nt (3 bf16 MFMAs per fp32 product: qkv / proj / fc1 as ONE bf16 GEMM over 3 K on gemm_nt256o_kernel -- "
-                                                       "split operand rows, MAEST_SPLIT3_A x MAEST_SPLIT3_B --, fc2 and the last block on gemm_nt256w_kernel<float, X3>; "
+                                                      ("maest_gemm_nt (3 bf16 MFMAs per fp32 product: all four linears of a block as ONE bf16 GEMM over 3 K on gemm_nt256o_kernel -- "
+                                                       "split operand rows, MAEST_SPLIT3_A x MAEST_SPLIT3_B --, the last block's head rows on gemm_nt256w_kernel<float, X3>; "
                                                        "algorithmic flops 2 M N K)"
                                                        if precision == "bf16x3" else "maest_gemm_nt (fp32 MFMA)")),
                            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}

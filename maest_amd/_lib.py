@@ -12,7 +12,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmaest_hip.so")
+# (MAEST_HIP_LIB: another build of the same library -- e.g. the fallback form of maest_amd/build.py --leave-out, for running the suite against it)
+LIB_PATH = os.environ.get("MAEST_HIP_LIB") or os.path.join(_HERE, "libmaest_hip.so")
 
 F32 = 0
 BF16 = 1

@@ -98,24 +98,30 @@ def audit_or_leave_out(name, obj, compile_failed=False, verbose=True):
     return why
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, leave_out=(), lib=None):
     """Compile every kernel source for gfx950 and link libmaest_hip.so.
+
+    leave_out / lib (tests, `python maest_amd/build.py --leave-out all --lib <path>`): build the fallback form on purpose -- the named
+    owned-register sources ("all": every one) compiled with MAEST_OWNED_DISABLED -- into another file, so that the whole GPU suite can be
+    run against it (env MAEST_HIP_LIB selects the library maest_amd loads).
 
     Three sources own fixed registers by hand (AUDITED); their code objects are audited (pw_audit.py).  If an audit cannot run (no
     device assembly found) or fails -- a hipcc that allocates differently from the validated one -- the source is recompiled with
     -DMAEST_OWNED_DISABLED: that kernel is left out, the library dispatches to the kernel it replaced (the eight-wave GEMMs
     / the four-wave attention forward: same results, ~10 % slower), and maest_kernel_forms() reports it.  MAEST_STRICT_AUDIT=1
     turns the fallback into an error (development)."""
-    if not force and not needs_build():
+    out_lib = lib or LIB
+    leave_out = set(AUDITED) if "all" in leave_out else set(leave_out)
+    if not force and not leave_out and lib is None and not needs_build():
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = {}
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for s in srcs:
-        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
+        o = os.path.join(HERE, "build", os.path.basename(s) + (".off.o" if os.path.basename(s) in leave_out else ".o"))
         objs[os.path.basename(s)] = o
-        cmd = _compile_cmd(s, o)
+        cmd = _compile_cmd(s, o, owned_disabled=os.path.basename(s) in leave_out)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     failed = []
     for cmd, p in procs:
@@ -130,19 +136,23 @@ def build(force=False, verbose=True):
             sys.stderr.write(out.decode())
     left_out = {}
     for name in AUDITED:
-        if name in objs:
+        if name in leave_out:
+            left_out[name] = "left out on request"
+        elif name in objs:
             why = audit_or_leave_out(name, objs[name], compile_failed=name in failed, verbose=verbose)
             if why:
                 left_out[name] = why
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + list(objs.values())
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_lib] + list(objs.values())
     subprocess.check_call(cmd)
     import json
-    with open(os.path.join(HERE, "build", "build_info.json"), "w") as f:
+    with open(os.path.join(HERE, "build", "build_info.json" if lib is None else os.path.basename(out_lib) + ".build_info.json"), "w") as f:
         json.dump({"hipcc": hipcc_version(), "validated_with": VALIDATED_HIPCC, "left_out": left_out}, f, indent=1)
     if verbose:
-        print("built", LIB, "(all owned-register kernels in)" if not left_out else f"(left out: {sorted(left_out)})")
-    return LIB
+        print("built", out_lib, "(all owned-register kernels in)" if not left_out else f"(left out: {sorted(left_out)})")
+    return out_lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    a = sys.argv[1:]
+    lo = a[a.index("--leave-out") + 1].split(",") if "--leave-out" in a else ()
+    build(force="--force" in a, leave_out=lo, lib=a[a.index("--lib") + 1] if "--lib" in a else None)
