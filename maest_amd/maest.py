@@ -285,13 +285,14 @@ class _Engine:
 
     def _gemm_form(self, shared: bool):
         """The bf16 NT GEMM's launch form for a pass (csrc/gemm_nt_ow.hip): persistent -- one workgroup per CU walking its tiles, the next
-        tile's first operand units requested from inside the epilogue: +0.5 % (training step) ... +0.8 % (inference) same-box,
-        profiles/r05_ab_gemm_persistent.txt -- when nothing else wants CUs during the pass; one workgroup per tile when the gradient
-        all-reduce's kernels run beside it (`shared`: a fixed tile list per workgroup cannot be re-dealt around them).  An explicit
-        MAEST_GEMM_WGS / set_option("gemm_wgs") is left alone."""
+        tile's first operand units requested from inside the epilogue -- and WITHOUT the second launch that runs the last partial round in
+        128-row tiles, when nothing else wants CUs during the pass: +0.5 % (training step) ... +0.8 % (inference) for the persistent form,
+        another +1.6 % / +0.4 % for dropping the 69 tail launches of a step (same-box, profiles/r05_ab_gemm_persistent.txt); one workgroup
+        per tile and the tail tiles when the gradient all-reduce's kernels run beside it (`shared`: a fixed tile list per workgroup cannot
+        be re-dealt around them).  Explicit MAEST_GEMM_WGS / MAEST_GEMM_TAIL settings (set_option) are left alone."""
         if not self.persistent_gemm or shared or ops.get_option("gemm_wgs") != 0:
             return contextlib.nullcontext()
-        return ops.options(gemm_wgs=256)
+        return ops.options(gemm_wgs=256, gemm_tail=0) if ops.get_option("gemm_tail") == 1 else ops.options(gemm_wgs=256)
 
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, *args, **kw):
