@@ -215,7 +215,13 @@ __device__ __forceinline__ void epi_scalar(const f32x16_t (&acc)[2][2], const Ge
                     default:
                         break;
                 }
-                if (p.out_dtype == MAEST_BF16) reinterpret_cast<bf16_t*>(p.C)[ci] = f2bf(v);
+                if (p.out_dtype == MAEST_SPLIT3_A) {          // [ hi | hi | lo ] thirds of a bf16 [M, 3 N] row (small M: the big-tile kernel has the fast form)
+                    const bf16_t hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+                    bf16_t* c3 = reinterpret_cast<bf16_t*>(p.C) + ci;
+                    c3[0] = hi;
+                    c3[p.N] = hi;
+                    c3[2 * (int64_t)p.N] = lo;
+                } else if (p.out_dtype == MAEST_BF16) reinterpret_cast<bf16_t*>(p.C)[ci] = f2bf(v);
                 else reinterpret_cast<float*>(p.C)[ci] = v;
             }
     }
@@ -583,7 +589,7 @@ extern "C" int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     const bool x3 = in_dtype == MAEST_F32X3;
     if (x3) in_dtype = MAEST_F32;
     // MAEST_SPLIT3_A output: gelu(acc + bias) written as [ hi | hi | lo ] bf16 thirds of a [M, 3 N] tensor (ldc >= 3 N) -- the A operand of
-    // the next split product run as one bf16 GEMM over 3 K; lives in the epilogue of the one-wave-per-SIMD kernel only
+    // the next split product run as one bf16 GEMM over 3 K: a staged epilogue form of the one-wave-per-SIMD kernel, element-wise elsewhere
     const bool split_out = out_dtype == MAEST_SPLIT3_A;
     MAEST_REQUIRE(out_dtype == MAEST_F32 || out_dtype == MAEST_BF16 || split_out, "maest_gemm_nt: bad out_dtype %d", out_dtype);
     MAEST_REQUIRE(!split_out || (in_dtype == MAEST_BF16 && !x3 && epi == MAEST_EPI_GELU && !aux_in && !aux_out && ldc >= 3 * (int64_t)N && split_k == 1),
@@ -620,8 +626,7 @@ extern "C" int maest_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
                                       aux_in, aux_out, ld_aux, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
-    MAEST_REQUIRE(!split_out, "maest_gemm_nt: MAEST_SPLIT3_A output is served by the 256-row-tile one-wave-per-SIMD kernel only "
-                  "(M >= MAEST_GEMM_MIN_M, N %% 256 == 0, K %% 64 == 0, aligned operands, maest_kernel_forms() & MAEST_FORM_GEMM_NT_OW)");
+    if (split_out) p.vec_ok = 0;       // (shapes the 256-row-tile kernel does not take: the element-wise epilogue writes the three thirds)
     p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
     p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
     const int total = K / ks;

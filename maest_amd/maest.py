@@ -402,10 +402,10 @@ class _Engine:
                 r = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save_stats=save)
                 ln2, mean2, rstd2 = r if save else (r, None, None)
             h = torch.empty((Mb, blk.mlp.fc1.out_features), dtype=dt, device=x.device) if save else None
-            fast_fc2 = fast_blk and ops.gemm_split3_out_supported(Mb, blk.mlp.fc1.out_features, 3 * EMBED_DIM)
+            fast_fc2 = fast_blk and ops.gemm_split3_out_fast(Mb, blk.mlp.fc1.out_features, 3 * EMBED_DIM)
             if fast_fc2:      # gelu(fc1) leaves the GEMM epilogue as [ hi | hi | lo ] rows: fc2 takes the 3 K bf16 GEMM as well
                 g = ops.gemm_nt(ln2, w3[(i, "fc1")], blk.mlp.fc1.bias, out_dtype=ops.SPLIT3, epi=ops.EPI_GELU, split3=True)
-            elif fast_blk:
+            elif fast_blk:    # (small M: an fp32 output and the per-chunk split kernel for fc2)
                 g = ops.gemm_nt(ln2, w3[(i, "fc1")], blk.mlp.fc1.bias, out_dtype=torch.float32, epi=ops.EPI_GELU, split3=True)
             else:
                 g = gemm_nt(ln2, W.get(blk.mlp.fc1.weight, dt), blk.mlp.fc1.bias, out_dtype=dt, epi=ops.EPI_GELU,
@@ -417,7 +417,7 @@ class _Engine:
             if split_add and i + 1 < nblocks:
                 pending = gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=dt)
                 x = x1
-            elif fast3 and g.dtype == torch.bfloat16:     # (split rows from the fc1 epilogue)
+            elif fast_blk and g.dtype == torch.bfloat16:     # (split rows from the fc1 epilogue)
                 x = ops.gemm_nt(g, w3[(i, "fc2")], blk.mlp.fc2.bias, out_dtype=torch.float32, epi=ops.EPI_RESIDUAL, aux_in=x1, split3=True)
             else:             # last block of this pass: nothing follows that could carry the add
                 x = gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=torch.float32,

@@ -110,7 +110,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     M = a.shape[0] if M is None else M
     N = b.shape[0] if N is None else N
     K = a.shape[1] if K is None else K
-    s3out = out_dtype == SPLIT3       # gelu(acc + bias) as MAEST_SPLIT3_A rows, bf16 [M, 3 N] (the one-wave-per-SIMD kernel's epilogue only)
+    s3out = out_dtype == SPLIT3       # gelu(acc + bias) as MAEST_SPLIT3_A rows, bf16 [M, 3 N] (bf16 operands, GELU epilogue without side output)
     if out is None:
         out = (torch.empty((M, 3 * N), dtype=torch.bfloat16, device=a.device) if s3out
                else torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device))
@@ -132,9 +132,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
-def gemm_split3_out_supported(M: int, N: int, K: int) -> bool:
-    """Whether maest_gemm_nt serves out_dtype = SPLIT3 for a bf16 [M, K] x [N, K] product with the GELU epilogue (the 256-row-tile
-    one-wave-per-SIMD kernel only: include/maest_hip.h)."""
+def gemm_split3_out_fast(M: int, N: int, K: int) -> bool:
+    """Whether maest_gemm_nt writes out_dtype = SPLIT3 from the staged epilogue of the 256-row-tile one-wave-per-SIMD kernel (bf16 [M, K] x
+    [N, K], GELU); other shapes / builds take the element-wise epilogue of the 128 x 128 kernel -- correct, but slower than an fp32 output
+    (measured at M = 4480: the engine then keeps fc2 on the per-chunk split kernel)."""
     return (M >= max(512, get_option("gemm_min_m")) and N % 256 == 0 and K % 64 == 0 and get_option("gemm_variant") == 0
             and bool(_lib.kernel_forms() & _lib.FORM_GEMM_NT_OW))
 
