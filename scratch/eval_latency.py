@@ -13,3 +13,14 @@ for B in (1, 2, 4, 8, 16, 32):
             net(x.clone())
             torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
     print(f"B={B:3d}: {statistics.median(ts[5:]):7.2f} ms per call  ({B / statistics.median(ts[5:]) * 1e3:7.1f} clips/s)", flush=True)
+# ... and replayed from a captured HIP graph (model.enable_hip_graph())
+net.enable_hip_graph()
+for B in (1, 8):
+    x = torch.randn(B, 96, 626, device=dev)
+    ts = []
+    with torch.no_grad():
+        for i in range(25):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            net(x.clone())
+            torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+    print(f"B={B:3d} (graph replay): {statistics.median(ts[5:]):7.2f} ms per call", flush=True)
