@@ -258,6 +258,11 @@ class _Engine:
         self.fold_qscale = os.environ.get("MAEST_FOLD_QSCALE", "1") != "0"
         self.persistent_gemm = os.environ.get("MAEST_PERSISTENT_GEMM", "1") != "0"
         self.x3_fast = os.environ.get("MAEST_X3_FAST", "1") != "0"
+        # bf16 mode: residual adds ride in the LayerNorm that follows (True, see forward) or in the proj / fc2 GEMMs' fp32 RESIDUAL epilogue (False)
+        # 1: both adds of a block in the LayerNorms; 0: both in GEMM epilogues; 2: proj's in norm2, fc2's in its epilogue.  Training forwards
+        # (a graph is recorded) and evaluation forwards choose separately
+        self.split_add = int(os.environ.get("MAEST_SPLIT_ADD", "1"))
+        self.split_add_eval = int(os.environ.get("MAEST_SPLIT_ADD_EVAL", os.environ.get("MAEST_SPLIT_ADD", "1")))
         self._weights_dirty = False
         self._side = {}
 
@@ -355,7 +360,11 @@ class _Engine:
         # the LayerNorm that follows (ops.add_layernorm_fwd) -- the fp32 stream is read and rewritten by a streaming
         # kernel instead of a GEMM epilogue (proj: 196 -> ~100 us).  The reference rounds these Linear outputs to 16 bits
         # before the add as well (autocast, ex_maest.py:51).  fp32 modes keep the fused fp32 residual epilogue.
-        split_add = dt != torch.float32
+        # split_add_fc2: the same choice for the add behind the MLP (fc2 GEMM -> next block's norm1), separately: K = 3072 amortises an fp32
+        # RESIDUAL epilogue better than proj's K = 768 does (profiles/r05_ab_split_add.txt)
+        mode = self.split_add if save else self.split_add_eval
+        split_add = dt != torch.float32 and mode in (1, 2)
+        split_add_fc2 = dt != torch.float32 and mode == 1
         pending = None            # delta of the previous block's fc2, to be added by this block's norm1
         for i in range(nblocks):
             blk = m.blocks[i]
@@ -414,7 +423,7 @@ class _Engine:
                 ctx["blocks"].append(dict(x=x_full, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse, x1=x1,
                                           mean2=mean2, rstd2=rstd2, ln2=ln2, h=h, g=g, tail=tail, ao_full=ao_full,
                                           q_rows=q_rows))
-            if split_add and i + 1 < nblocks:
+            if split_add_fc2 and i + 1 < nblocks:
                 pending = gemm_nt(g, W.get(blk.mlp.fc2.weight, dt), blk.mlp.fc2.bias, out_dtype=dt)
                 x = x1
             elif fast_blk and g.dtype == torch.bfloat16:     # (split rows from the fc1 epilogue)
