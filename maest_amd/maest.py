@@ -32,6 +32,7 @@ from __future__ import annotations
 import logging
 import contextlib
 import math
+import os
 import warnings
 import weakref
 from functools import partial
@@ -254,7 +255,6 @@ class _Engine:
         # on the per-chunk split kernels.  Same-box at configs[1]: profiles/r05_ab_x3_fast.txt
         self.x3_fast = True
         # (A/B switches of the three engine-level choices above: MAEST_FOLD_QSCALE / MAEST_PERSISTENT_GEMM / MAEST_X3_FAST = 0 turn one off)
-        import os
         self.fold_qscale = os.environ.get("MAEST_FOLD_QSCALE", "1") != "0"
         self.persistent_gemm = os.environ.get("MAEST_PERSISTENT_GEMM", "1") != "0"
         self.x3_fast = os.environ.get("MAEST_X3_FAST", "1") != "0"
