@@ -186,7 +186,8 @@ def case_transpose(dev, dtype, rows, cols):
     close(d, w.to(dtype), 0, 0, "cast")
     close(dt_, w.to(dtype).t(), 0, 0, "cast transposed")
     # many parameters, one launch (ragged shapes, NULL outputs)
-    ws = [rnd((rows, cols), 60), rnd((cols, 33), 61), rnd((65, 64), 62)]
+    # (sides that are multiples of 4 take the kernel's quad path -- 16-byte loads, 8-byte stores --, the others the element-wise one)
+    ws = [rnd((rows, cols), 60), rnd((cols, 33), 61), rnd((65, 64), 62), rnd((132, 72), 63), rnd((64, 256), 64)]
     for want, want_t in ((True, True), (False, True), (True, False)):
         outs = ops.cast_weights_multi([t.to(dev) for t in ws], dtype, want=want, want_t=want_t)
         for t, (o, ot) in zip(ws, outs):
@@ -195,6 +196,15 @@ def case_transpose(dev, dtype, rows, cols):
                 close(o, t.to(dtype), 0, 0, "cast multi")
             if ot is not None:
                 close(ot, t.to(dtype).t(), 0, 0, "cast multi transposed")
+
+
+    # leading rows of the PLAIN copy scaled before the rounding (the q rows of a qkv projection, MAEST_BF16_QS); the transposed copy is not
+    for t in (rnd((132, 72), 65), rnd((70, 33), 66)):
+        (o, ot), = ops.cast_weights_multi([t.to(dev)], dtype, want=True, want_t=True, scaled_rows=[40], row_scale=0.1803)
+        want_o = t.clone()
+        want_o[:40] *= 0.1803
+        close(o, want_o.to(dtype), 0, 0, "cast multi, scaled leading rows")
+        close(ot, t.to(dtype).t(), 0, 0, "cast multi, transposed copy unscaled")
 
 
 # --------------------------------------------------------------------------------------- LayerNorm

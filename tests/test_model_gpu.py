@@ -967,3 +967,38 @@ def test_last_block_on_head_tokens_equals_the_complete_evaluation(precision, pat
         assert e < tol, f"{n}: restricted last block changes the gradient by {e:.2e} (relative L2)"
     print(f"head-token last block vs complete ({precision}, patchout {patchout}): loss {l1:.7f} vs {l0:.7f}, worst gradient "
           f"deviation {worst[1]:.2e} at {worst[0]}")
+
+
+def test_training_steps_in_flight_are_bounded():
+    """A bare training loop (nothing reads the loss) must not let the host run arbitrarily far ahead of the device: blocks recorded on
+    the side stream cannot be recycled while their step is still queued, so the reserved pool grows with the distance (90 -> 247 GB over
+    60 steps at batch 256 before the bound).  The recording forward of step k waits for the backward of step k - run_ahead; results are
+    unchanged (same loss curve with the bound off)."""
+    finals = {}
+    for ahead in (3, 0):
+        torch.manual_seed(13)
+        np.random.seed(13)
+        net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision="bf16").train()
+        net._engine.run_ahead = ahead
+        mod = Module(net=net, mixup_alpha=0.3, lr=1e-4)
+        opt = mod.get_optimizer()
+        x = randn((32, 1, 96, 626), 510).to(DEV)
+        y = (torch.rand((32, 400), generator=torch.Generator().manual_seed(3)) < 0.02).float().to(DEV)
+        torch.cuda.synchronize()
+        losses, evs = [], []
+        for it in range(12):
+            loss = mod.training_step((x, None, y), it)
+            if ahead and it >= ahead:
+                # the recording forward has waited for the backward of step it - ahead
+                assert evs[it - ahead].query(), f"step {it}: the backward of step {it - ahead} is still running"
+            loss.backward()
+            losses.append(loss.detach())
+            q = net._engine._inflight
+            assert len(q) <= ahead
+            evs.append(q[-1] if ahead else None)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        finals[ahead] = torch.stack(losses).double().cpu().numpy()
+    # (split-K atomics make two runs differ in the last bits: the loss curves agree, not the bit patterns)
+    assert np.max(np.abs(finals[3] - finals[0]) / finals[0]) < 2e-3, (finals[3], finals[0])
