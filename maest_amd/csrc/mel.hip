@@ -10,8 +10,10 @@
 // samples in flight), without block barriers: the 512 real samples are packed as 256 complex points and transformed as
 // 256 = 16 x 16 -- two 16-point DFTs in registers around one exchange through LDS --, unpacked to the 257-bin one-sided
 // spectrum, and projected onto the mel bands with the filterbank stored in band-sparse form (each triangular band touches
-// <= fb_stride consecutive bins).  All arithmetic is fp32.  (Rounds 1-2: one frame per wave, four radix-4 stages through
-// LDS, ~800 instructions per frame and wave = 0.11 of the HBM roofline; DESIGN.md section 4 has the before / after.)
+// <= fb_stride consecutive bins): the four frames' power spectra lie bin-major in LDS, a lane forms one band and one half
+// band of all four frames from 16-byte reads with its weights in registers.  All arithmetic is fp32.  (Rounds 1-2: one
+// frame per wave, four radix-4 stages through LDS, ~800 instructions per frame and wave = 0.11 of the HBM roofline; round 3:
+// 16 x 16 with a per-frame projection, ~440 = 0.17; round 5: ~280 = 0.23 -- DESIGN.md section 4.)
 #include "common.h"
 
 namespace maest {
@@ -22,7 +24,6 @@ constexpr int MEL_NBINS = 257;
 constexpr int MEL_BANDS = 96;
 constexpr int MEL_FRAMES_PER_BLOCK = 64;
 constexpr int MEL_OUT_LD = MEL_FRAMES_PER_BLOCK + 1;
-constexpr int MEL_WREG0 = 8, MEL_WREG1 = 16;   // filter weights kept in registers for bands 0..63 / 64..95
 
 struct cplx {
     float re, im;
@@ -37,6 +38,20 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
 __device__ __forceinline__ cplx mul_neg_i(cplx a) { return {a.im, -a.re}; }   // a * (-i)
 __device__ __forceinline__ int rev4_256(int k) {  // reverse the four base-4 digits of k
     return ((k & 3) << 6) | (((k >> 2) & 3) << 4) | (((k >> 4) & 3) << 2) | ((k >> 6) & 3);
+}
+
+__device__ __forceinline__ float mel_log2(float x) { return __builtin_amdgcn_logf(x); }       // v_log_f32
+
+// The value lane (16 - l) mod 16 of the same 16-lane row holds (l = lane mod 16): two DPP moves on the device -- rotate the row by one,
+// mirror it: no LDS crossbar, no wait --, a lane permutation under the host emulator.
+__device__ __forceinline__ float mel_row_partner(float x, int src_lane) {
+#if defined(__AMDGCN__)
+    int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x12f /* row_ror:15 */, 0xf, 0xf, false);
+    t = __builtin_amdgcn_update_dpp(0, t, 0x140 /* row_mirror */, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, t);
+#else
+    return __shfl(x, src_lane, 64);
+#endif
 }
 
 // LDS hand-off between the lanes of ONE wave: a wave's DS instructions execute in order and all 64 lanes issue them
@@ -103,14 +118,15 @@ __device__ __forceinline__ void mel_fetch(f32x16_t& xe, f32x16_t& xo, const floa
 
 constexpr int MEL_XROW = 18 * 8;                  // exchange tile: 16 rows (k1) of 16 complex, pitch 18 (b128 reads conflict-free)
 constexpr int MEL_XFRAME = 16 * MEL_XROW;         // 2304 B per frame
-constexpr int MEL_PWFRAME = 260;                  // floats: 257 bins + the zero padding clamped reads may touch
+constexpr int MEL_PWBINS = 272;                   // 257 bins + 15 zero bins (a 16-weight register window starting at the last band's first bin)
 
 // Round 3 form: a wave transforms FOUR frames at a time, 16 lanes per frame and 16 complex points per lane, as 256 = 16 x 16:
 // a 16-point DFT over n1 in registers (twiddles of the 16-point transform are literals), the W256^(n2 k1) factors (per-lane
 // registers), ONE exchange through LDS (lane n2 writes column n2, lane k1 reads row k1), a 16-point DFT over n2 in registers.
 // The real-FFT unpack needs Z[256 - k], which lives in lane 16 - l of the same group: one lane permutation per value.  The
-// mel projection keeps the former mapping (64 lanes x 1.5 bands per frame, filter weights in registers).  Per frame and
-// wave ~240 instructions against ~800 for four radix-4 stages through LDS with one frame per wave.
+// mel projection runs over the four frames at once (a band and a half band per lane, filter weights in registers).  Per frame and
+// wave ~280 instructions (counted in the code object: 1120 per four frames) against ~800 for four radix-4 stages through LDS with
+// one frame per wave.
 __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict__ wave_in, int S, int T,
                                                      const float* __restrict__ window,
                                                      const float* __restrict__ twiddle,   // [512][2] exp(-2 pi i k / 512)
@@ -122,8 +138,9 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l = lane & 15, grp = lane >> 4;
     float* wtab = reinterpret_cast<float*>(smem);                     // [512] Hann window
-    float* tw256 = wtab + 512;                                        // [256][2] exp(-2 pi i m / 256)
-    float* fbw = tw256 + 512;                                         // [96][16] leading filter weights of every band
+    float* tw256 = wtab + 512;                                        // [16 k1][16 l][2] exp(-2 pi i l k1 / 256): lane l reads at l + 16 k1 (immediate offsets)
+    float* tw512 = tw256 + 512;                                       // [256][2] exp(-2 pi i k / 512): lane l reads at l + 16 k2
+    float* fbw = tw512 + 512;                                         // [96][16] leading filter weights of every band
     float* otile = fbw + MEL_BANDS * 16;                              // [96][65]
     char* xch = reinterpret_cast<char*>(otile + MEL_BANDS * MEL_OUT_LD) + wv * 4 * MEL_XFRAME;          // per wave: 4 frames
     // the power spectra of the four frames reuse the exchange tiles (2304 >= 1040 bytes per frame; a wave-level sync apart)
@@ -135,24 +152,29 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
     f32x16_t xe, xo;       // even / odd samples = real / imaginary parts of the packed points (vector values: an array would live in scratch)
     if (interior) mel_fetch<true>(xe, xo, wsrc, t0 + wv * 16 + grp, T, S, l);
     else mel_fetch<false>(xe, xo, wsrc, t0 + wv * 16 + grp, T, S, l);
-    const cplx w512l = {twiddle[2 * l], twiddle[2 * l + 1]};          // W512^l
-    // this lane's two bands (lane, lane + 64)
-    int mb_start[2], mb_len[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = lane + 64 * j;
-        mb_start[j] = m < MEL_BANDS ? fb_start[m] : 0;
-        mb_len[j] = m < MEL_BANDS ? fb_len[m] : 0;
-    }
+    // this lane's band (lane) and half band (64 + lane / 2, weight slots 8 (lane & 1) .. + 7): first bin, length
+    const int mbnd = 64 + (lane >> 1);
+    const int sa = fb_start[lane], na = fb_len[lane] < fb_stride ? fb_len[lane] : fb_stride;
+    const int sb = fb_start[mbnd] + 8 * (lane & 1), nb = fb_len[mbnd] < fb_stride ? fb_len[mbnd] : fb_stride;
+    // log10(1 + s x) -> z-norm as one multiply-add behind the hardware's log2 (v_log_f32, 1 ulp; the argument is >= 1)
+    const float out_mul = 0.30102999566398120f / norm_2std, out_add = -norm_mean / norm_2std;
+    const float ls4 = 0.25f * log_scale;         // the power spectra below are kept times four
     for (int i = threadIdx.x; i < 512; i += 256) {
         wtab[i] = window[i];
-        tw256[i] = twiddle[4 * (i >> 1) + (i & 1)];
+        tw256[i] = twiddle[4 * ((((i >> 1) & 15) * (i >> 5)) & 255) + (i & 1)];
+        tw512[i] = twiddle[i];
     }
     for (int i = threadIdx.x; i < MEL_BANDS * 16; i += 256) {
         const int m = i >> 4, k = i & 15;
         fbw[i] = k < fb_len[m] && k < fb_stride ? fb_w[m * fb_stride + k] : 0.0f;
     }
     __syncthreads();
+    float wa[8], wb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        wa[i] = fbw[lane * 16 + i];
+        wb[i] = fbw[mbnd * 16 + 8 * (lane & 1) + i];
+    }
 
     for (int quad = 0; quad < 4; ++quad) {
         const int tl0 = wv * 16 + quad * 4;      // first of this wave's four frames within the block
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
         for (int k1 = 0; k1 < 16; ++k1) {
             cplx y = v[rev16(k1)];
             if (k1 > 0) {                         // W256^(l k1)
-                const float2 t2 = *reinterpret_cast<const float2*>(tw256 + 2 * ((l * k1) & 255));
+                const float2 t2 = *reinterpret_cast<const float2*>(tw256 + 2 * (16 * k1 + l));
                 y = cmul(y, cplx{t2.x, t2.y});
             }
             *reinterpret_cast<float2*>(xf + k1 * MEL_XROW + l * 8) = make_float2(y.re, y.im);
@@ -189,62 +211,62 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
         dft16(v);                                 // Z[l + 16 k2] at v[rev16(k2)]
         // ---- unpack the real FFT: X[k] = E[k] + W512^k O[k], power spectrum for k = l + 16 k2 (and bin 256 from lane 0)
         wave_lds_sync();                          // every lane has read its row: the tiles become the power spectra
-        float* pw = reinterpret_cast<float*>(xf);
-        if (l < 3) pw[MEL_NBINS + l] = 0.0f;      // the padding the clamped reads below may touch
+        // power spectra of the wave's four frames, bin-major: pw[bin][frame] -- the projection below takes one bin of all four frames
+        // with a single 16-byte read; the 64 lanes of a store cover 64 consecutive floats.  Bins 257 .. 271 are zero: a band's
+        // register-resident weights run past its last bin (weight 0) and must meet finite values there.
+        float* pw = reinterpret_cast<float*>(xch);
+        if (lane < 4 * (MEL_PWBINS - MEL_NBINS)) pw[4 * MEL_NBINS + lane] = 0.0f;
         const int src = (lane & 48) | ((16 - l) & 15);
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
-            constexpr float W32C[16] = {1.0000000000f, 0.9807852804f, 0.9238795325f, 0.8314696123f, 0.7071067812f, 0.5555702330f, 0.3826834324f, 0.1950903220f, 0.0000000000f, -0.1950903220f, -0.3826834324f, -0.5555702330f, -0.7071067812f, -0.8314696123f, -0.9238795325f, -0.9807852804f};
-            constexpr float W32S[16] = {-0.0000000000f, -0.1950903220f, -0.3826834324f, -0.5555702330f, -0.7071067812f, -0.8314696123f, -0.9238795325f, -0.9807852804f, -1.0000000000f, -0.9807852804f, -0.9238795325f, -0.8314696123f, -0.7071067812f, -0.5555702330f, -0.3826834324f, -0.1950903220f};      // exp(-2 pi i k2 / 32)
             const cplx zk = v[rev16(k2)];
             // Z[256 - k] sits in lane 16 - l, slot 15 - k2 (lane 0 pairs with itself: slot (16 - k2) mod 16)
             const cplx za = v[rev16((16 - k2) & 15)], zb = v[rev16(15 - k2)];      // (selected per component: a select between
             const cplx snd = {l == 0 ? za.re : zb.re, l == 0 ? za.im : zb.im};      //  two array elements would pin v[] to scratch)
-            cplx zc = {__shfl(snd.re, src, 64), __shfl(snd.im, src, 64)};
+            cplx zc = {mel_row_partner(snd.re, src), mel_row_partner(snd.im, src)};
             zc.im = -zc.im;
-            const cplx e = {0.5f * (zk.re + zc.re), 0.5f * (zk.im + zc.im)};
-            const cplx d = {0.5f * (zk.re - zc.re), 0.5f * (zk.im - zc.im)};
-            const cplx o = mul_neg_i(d);                                 // (Z[k] - conj Z[N-k]) / (2i)
-            const cplx w32 = {W32C[k2], W32S[k2]};
-            const cplx w = cmul(w512l, w32);                              // exp(-2 pi i (l + 16 k2) / 512)
-            const cplx xk = cadd(e, cmul(o, w));
-            pw[l + 16 * k2] = __builtin_fmaf(xk.re, xk.re, xk.im * xk.im);
+            // 2 X[k] = (Z[k] + conj Z[N-k]) - i (Z[k] - conj Z[N-k]) W512^k: the halves are left out (the power comes out times four,
+            // exactly; the factor rides in the log's scale below)
+            const cplx e = {zk.re + zc.re, zk.im + zc.im};
+            const cplx d = {zk.re - zc.re, zk.im - zc.im};
+            const cplx o = mul_neg_i(d);
+            const float2 w2 = *reinterpret_cast<const float2*>(tw512 + 2 * (l + 16 * k2));      // exp(-2 pi i (l + 16 k2) / 512)
+            const cplx xk = cadd(e, cmul(o, cplx{w2.x, w2.y}));
+            pw[4 * (l + 16 * k2) + grp] = __builtin_fmaf(xk.re, xk.re, xk.im * xk.im);
             if (k2 == 0 && l == 0) {
-                const float x256 = zk.re - zk.im;                         // X[256] = Re Z[0] - Im Z[0]
-                pw[256] = x256 * x256;
+                const float x256 = 2.0f * (zk.re - zk.im);                // 2 X[256] = 2 (Re Z[0] - Im Z[0])
+                pw[4 * 256 + grp] = x256 * x256;
             }
         }
         wave_lds_sync();
-        // ---- mel projection + logC + z-norm into the block's output tile, one frame at a time over all 64 lanes; the
-        // first MEL_WREG0 / MEL_WREG1 filter weights of this lane's two bands in registers for the four frames (the slaney
-        // bank's bands are 1..6 and 5..15 bins long), zero beyond the band; longer bands finish in a global-read loop
-        float mw0[MEL_WREG0], mw1[MEL_WREG1];
+        // ---- mel projection + logC + z-norm into the block's output tile, the wave's four frames at once: lane L forms band L from
+        // 8 bins (the slaney bank's bands 0 .. 63 are 1 .. 6 bins long) and one HALF of band 64 + L / 2 (8 of its 16 weight slots: bands
+        // 64 .. 95 are 6 .. 15 bins long), a bin of the four frames per 16-byte LDS read, the weights in registers (wa / wb, loaded in
+        // front of the frame loop); the halves meet through one lane exchange.  Longer bands finish in a global-read loop (never with
+        // this bank).  (Rounds 3 - 5a: one frame at a time, 1.5 bands per lane, a 4-byte LDS read per product and its wait in front of
+        // every multiply-add: 724 of the ~1800 instructions a wave spent on four frames.)
+        {
+            const f32x4_t* pwq = reinterpret_cast<const f32x4_t*>(xch);
+            f32x4_t acc_a = {0.0f, 0.0f, 0.0f, 0.0f}, acc_b = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < MEL_WREG0; ++i) mw0[i] = fbw[lane * 16 + i];
-#pragma unroll
-        for (int i = 0; i < MEL_WREG1; ++i) mw1[i] = lane + 64 < MEL_BANDS ? fbw[(lane + 64) * 16 + i] : 0.0f;
+            for (int i = 0; i < 8; ++i) {
+                const f32x4_t pa = pwq[sa + i], pb = pwq[sb + i];
+                acc_a = __builtin_elementwise_fma(pa, f32x4_t{wa[i], wa[i], wa[i], wa[i]}, acc_a);
+                acc_b = __builtin_elementwise_fma(pb, f32x4_t{wb[i], wb[i], wb[i], wb[i]}, acc_b);
+            }
 #pragma unroll 1
-        for (int f = 0; f < 4; ++f) {
-            const float* pwf = reinterpret_cast<const float*>(xch + f * MEL_XFRAME);
-            const int tl = tl0 + f;
+            for (int i = 8; i < na; ++i) acc_a += pwq[sa + i] * fb_w[lane * fb_stride + i];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int m = lane + 64 * j;
-                if (m < MEL_BANDS) {
-                    const int s0 = mb_start[j], n = mb_len[j];
-                    float acc = 0.0f;
-                    if (j == 0) {
+            for (int f = 0; f < 4; ++f) acc_b[f] += __shfl_xor(acc_b[f], 1, 64);
+            if ((lane & 1) == 0)
+#pragma unroll 1
+                for (int i = 16; i < nb; ++i) acc_b += pwq[sb + i] * fb_w[mbnd * fb_stride + i];
+            const int tl = wv * 16 + quad * 4;
 #pragma unroll
-                        for (int i = 0; i < MEL_WREG0; ++i) acc = __builtin_fmaf(pwf[s0 + i < MEL_NBINS ? s0 + i : MEL_NBINS], mw0[i], acc);
-                        for (int i = MEL_WREG0; i < n; ++i) acc += pwf[s0 + i] * fb_w[m * fb_stride + i];
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < MEL_WREG1; ++i) acc = __builtin_fmaf(pwf[s0 + i < MEL_NBINS ? s0 + i : MEL_NBINS], mw1[i], acc);
-                        for (int i = MEL_WREG1; i < n; ++i) acc += pwf[s0 + i] * fb_w[m * fb_stride + i];
-                    }
-                    const float lm = log10f(1.0f + acc * log_scale);
-                    otile[m * MEL_OUT_LD + tl] = (lm - norm_mean) / norm_2std;
-                }
+            for (int f = 0; f < 4; ++f) {
+                otile[lane * MEL_OUT_LD + tl + f] = __builtin_fmaf(mel_log2(__builtin_fmaf(acc_a[f], ls4, 1.0f)), out_mul, out_add);
+                if ((lane & 1) == 0)
+                    otile[mbnd * MEL_OUT_LD + tl + f] = __builtin_fmaf(mel_log2(__builtin_fmaf(acc_b[f], ls4, 1.0f)), out_mul, out_add);
             }
         }
         wave_lds_sync();       // pw / the exchange tile are rewritten by the next four frames
@@ -268,7 +290,7 @@ extern "C" int maest_logmel(const float* wave, int B, int S, const float* window
     MAEST_REQUIRE(B > 0 && S > MEL_NFFT / 2, "maest_logmel: bad shape B=%d S=%d (reflect padding needs S > 256)", B, S);
     MAEST_REQUIRE(fb_stride > 0, "maest_logmel: bad fb_stride");
     const int T = 1 + S / MEL_HOP;
-    const int smem_bytes = (512 + 512 + MEL_BANDS * 16 + MEL_BANDS * MEL_OUT_LD) * 4 + 4 * 4 * MEL_XFRAME;
+    const int smem_bytes = (512 + 512 + 512 + MEL_BANDS * 16 + MEL_BANDS * MEL_OUT_LD) * 4 + 4 * 4 * MEL_XFRAME;
     dim3 grid((T + MEL_FRAMES_PER_BLOCK - 1) / MEL_FRAMES_PER_BLOCK, B);
     static DeviceOnce once;                       // 70 KiB of dynamic LDS: above the 64 KiB a kernel gets without the attribute
     ensure_dynamic_lds(once, &logmel_kernel, smem_bytes);

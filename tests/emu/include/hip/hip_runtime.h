@@ -255,6 +255,7 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 static inline uint64_t __builtin_amdgcn_s_memtime() { static thread_local uint64_t t = 0; return t += 1000; }
 static inline void __builtin_amdgcn_s_sleep(int) {}
