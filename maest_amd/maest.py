@@ -218,13 +218,17 @@ def _split_k(n_out: int, k_out: int, tokens: int) -> int:
     return max(1, min(1024 // tiles, math.ceil(tokens / 64)))
 
 
-def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int, out=None, bias_out=None, x3=False) -> torch.Tensor:
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int, out=None, bias_out=None, x3=False, wgs: int = 0) -> torch.Tensor:
     """dW[n_out, k_out] = dy[M, n_out]^T @ x[M, k_out] (fp32) and, fused in the same kernel,
     db[n_out] = dy.sum(0): token-major operands are consumed in place (csrc/gemm.hip: gemm_tn_kernel).
-    `out` / `bias_out` (pre-zeroed fp32) receive the results if given."""
+    `out` / `bias_out` (pre-zeroed fp32) receive the results if given.  wgs > 0: about that many workgroups (K splits = wgs // tiles)
+    instead of the kernel's own plan, which fills the 256 CUs in one round."""
     dw = (torch.zeros((n_out, k_out), dtype=torch.float32, device=dy.device) if out is None
           else out.view(n_out, k_out))
-    ops.gemm_tn(dy, x, dw, colsum=bias_out, split_k=0, M=n_out, N=k_out, x3=x3)   # 0 = kernel-chosen split
+    split = 0                                                                     # 0 = kernel-chosen split
+    if wgs > 0 and n_out % 256 == 0 and k_out % 256 == 0:
+        split = max(1, wgs // ((n_out // 256) * (k_out // 256)))
+    ops.gemm_tn(dy, x, dw, colsum=bias_out, split_k=split, M=n_out, N=k_out, x3=x3)
     return dw
 
 
@@ -274,6 +278,13 @@ class _Engine:
         # (~190 ms of queued work at batch 256) ride out a full Python garbage collection on the host (120 - 170 ms measured) without
         # a bubble on the device; the pool stays at ~1/4 of the unbounded loop's.
         self.run_ahead = int(os.environ.get("MAEST_RUN_AHEAD", "4"))
+        # Weight gradients on the side stream run BESIDE the dgrad chain: launched half as wide as the kernel's own one-round plan (108 - 126
+        # workgroups: 3 K splits for fc1 / fc2, 4 for qkv, 14 for proj) they leave the other CUs to the main stream's kernel, add a third
+        # of the split-K atomics and run three times the K range per workgroup: -1.0 ... -2.1 % on the training step on three boxes; 64 / 96
+        # make the wgrad the critical path (+40 % / +4 %), 160 / 192 equal the full width (profiles/r05e_ab_wgrad_width.txt).
+        # MAEST_WGRAD_WGS = 0: the kernel's plan.  Without the side stream (serialized passes) the plan is the kernel's.
+        self.wgrad_wgs = int(os.environ.get("MAEST_WGRAD_WGS", "128"))
+        self.bwd_gemm_wgs = int(os.environ.get("MAEST_BWD_GEMM_WGS", "256"))     # persistent workgroups of the dgrad GEMMs (A/B)
         self._inflight = collections.deque()
 
     def throttle(self):
@@ -312,7 +323,7 @@ class _Engine:
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
 
-    def _gemm_form(self, shared: bool):
+    def _gemm_form(self, shared: bool, wgs: int = 256):
         """The bf16 NT GEMM's launch form for a pass (csrc/gemm_nt_ow.hip): persistent -- one workgroup per CU walking its tiles, the next
         tile's first operand units requested from inside the epilogue -- and WITHOUT the second launch that runs the last partial round in
         128-row tiles, when nothing else wants CUs during the pass: +0.5 % (training step) ... +0.8 % (inference) for the persistent form,
@@ -321,7 +332,7 @@ class _Engine:
         be re-dealt around them).  Explicit MAEST_GEMM_WGS / MAEST_GEMM_TAIL settings (set_option) are left alone."""
         if not self.persistent_gemm or shared or ops.get_option("gemm_wgs") != 0:
             return contextlib.nullcontext()
-        return ops.options(gemm_wgs=256, gemm_tail=0) if ops.get_option("gemm_tail") == 1 else ops.options(gemm_wgs=256)
+        return ops.options(gemm_wgs=wgs, gemm_tail=0) if ops.get_option("gemm_tail") == 1 else ops.options(gemm_wgs=wgs)
 
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, *args, **kw):
@@ -484,7 +495,7 @@ class _Engine:
 
     # ---- backward ---------------------------------------------------------------------------
     def backward(self, ctx, grads_out, sink=None):
-        with self._gemm_form(shared=sink is not None):
+        with self._gemm_form(shared=sink is not None, wgs=self.bwd_gemm_wgs):
             G = self._backward(ctx, grads_out, sink)
         self._step_done(ctx["x_final"].device)
         return G
@@ -553,7 +564,7 @@ class _Engine:
                 ev.record(main)            # dy, x and the zeroed destinations are ready at this point
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    _wgrad(dy, x, n_out, k_out, gw, gb, x3m)
+                    _wgrad(dy, x, n_out, k_out, gw, gb, x3m, wgs=self.wgrad_wgs)
                 for t in (dy, x, gw, gb):
                     t.record_stream(side)  # keep the caching allocator from recycling them under the side stream
             else:
