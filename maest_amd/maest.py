@@ -281,7 +281,7 @@ class _Engine:
         # Weight gradients on the side stream run BESIDE the dgrad chain: launched half as wide as the kernel's own one-round plan (108 - 126
         # workgroups: 3 K splits for fc1 / fc2, 4 for qkv, 14 for proj) they leave the other CUs to the main stream's kernel, add a third
         # of the split-K atomics and run three times the K range per workgroup: -1.0 ... -2.1 % on the training step on three boxes; 64 / 96
-        # make the wgrad the critical path (+40 % / +4 %), 160 / 192 equal the full width (profiles/r05e_ab_wgrad_width.txt).
+        # make the wgrad the critical path (+40 % / +4 %), 160 / 192 equal the full width (profiles/r05e_step_level_ab.txt).
         # MAEST_WGRAD_WGS = 0: the kernel's plan.  Without the side stream (serialized passes) the plan is the kernel's.
         self.wgrad_wgs = int(os.environ.get("MAEST_WGRAD_WGS", "128"))
         self.bwd_gemm_wgs = int(os.environ.get("MAEST_BWD_GEMM_WGS", "256"))     # persistent workgroups of the dgrad GEMMs (A/B)
