@@ -1002,3 +1002,26 @@ def test_training_steps_in_flight_are_bounded():
         finals[ahead] = torch.stack(losses).double().cpu().numpy()
     # (split-K atomics make two runs differ in the last bits: the loss curves agree, not the bit patterns)
     assert np.max(np.abs(finals[3] - finals[0]) / finals[0]) < 2e-3, (finals[3], finals[0])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_wgrad_launch_width_does_not_change_the_gradients(precision):
+    """The engine launches the weight-gradient GEMMs of the side stream half as wide as the kernel's own plan (`_Engine.wgrad_wgs` = 128:
+    fewer K splits, longer K ranges per workgroup).  A different split only re-orders fp32 sums: gradients of the G5 step with the
+    kernel's plan (0), the shipped width and a very narrow one agree to summation noise."""
+    g = np.load(os.path.join(GOLD, "g5_train_step.npz"))
+    net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision=precision).train()
+    assert net._engine.wgrad_wgs == 128 and net._engine.overlap_wgrad
+    mod = Module(net=net, mixup_alpha=0.3)
+    x, y, mix, po = _g5_batch(g)
+    grads = {}
+    for w in (0, 128, 40):
+        net._engine.wgrad_wgs = w
+        net.zero_grad(set_to_none=True)
+        mod.training_step((x, None, y), 0, _mixup=mix, _patchout=po).backward()
+        torch.cuda.synchronize()
+        grads[w] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    for w in (128, 40):
+        for n, r in grads[0].items():
+            d = (grads[w][n] - r).abs().max().item()
+            assert d <= 2e-5 * max(r.abs().max().item(), 1e-6) + 1e-7, (w, n, d)
