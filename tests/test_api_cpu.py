@@ -332,3 +332,30 @@ def test_failed_register_audit_leaves_the_kernel_out_instead_of_failing_the_buil
     # and the product build has all three
     if os.path.exists(_lib.LIB_PATH):
         assert _lib.kernel_forms() == _lib.FORM_GEMM_NT_OW | _lib.FORM_GEMM_TN_OW | _lib.FORM_ATTN_FWD_PW
+
+
+def test_run_ahead_bound_is_host_logic():
+    """_Engine.throttle(): the recording forward of step k waits for the backward of step k - run_ahead (events stand in for the device)."""
+    from maest_amd.maest import _Engine
+
+    class Ev:
+        def __init__(self, log, i):
+            self.log, self.i = log, i
+
+        def synchronize(self):
+            self.log.append(self.i)
+
+    net = get_maest("discogs-maest-10s-pw-129e", pretrained=False)
+    eng = net._engine
+    assert isinstance(eng, _Engine) and eng.run_ahead == 4 and eng.wgrad_wgs == 128
+    waited = []
+    for step in range(7):
+        eng.throttle()                                   # forward of `step`
+        eng._inflight.append(Ev(waited, step))           # its backward's event
+    assert waited == [0, 1, 2] and len(eng._inflight) == 4
+    eng.run_ahead = 0                                    # unbounded: never waits
+    eng.throttle()
+    assert waited == [0, 1, 2]
+    eng.run_ahead = 1
+    eng.throttle()
+    assert waited == [0, 1, 2, 3, 4, 5, 6] and len(eng._inflight) == 0
