@@ -25,17 +25,57 @@ constexpr int MEL_BANDS = 96;
 constexpr int MEL_FRAMES_PER_BLOCK = 64;
 constexpr int MEL_OUT_LD = MEL_FRAMES_PER_BLOCK + 1;
 
-struct cplx {
-    float re, im;
-};
-__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
-// (fused multiply-adds written out: the library is built with -ffp-contract=off for the bit-exact fp32 paths elsewhere; the mel
-//  front end is checked against its oracle to 2e-4 after the log, and its kernel is bound by instruction issue)
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
-    return {__builtin_fmaf(a.re, b.re, -(a.im * b.im)), __builtin_fmaf(a.re, b.im, a.im * b.re)};
+// A complex value is a (re, im) pair in ONE 64-bit register pair, and the arithmetic is the packed fp32 instruction set with its operand
+// modifiers written out: `op_sel` / `op_sel_hi` choose which half of a source feeds the low / high result, `neg_lo` / `neg_hi` negate it --
+// a multiplication by -i or a conjugation costs no instruction, a complex product two.  (Left to hipcc, the same source spent a third of
+// the two 16-point DFT stages on moves that re-paired registers: 175 of 518 instructions per four frames.)  The host emulator takes the
+// plain C++ twins, which perform the same IEEE operations.
+typedef f32x2_t cplx;
+#define MEL_RE(z) ((z)[0])
+#define MEL_IM(z) ((z)[1])
+#if defined(__AMDGCN__)
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { cplx d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { cplx d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// a + (-i) t = (a.re + t.im, a.im - t.re)  /  a - (-i) t = (a.re - t.im, a.im + t.re)
+__device__ __forceinline__ cplx cadd_rot(cplx a, cplx t) { cplx d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(t)); return d; }
+__device__ __forceinline__ cplx csub_rot(cplx a, cplx t) { cplx d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(t)); return d; }
+// a b = (a.re b.re - a.im b.im, a.re b.im + a.im b.re): the a.im products first (cmul_a), then a.re (b.re, b.im) added by one packed fma (cmul_b)
+// (the two halves of a product as separate statements: asm statements keep their source order, so independent products are written
+//  interleaved -- first halves, then second halves -- and no instruction waits on its predecessor)
+template <bool NEG>
+__device__ __forceinline__ cplx cmul_a(cplx a, cplx b) {         // NEG: the product with -b
+    cplx t;
+    if (NEG) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (a.im b.im, -a.im b.re)
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    return t;
 }
-__device__ __forceinline__ cplx mul_neg_i(cplx a) { return {a.im, -a.re}; }   // a * (-i)
+template <bool NEG>
+__device__ __forceinline__ cplx cmul_b(cplx a, cplx b, cplx t) {
+    cplx d;
+    if (NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
+    return d;
+}
+// a + conj(p) / a - conj(p)
+__device__ __forceinline__ cplx cadd_conj(cplx a, cplx p) { cplx d; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(p)); return d; }
+__device__ __forceinline__ cplx csub_conj(cplx a, cplx p) { cplx d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(p)); return d; }
+__device__ __forceinline__ cplx csqr2(cplx a) { cplx q; asm("v_pk_mul_f32 %0, %1, %1" : "=v"(q) : "v"(a)); return q; }      // (re^2, im^2)
+#else
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return cplx{a[0] + b[0], a[1] + b[1]}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return cplx{a[0] - b[0], a[1] - b[1]}; }
+__device__ __forceinline__ cplx cadd_rot(cplx a, cplx t) { return cplx{a[0] + t[1], a[1] - t[0]}; }
+__device__ __forceinline__ cplx csub_rot(cplx a, cplx t) { return cplx{a[0] - t[1], a[1] + t[0]}; }
+template <bool NEG>
+__device__ __forceinline__ cplx cmul_a(cplx a, cplx b) { return NEG ? cplx{a[1] * b[1], -(a[1] * b[0])} : cplx{-(a[1] * b[1]), a[1] * b[0]}; }
+template <bool NEG>
+__device__ __forceinline__ cplx cmul_b(cplx a, cplx b, cplx t) {
+    return NEG ? cplx{__builtin_fmaf(a[0], -b[0], t[0]), __builtin_fmaf(a[0], -b[1], t[1])}
+               : cplx{__builtin_fmaf(a[0], b[0], t[0]), __builtin_fmaf(a[0], b[1], t[1])};
+}
+__device__ __forceinline__ cplx cadd_conj(cplx a, cplx p) { return cplx{a[0] + p[0], a[1] - p[1]}; }
+__device__ __forceinline__ cplx csub_conj(cplx a, cplx p) { return cplx{a[0] - p[0], a[1] + p[1]}; }
+__device__ __forceinline__ cplx csqr2(cplx a) { return cplx{a[0] * a[0], a[1] * a[1]}; }
+#endif
 __device__ __forceinline__ int rev4_256(int k) {  // reverse the four base-4 digits of k
     return ((k & 3) << 6) | (((k >> 2) & 3) << 4) | (((k >> 4) & 3) << 2) | ((k >> 6) & 3);
 }
@@ -46,8 +86,8 @@ __device__ __forceinline__ float mel_log2(float x) { return __builtin_amdgcn_log
 // mirror it: no LDS crossbar, no wait --, a lane permutation under the host emulator.
 __device__ __forceinline__ float mel_row_partner(float x, int src_lane) {
 #if defined(__AMDGCN__)
-    int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x12f /* row_ror:15 */, 0xf, 0xf, false);
-    t = __builtin_amdgcn_update_dpp(0, t, 0x140 /* row_mirror */, 0xf, 0xf, false);
+    int t = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x12f /* row_ror:15 */, 0xf, 0xf, false);
+    t = __builtin_amdgcn_mov_dpp(t, 0x140 /* row_mirror */, 0xf, 0xf, false);
     return __builtin_bit_cast(float, t);
 #else
     return __shfl(x, src_lane, 64);
@@ -62,27 +102,45 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// ---- 16-point DFT in registers: v[n] (n = 4 a + b) -> Y[k] (k = c + 4 d) left at v[4 c + d] (base-4 digit reversal)
-__device__ __forceinline__ void dft4(cplx& a0, cplx& a1, cplx& a2, cplx& a3) {
-    const cplx b0 = cadd(a0, a2), b1 = csub(a0, a2), b2 = cadd(a1, a3), b3 = mul_neg_i(csub(a1, a3));
-    a0 = cadd(b0, b2); a1 = cadd(b1, b3); a2 = csub(b0, b2); a3 = csub(b1, b3);
+// ---- 16-point DFT in registers: v[n] (n = 4 a + b) -> Y[k] (k = c + 4 d) left at v[4 c + d] (base-4 digit reversal).  Four radix-4
+// butterflies at a time, written operation by operation across the four (no statement depends on the one in front of it).
+// ROT2 (second stage, third butterfly): its third input still owes a factor -i (the twiddle exp(-2 pi i 4 / 16)), taken by operand modifiers.
+template <int S0, int ST, bool STAGE2>      // butterfly j works on v[S0 j + ST i], i = 0 .. 3
+__device__ __forceinline__ void dft4x4(cplx (&v)[16]) {
+    cplx b0[4], b1[4], b2[4], t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool rot = STAGE2 && j == 2;
+        b0[j] = rot ? cadd_rot(v[S0 * j], v[S0 * j + 2 * ST]) : cadd(v[S0 * j], v[S0 * j + 2 * ST]);
+        b2[j] = cadd(v[S0 * j + ST], v[S0 * j + 3 * ST]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool rot = STAGE2 && j == 2;
+        b1[j] = rot ? csub_rot(v[S0 * j], v[S0 * j + 2 * ST]) : csub(v[S0 * j], v[S0 * j + 2 * ST]);
+        t[j] = csub(v[S0 * j + ST], v[S0 * j + 3 * ST]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[S0 * j] = cadd(b0[j], b2[j]);
+        v[S0 * j + 2 * ST] = csub(b0[j], b2[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[S0 * j + ST] = cadd_rot(b1[j], t[j]);
+        v[S0 * j + 3 * ST] = csub_rot(b1[j], t[j]);
+    }
 }
 __device__ __forceinline__ void dft16(cplx (&v)[16]) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);     // over a: v[4 c + b] = T[c][b]
-    // T[c][b] *= exp(-2 pi i b c / 16)
-    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], cplx{C1, -S1});
-    v[4 * 2 + 1] = cmul(v[4 * 2 + 1], cplx{R, -R});
-    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], cplx{S1, -C1});
-    v[4 * 1 + 2] = cmul(v[4 * 1 + 2], cplx{R, -R});
-    v[4 * 2 + 2] = mul_neg_i(v[4 * 2 + 2]);
-    v[4 * 3 + 2] = cmul(v[4 * 3 + 2], cplx{-R, -R});
-    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], cplx{S1, -C1});
-    v[4 * 2 + 3] = cmul(v[4 * 2 + 3], cplx{-R, -R});
-    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], cplx{-C1, S1});
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);   // over b: v[4 c + d] = Y[c + 4 d]
+    const cplx w1 = {C1, -S1}, w2 = {R, -R}, w3 = {S1, -C1}, w6 = {R, R};
+    dft4x4<1, 4, false>(v);                            // over a: v[4 c + b] = T[c][b]
+    // T[c][b] *= exp(-2 pi i b c / 16)   (b c = 4: -i, left to the second stage's butterfly; -(R, R) and -(C1, -S1) by operand modifiers)
+    const cplx t5 = cmul_a<false>(v[5], w1), t9 = cmul_a<false>(v[9], w2), t13 = cmul_a<false>(v[13], w3), t6 = cmul_a<false>(v[6], w2);
+    const cplx t14 = cmul_a<true>(v[14], w6), t7 = cmul_a<false>(v[7], w3), t11 = cmul_a<true>(v[11], w6), t15 = cmul_a<true>(v[15], w1);
+    v[5] = cmul_b<false>(v[5], w1, t5); v[9] = cmul_b<false>(v[9], w2, t9); v[13] = cmul_b<false>(v[13], w3, t13); v[6] = cmul_b<false>(v[6], w2, t6);
+    v[14] = cmul_b<true>(v[14], w6, t14); v[7] = cmul_b<false>(v[7], w3, t7); v[11] = cmul_b<true>(v[11], w6, t11); v[15] = cmul_b<true>(v[15], w1, t15);
+    dft4x4<4, 1, true>(v);                             // over b: v[4 c + d] = Y[c + 4 d]
 }
 __device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k >> 2); }    // where dft16 leaves Y[k]
 
@@ -91,13 +149,14 @@ __device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k 
 // loads, 16 lanes = one 128-byte line; otherwise clamped (frames >= T take the last frame's data and are not stored) and
 // reflect-padded sample by sample
 template <bool INTERIOR>
-__device__ __forceinline__ void mel_fetch(f32x16_t& xe, f32x16_t& xo, const float* __restrict__ wsrc, int t, int T, int S, int l) {
+__device__ __forceinline__ void mel_fetch(f32x16_t& xa, f32x16_t& xb, const float* __restrict__ wsrc, int t, int T, int S, int l) {
     if (INTERIOR) {
         const float* p0 = wsrc + t * MEL_HOP - MEL_NFFT / 2 + 2 * l;
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const float2 v = *reinterpret_cast<const float2*>(p0 + 32 * n1);
-            xe[n1] = v.x; xo[n1] = v.y;
+            if (n1 < 8) { xa[2 * n1] = v.x; xa[2 * n1 + 1] = v.y; }
+            else { xb[2 * n1 - 16] = v.x; xb[2 * n1 - 15] = v.y; }
         }
         return;
     }
@@ -110,8 +169,8 @@ __device__ __forceinline__ void mel_fetch(f32x16_t& xe, f32x16_t& xo, const floa
             int i = tc * MEL_HOP + p + e - MEL_NFFT / 2;
             if (i < 0) i = -i;
             if (i >= S) i = 2 * (S - 1) - i;
-            if (e == 0) xe[n1] = wsrc[i];
-            else xo[n1] = wsrc[i];
+            if (n1 < 8) xa[2 * n1 + e] = wsrc[i];
+            else xb[2 * n1 - 16 + e] = wsrc[i];
         }
     }
 }
@@ -149,9 +208,9 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
     const float* wsrc = wave_in + (int64_t)b * S;
     const bool interior = t0 > 0 && (t0 + MEL_FRAMES_PER_BLOCK) * MEL_HOP + MEL_NFFT / 2 <= S && t0 + MEL_FRAMES_PER_BLOCK <= T &&
                           (reinterpret_cast<uintptr_t>(wsrc) & 7) == 0;      // block-uniform
-    f32x16_t xe, xo;       // even / odd samples = real / imaginary parts of the packed points (vector values: an array would live in scratch)
-    if (interior) mel_fetch<true>(xe, xo, wsrc, t0 + wv * 16 + grp, T, S, l);
-    else mel_fetch<false>(xe, xo, wsrc, t0 + wv * 16 + grp, T, S, l);
+    f32x16_t xa, xb;       // the lane's 16 packed points as loaded: (even, odd) sample = (re, im), points 0 .. 7 | 8 .. 15 (vector values: an array would live in scratch)
+    if (interior) mel_fetch<true>(xa, xb, wsrc, t0 + wv * 16 + grp, T, S, l);
+    else mel_fetch<false>(xa, xb, wsrc, t0 + wv * 16 + grp, T, S, l);
     // this lane's band (lane) and half band (64 + lane / 2, weight slots 8 (lane & 1) .. + 7): first bin, length
     const int mbnd = 64 + (lane >> 1);
     const int sa = fb_start[lane], na = fb_len[lane] < fb_stride ? fb_len[lane] : fb_stride;
@@ -182,32 +241,41 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
         cplx v[16];
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
-            const float2 w2 = *reinterpret_cast<const float2*>(wtab + 2 * (16 * n1 + l));
-            v[n1] = {xe[n1] * w2.x, xo[n1] * w2.y};
+            const cplx w2 = *reinterpret_cast<const cplx*>(wtab + 2 * (16 * n1 + l));
+            const cplx xin = n1 < 8 ? cplx{xa[2 * (n1 & 7)], xa[2 * (n1 & 7) + 1]} : cplx{xb[2 * (n1 & 7)], xb[2 * (n1 & 7) + 1]};
+            v[n1] = xin * w2;
         }
         if (quad + 1 < 4) {                       // the next four frames' samples fly while these are transformed
-            if (interior) mel_fetch<true>(xe, xo, wsrc, t0 + tl0 + 4 + grp, T, S, l);
-            else mel_fetch<false>(xe, xo, wsrc, t0 + tl0 + 4 + grp, T, S, l);
+            if (interior) mel_fetch<true>(xa, xb, wsrc, t0 + tl0 + 4 + grp, T, S, l);
+            else mel_fetch<false>(xa, xb, wsrc, t0 + tl0 + 4 + grp, T, S, l);
         }
-        // ---- 256 = 16 x 16: DFT over n1, twiddle, exchange, DFT over n2
+        // ---- 256 = 16 x 16: DFT over n1, twiddle, exchange, DFT over n2.  (The lane's table values are read a stage ahead of their use:
+        // the packed-math statements are asm, which hipcc does not move loads across)
+        cplx tw[15];
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) tw[k1 - 1] = *reinterpret_cast<const cplx*>(tw256 + 2 * (16 * k1 + l));      // W256^(l k1)
         dft16(v);
         char* xf = xch + grp * MEL_XFRAME;
+        *reinterpret_cast<cplx*>(xf + l * 8) = v[rev16(0)];
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) {
-            cplx y = v[rev16(k1)];
-            if (k1 > 0) {                         // W256^(l k1)
-                const float2 t2 = *reinterpret_cast<const float2*>(tw256 + 2 * (16 * k1 + l));
-                y = cmul(y, cplx{t2.x, t2.y});
-            }
-            *reinterpret_cast<float2*>(xf + k1 * MEL_XROW + l * 8) = make_float2(y.re, y.im);
+        for (int g = 0; g < 3; ++g) {             // k1 = 1 + 5 g .. 5 + 5 g: five products at a time, first halves then second halves
+            cplx ta[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) ta[i] = cmul_a<false>(v[rev16(1 + 5 * g + i)], tw[5 * g + i]);
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                *reinterpret_cast<cplx*>(xf + (1 + 5 * g + i) * MEL_XROW + l * 8) = cmul_b<false>(v[rev16(1 + 5 * g + i)], tw[5 * g + i], ta[i]);
         }
         wave_lds_sync();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float4 q = *reinterpret_cast<const float4*>(xf + l * MEL_XROW + j * 16);
-            v[2 * j] = {q.x, q.y};
-            v[2 * j + 1] = {q.z, q.w};
+            const f32x4_t q = *reinterpret_cast<const f32x4_t*>(xf + l * MEL_XROW + j * 16);
+            v[2 * j] = cplx{q[0], q[1]};
+            v[2 * j + 1] = cplx{q[2], q[3]};
         }
+        cplx wu[16];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) wu[k2] = *reinterpret_cast<const cplx*>(tw512 + 2 * (l + 16 * k2));          // exp(-2 pi i (l + 16 k2) / 512)
         dft16(v);                                 // Z[l + 16 k2] at v[rev16(k2)]
         // ---- unpack the real FFT: X[k] = E[k] + W512^k O[k], power spectrum for k = l + 16 k2 (and bin 256 from lane 0)
         wave_lds_sync();                          // every lane has read its row: the tiles become the power spectra
@@ -217,26 +285,36 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
         float* pw = reinterpret_cast<float*>(xch);
         if (lane < 4 * (MEL_PWBINS - MEL_NBINS)) pw[4 * MEL_NBINS + lane] = 0.0f;
         const int src = (lane & 48) | ((16 - l) & 15);
+        // Z[256 - k] sits in lane 16 - l, slot 15 - k2 (lane 0 pairs with itself: slot (16 - k2) mod 16): the partner values of all 16 slots
+        // first (selects and lane moves: plain statements, scheduled by hipcc), then the packed arithmetic four slots at a time
+        cplx pz[16];
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
-            const cplx zk = v[rev16(k2)];
-            // Z[256 - k] sits in lane 16 - l, slot 15 - k2 (lane 0 pairs with itself: slot (16 - k2) mod 16)
             const cplx za = v[rev16((16 - k2) & 15)], zb = v[rev16(15 - k2)];      // (selected per component: a select between
-            const cplx snd = {l == 0 ? za.re : zb.re, l == 0 ? za.im : zb.im};      //  two array elements would pin v[] to scratch)
-            cplx zc = {mel_row_partner(snd.re, src), mel_row_partner(snd.im, src)};
-            zc.im = -zc.im;
-            // 2 X[k] = (Z[k] + conj Z[N-k]) - i (Z[k] - conj Z[N-k]) W512^k: the halves are left out (the power comes out times four,
-            // exactly; the factor rides in the log's scale below)
-            const cplx e = {zk.re + zc.re, zk.im + zc.im};
-            const cplx d = {zk.re - zc.re, zk.im - zc.im};
-            const cplx o = mul_neg_i(d);
-            const float2 w2 = *reinterpret_cast<const float2*>(tw512 + 2 * (l + 16 * k2));      // exp(-2 pi i (l + 16 k2) / 512)
-            const cplx xk = cadd(e, cmul(o, cplx{w2.x, w2.y}));
-            pw[4 * (l + 16 * k2) + grp] = __builtin_fmaf(xk.re, xk.re, xk.im * xk.im);
-            if (k2 == 0 && l == 0) {
-                const float x256 = 2.0f * (zk.re - zk.im);                // 2 X[256] = 2 (Re Z[0] - Im Z[0])
-                pw[4 * 256 + grp] = x256 * x256;
-            }
+            const float sr = l == 0 ? MEL_RE(za) : MEL_RE(zb), si = l == 0 ? MEL_IM(za) : MEL_IM(zb);      //  two array elements would pin v[] to scratch)
+            pz[k2] = cplx{mel_row_partner(sr, src), mel_row_partner(si, src)};
+        }
+        if (l == 0) {
+            const float x256 = 2.0f * (MEL_RE(v[rev16(0)]) - MEL_IM(v[rev16(0)]));      // 2 X[256] = 2 (Re Z[0] - Im Z[0])
+            pw[4 * 256 + grp] = x256 * x256;
+        }
+        // 2 X[k] = (Z[k] + conj Z[N-k]) - i (Z[k] - conj Z[N-k]) W512^k: the halves are left out (the power comes out times four,
+        // exactly; the factor rides in the log's scale below)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            cplx e[4], d[4], t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { e[i] = cadd_conj(v[rev16(4 * g + i)], pz[4 * g + i]); d[i] = csub_conj(v[rev16(4 * g + i)], pz[4 * g + i]); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = cmul_a<false>(d[i], wu[4 * g + i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = cmul_b<false>(d[i], wu[4 * g + i], t[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = cadd_rot(e[i], d[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = csqr2(e[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pw[4 * (l + 16 * (4 * g + i)) + grp] = MEL_RE(t[i]) + MEL_IM(t[i]);
         }
         wave_lds_sync();
         // ---- mel projection + logC + z-norm into the block's output tile, the wave's four frames at once: lane L forms band L from
