@@ -14,6 +14,8 @@
 // band of all four frames from 16-byte reads with its weights in registers.  All arithmetic is fp32.  (Rounds 1-2: one
 // frame per wave, four radix-4 stages through LDS, ~800 instructions per frame and wave = 0.11 of the HBM roofline; round 3:
 // 16 x 16 with a per-frame projection, ~440 = 0.17; round 5: ~280 = 0.23 -- DESIGN.md section 4.)
+#include <type_traits>
+
 #include "common.h"
 
 namespace maest {
@@ -149,14 +151,12 @@ __device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k 
 // loads, 16 lanes = one 128-byte line; otherwise clamped (frames >= T take the last frame's data and are not stored) and
 // reflect-padded sample by sample
 template <bool INTERIOR>
-__device__ __forceinline__ void mel_fetch(f32x16_t& xa, f32x16_t& xb, const float* __restrict__ wsrc, int t, int T, int S, int l) {
+__device__ __forceinline__ void mel_fetch(cplx (&xin)[16], const float* __restrict__ wsrc, int t, int T, int S, int l) {
     if (INTERIOR) {
         const float* p0 = wsrc + t * MEL_HOP - MEL_NFFT / 2 + 2 * l;
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
-            const float2 v = *reinterpret_cast<const float2*>(p0 + 32 * n1);
-            if (n1 < 8) { xa[2 * n1] = v.x; xa[2 * n1 + 1] = v.y; }
-            else { xb[2 * n1 - 16] = v.x; xb[2 * n1 - 15] = v.y; }
+            xin[n1] = *reinterpret_cast<const cplx*>(p0 + 32 * n1);
         }
         return;
     }
@@ -169,8 +169,7 @@ __device__ __forceinline__ void mel_fetch(f32x16_t& xa, f32x16_t& xb, const floa
             int i = tc * MEL_HOP + p + e - MEL_NFFT / 2;
             if (i < 0) i = -i;
             if (i >= S) i = 2 * (S - 1) - i;
-            if (n1 < 8) xa[2 * n1 + e] = wsrc[i];
-            else xb[2 * n1 - 16 + e] = wsrc[i];
+            xin[n1][e] = wsrc[i];
         }
     }
 }
@@ -199,8 +198,7 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
     float* wtab = reinterpret_cast<float*>(smem);                     // [512] Hann window
     float* tw256 = wtab + 512;                                        // [16 k1][16 l][2] exp(-2 pi i l k1 / 256): lane l reads at l + 16 k1 (immediate offsets)
     float* tw512 = tw256 + 512;                                       // [256][2] exp(-2 pi i k / 512): lane l reads at l + 16 k2
-    float* fbw = tw512 + 512;                                         // [96][16] leading filter weights of every band
-    float* otile = fbw + MEL_BANDS * 16;                              // [96][65]
+    float* otile = tw512 + 512;                                       // [96][65]
     char* xch = reinterpret_cast<char*>(otile + MEL_BANDS * MEL_OUT_LD) + wv * 4 * MEL_XFRAME;          // per wave: 4 frames
     // the power spectra of the four frames reuse the exchange tiles (2304 >= 1040 bytes per frame; a wave-level sync apart)
     const int b = blockIdx.y;
@@ -208,9 +206,7 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
     const float* wsrc = wave_in + (int64_t)b * S;
     const bool interior = t0 > 0 && (t0 + MEL_FRAMES_PER_BLOCK) * MEL_HOP + MEL_NFFT / 2 <= S && t0 + MEL_FRAMES_PER_BLOCK <= T &&
                           (reinterpret_cast<uintptr_t>(wsrc) & 7) == 0;      // block-uniform
-    f32x16_t xa, xb;       // the lane's 16 packed points as loaded: (even, odd) sample = (re, im), points 0 .. 7 | 8 .. 15 (vector values: an array would live in scratch)
-    if (interior) mel_fetch<true>(xa, xb, wsrc, t0 + wv * 16 + grp, T, S, l);
-    else mel_fetch<false>(xa, xb, wsrc, t0 + wv * 16 + grp, T, S, l);
+    cplx xin[16];          // the lane's 16 packed points as loaded: (even, odd) sample = (re, im)
     // this lane's band (lane) and half band (64 + lane / 2, weight slots 8 (lane & 1) .. + 7): first bin, length
     const int mbnd = 64 + (lane >> 1);
     const int sa = fb_start[lane], na = fb_len[lane] < fb_stride ? fb_len[lane] : fb_stride;
@@ -218,142 +214,149 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
     // log10(1 + s x) -> z-norm as one multiply-add behind the hardware's log2 (v_log_f32, 1 ulp; the argument is >= 1)
     const float out_mul = 0.30102999566398120f / norm_2std, out_add = -norm_mean / norm_2std;
     const float ls4 = 0.25f * log_scale;         // the power spectra below are kept times four
-    for (int i = threadIdx.x; i < 512; i += 256) {
-        wtab[i] = window[i];
-        tw256[i] = twiddle[4 * ((((i >> 1) & 15) * (i >> 5)) & 255) + (i & 1)];
-        tw512[i] = twiddle[i];
-    }
-    for (int i = threadIdx.x; i < MEL_BANDS * 16; i += 256) {
-        const int m = i >> 4, k = i & 15;
-        fbw[i] = k < fb_len[m] && k < fb_stride ? fb_w[m * fb_stride + k] : 0.0f;
-    }
-    __syncthreads();
+    // tables: 128 threads copy the window, 128 the 512-point twiddles (16 bytes each), every thread gathers one 256-point twiddle
+    if (threadIdx.x < 128) *reinterpret_cast<f32x4_t*>(wtab + 4 * threadIdx.x) = *reinterpret_cast<const f32x4_t*>(window + 4 * threadIdx.x);
+    else *reinterpret_cast<f32x4_t*>(tw512 + 4 * (threadIdx.x - 128)) = *reinterpret_cast<const f32x4_t*>(twiddle + 4 * (threadIdx.x - 128));
+    *reinterpret_cast<cplx*>(tw256 + 2 * threadIdx.x) =
+        *reinterpret_cast<const cplx*>(twiddle + 4 * (((threadIdx.x & 15) * (threadIdx.x >> 4)) & 255));       // exp(-2 pi i l k1 / 256) at [16 k1 + l]
+    // the first 8 filter weights of this lane's band and its half band's 8 (zero beyond the band: the host pads its rows with zeros)
     float wa[8], wb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        wa[i] = fbw[lane * 16 + i];
-        wb[i] = fbw[mbnd * 16 + 8 * (lane & 1) + i];
-    }
-
-    for (int quad = 0; quad < 4; ++quad) {
-        const int tl0 = wv * 16 + quad * 4;      // first of this wave's four frames within the block
-        // ---- framing (center=True, reflect padding of 256 samples) + window + complex packing: v[n1] = z[16 n1 + l]
-        cplx v[16];
-#pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            const cplx w2 = *reinterpret_cast<const cplx*>(wtab + 2 * (16 * n1 + l));
-            const cplx xin = n1 < 8 ? cplx{xa[2 * (n1 & 7)], xa[2 * (n1 & 7) + 1]} : cplx{xb[2 * (n1 & 7)], xb[2 * (n1 & 7) + 1]};
-            v[n1] = xin * w2;
-        }
-        if (quad + 1 < 4) {                       // the next four frames' samples fly while these are transformed
-            if (interior) mel_fetch<true>(xa, xb, wsrc, t0 + tl0 + 4 + grp, T, S, l);
-            else mel_fetch<false>(xa, xb, wsrc, t0 + tl0 + 4 + grp, T, S, l);
-        }
-        // ---- 256 = 16 x 16: DFT over n1, twiddle, exchange, DFT over n2.  (The lane's table values are read a stage ahead of their use:
-        // the packed-math statements are asm, which hipcc does not move loads across)
-        cplx tw[15];
-#pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) tw[k1 - 1] = *reinterpret_cast<const cplx*>(tw256 + 2 * (16 * k1 + l));      // W256^(l k1)
-        dft16(v);
-        char* xf = xch + grp * MEL_XFRAME;
-        *reinterpret_cast<cplx*>(xf + l * 8) = v[rev16(0)];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {             // k1 = 1 + 5 g .. 5 + 5 g: five products at a time, first halves then second halves
-            cplx ta[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) ta[i] = cmul_a<false>(v[rev16(1 + 5 * g + i)], tw[5 * g + i]);
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-                *reinterpret_cast<cplx*>(xf + (1 + 5 * g + i) * MEL_XROW + l * 8) = cmul_b<false>(v[rev16(1 + 5 * g + i)], tw[5 * g + i], ta[i]);
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const f32x4_t q = *reinterpret_cast<const f32x4_t*>(xf + l * MEL_XROW + j * 16);
-            v[2 * j] = cplx{q[0], q[1]};
-            v[2 * j + 1] = cplx{q[2], q[3]};
-        }
-        cplx wu[16];
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) wu[k2] = *reinterpret_cast<const cplx*>(tw512 + 2 * (l + 16 * k2));          // exp(-2 pi i (l + 16 k2) / 512)
-        dft16(v);                                 // Z[l + 16 k2] at v[rev16(k2)]
-        // ---- unpack the real FFT: X[k] = E[k] + W512^k O[k], power spectrum for k = l + 16 k2 (and bin 256 from lane 0)
-        wave_lds_sync();                          // every lane has read its row: the tiles become the power spectra
-        // power spectra of the wave's four frames, bin-major: pw[bin][frame] -- the projection below takes one bin of all four frames
-        // with a single 16-byte read; the 64 lanes of a store cover 64 consecutive floats.  Bins 257 .. 271 are zero: a band's
-        // register-resident weights run past its last bin (weight 0) and must meet finite values there.
-        float* pw = reinterpret_cast<float*>(xch);
-        if (lane < 4 * (MEL_PWBINS - MEL_NBINS)) pw[4 * MEL_NBINS + lane] = 0.0f;
-        const int src = (lane & 48) | ((16 - l) & 15);
-        // Z[256 - k] sits in lane 16 - l, slot 15 - k2 (lane 0 pairs with itself: slot (16 - k2) mod 16): the partner values of all 16 slots
-        // first (selects and lane moves: plain statements, scheduled by hipcc), then the packed arithmetic four slots at a time
-        cplx pz[16];
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-            const cplx za = v[rev16((16 - k2) & 15)], zb = v[rev16(15 - k2)];      // (selected per component: a select between
-            const float sr = l == 0 ? MEL_RE(za) : MEL_RE(zb), si = l == 0 ? MEL_IM(za) : MEL_IM(zb);      //  two array elements would pin v[] to scratch)
-            pz[k2] = cplx{mel_row_partner(sr, src), mel_row_partner(si, src)};
-        }
-        if (l == 0) {
-            const float x256 = 2.0f * (MEL_RE(v[rev16(0)]) - MEL_IM(v[rev16(0)]));      // 2 X[256] = 2 (Re Z[0] - Im Z[0])
-            pw[4 * 256 + grp] = x256 * x256;
-        }
-        // 2 X[k] = (Z[k] + conj Z[N-k]) - i (Z[k] - conj Z[N-k]) W512^k: the halves are left out (the power comes out times four,
-        // exactly; the factor rides in the log's scale below)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            cplx e[4], d[4], t[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { e[i] = cadd_conj(v[rev16(4 * g + i)], pz[4 * g + i]); d[i] = csub_conj(v[rev16(4 * g + i)], pz[4 * g + i]); }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) t[i] = cmul_a<false>(d[i], wu[4 * g + i]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d[i] = cmul_b<false>(d[i], wu[4 * g + i], t[i]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) e[i] = cadd_rot(e[i], d[i]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) t[i] = csqr2(e[i]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pw[4 * (l + 16 * (4 * g + i)) + grp] = MEL_RE(t[i]) + MEL_IM(t[i]);
-        }
-        wave_lds_sync();
-        // ---- mel projection + logC + z-norm into the block's output tile, the wave's four frames at once: lane L forms band L from
-        // 8 bins (the slaney bank's bands 0 .. 63 are 1 .. 6 bins long) and one HALF of band 64 + L / 2 (8 of its 16 weight slots: bands
-        // 64 .. 95 are 6 .. 15 bins long), a bin of the four frames per 16-byte LDS read, the weights in registers (wa / wb, loaded in
-        // front of the frame loop); the halves meet through one lane exchange.  Longer bands finish in a global-read loop (never with
-        // this bank).  (Rounds 3 - 5a: one frame at a time, 1.5 bands per lane, a 4-byte LDS read per product and its wait in front of
-        // every multiply-add: 724 of the ~1800 instructions a wave spent on four frames.)
-        {
-            const f32x4_t* pwq = reinterpret_cast<const f32x4_t*>(xch);
-            f32x4_t acc_a = {0.0f, 0.0f, 0.0f, 0.0f}, acc_b = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x4_t pa = pwq[sa + i], pb = pwq[sb + i];
-                acc_a = __builtin_elementwise_fma(pa, f32x4_t{wa[i], wa[i], wa[i], wa[i]}, acc_a);
-                acc_b = __builtin_elementwise_fma(pb, f32x4_t{wb[i], wb[i], wb[i], wb[i]}, acc_b);
-            }
-#pragma unroll 1
-            for (int i = 8; i < na; ++i) acc_a += pwq[sa + i] * fb_w[lane * fb_stride + i];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) acc_b[f] += __shfl_xor(acc_b[f], 1, 64);
-            if ((lane & 1) == 0)
-#pragma unroll 1
-                for (int i = 16; i < nb; ++i) acc_b += pwq[sb + i] * fb_w[mbnd * fb_stride + i];
-            const int tl = wv * 16 + quad * 4;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                otile[lane * MEL_OUT_LD + tl + f] = __builtin_fmaf(mel_log2(__builtin_fmaf(acc_a[f], ls4, 1.0f)), out_mul, out_add);
-                if ((lane & 1) == 0)
-                    otile[mbnd * MEL_OUT_LD + tl + f] = __builtin_fmaf(mel_log2(__builtin_fmaf(acc_b[f], ls4, 1.0f)), out_mul, out_add);
-            }
-        }
-        wave_lds_sync();       // pw / the exchange tile are rewritten by the next four frames
+        wa[i] = i < na ? fb_w[lane * fb_stride + i] : 0.0f;
+        wb[i] = 8 * (lane & 1) + i < nb ? fb_w[mbnd * fb_stride + 8 * (lane & 1) + i] : 0.0f;
     }
     __syncthreads();
-    // ---- coalesced store of the [96][64] tile
-    for (int i = threadIdx.x; i < MEL_BANDS * MEL_FRAMES_PER_BLOCK; i += 256) {
-        const int m = i >> 6, tl = i & 63;
-        if (t0 + tl < T) out[((int64_t)b * MEL_BANDS + m) * T + t0 + tl] = otile[m * MEL_OUT_LD + tl];
+
+    // (one copy of the frame loop per fetch form: with both forms inside one loop the prefetch registers met in phi copies, 32 moves per pass)
+    auto frames = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+        mel_fetch<INTERIOR>(xin, wsrc, t0 + wv * 16 + grp, T, S, l);
+        for (int quad = 0; quad < 4; ++quad) {
+            const int tl0 = wv * 16 + quad * 4;      // first of this wave's four frames within the block
+            // ---- framing (center=True, reflect padding of 256 samples) + window + complex packing: v[n1] = z[16 n1 + l]
+            cplx v[16];
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const cplx w2 = *reinterpret_cast<const cplx*>(wtab + 2 * (16 * n1 + l));
+                v[n1] = xin[n1] * w2;
+            }
+            if (quad + 1 < 4) {                       // the next four frames' samples fly while these are transformed
+                mel_fetch<INTERIOR>(xin, wsrc, t0 + tl0 + 4 + grp, T, S, l);
+            }
+            // ---- 256 = 16 x 16: DFT over n1, twiddle, exchange, DFT over n2.  (The lane's table values are read a stage ahead of their use:
+            // the packed-math statements are asm, which hipcc does not move loads across)
+            cplx tw[15];
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) tw[k1 - 1] = *reinterpret_cast<const cplx*>(tw256 + 2 * (16 * k1 + l));      // W256^(l k1)
+            dft16(v);
+            char* xf = xch + grp * MEL_XFRAME;
+            *reinterpret_cast<cplx*>(xf + l * 8) = v[rev16(0)];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {             // k1 = 1 + 5 g .. 5 + 5 g: five products at a time, first halves then second halves
+                cplx ta[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) ta[i] = cmul_a<false>(v[rev16(1 + 5 * g + i)], tw[5 * g + i]);
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                    *reinterpret_cast<cplx*>(xf + (1 + 5 * g + i) * MEL_XROW + l * 8) = cmul_b<false>(v[rev16(1 + 5 * g + i)], tw[5 * g + i], ta[i]);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4_t q = *reinterpret_cast<const f32x4_t*>(xf + l * MEL_XROW + j * 16);
+                v[2 * j] = cplx{q[0], q[1]};
+                v[2 * j + 1] = cplx{q[2], q[3]};
+            }
+            cplx wu[16];
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) wu[k2] = *reinterpret_cast<const cplx*>(tw512 + 2 * (l + 16 * k2));          // exp(-2 pi i (l + 16 k2) / 512)
+            dft16(v);                                 // Z[l + 16 k2] at v[rev16(k2)]
+            // ---- unpack the real FFT: X[k] = E[k] + W512^k O[k], power spectrum for k = l + 16 k2 (and bin 256 from lane 0)
+            wave_lds_sync();                          // every lane has read its row: the tiles become the power spectra
+            // power spectra of the wave's four frames, bin-major: pw[bin][frame] -- the projection below takes one bin of all four frames
+            // with a single 16-byte read; the 64 lanes of a store cover 64 consecutive floats.  Bins 257 .. 271 are zero: a band's
+            // register-resident weights run past its last bin (weight 0) and must meet finite values there.
+            float* pw = reinterpret_cast<float*>(xch);
+            if (lane < 4 * (MEL_PWBINS - MEL_NBINS)) pw[4 * MEL_NBINS + lane] = 0.0f;
+            const int src = (lane & 48) | ((16 - l) & 15);
+            // Z[256 - k] sits in lane 16 - l, slot 15 - k2 (lane 0 pairs with itself: slot (16 - k2) mod 16): the partner values of all 16 slots
+            // first (selects and lane moves: plain statements, scheduled by hipcc), then the packed arithmetic four slots at a time
+            cplx pz[16];
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const cplx za = v[rev16((16 - k2) & 15)], zb = v[rev16(15 - k2)];      // (selected per component: a select between
+                const float sr = l == 0 ? MEL_RE(za) : MEL_RE(zb), si = l == 0 ? MEL_IM(za) : MEL_IM(zb);      //  two array elements would pin v[] to scratch)
+                pz[k2] = cplx{mel_row_partner(sr, src), mel_row_partner(si, src)};
+            }
+            if (l == 0) {
+                const float x256 = 2.0f * (MEL_RE(v[rev16(0)]) - MEL_IM(v[rev16(0)]));      // 2 X[256] = 2 (Re Z[0] - Im Z[0])
+                pw[4 * 256 + grp] = x256 * x256;
+            }
+            // 2 X[k] = (Z[k] + conj Z[N-k]) - i (Z[k] - conj Z[N-k]) W512^k: the halves are left out (the power comes out times four,
+            // exactly; the factor rides in the log's scale below)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                cplx e[4], d[4], t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { e[i] = cadd_conj(v[rev16(4 * g + i)], pz[4 * g + i]); d[i] = csub_conj(v[rev16(4 * g + i)], pz[4 * g + i]); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = cmul_a<false>(d[i], wu[4 * g + i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = cmul_b<false>(d[i], wu[4 * g + i], t[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = cadd_rot(e[i], d[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = csqr2(e[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pw[4 * (l + 16 * (4 * g + i)) + grp] = MEL_RE(t[i]) + MEL_IM(t[i]);
+            }
+            wave_lds_sync();
+            // ---- mel projection + logC + z-norm into the block's output tile, the wave's four frames at once: lane L forms band L from
+            // 8 bins (the slaney bank's bands 0 .. 63 are 1 .. 6 bins long) and one HALF of band 64 + L / 2 (8 of its 16 weight slots: bands
+            // 64 .. 95 are 6 .. 15 bins long), a bin of the four frames per 16-byte LDS read, the weights in registers (wa / wb, loaded in
+            // front of the frame loop); the halves meet through one lane exchange.  Longer bands finish in a global-read loop (never with
+            // this bank).  (Rounds 3 - 5a: one frame at a time, 1.5 bands per lane, a 4-byte LDS read per product and its wait in front of
+            // every multiply-add: 724 of the ~1800 instructions a wave spent on four frames.)
+            {
+                const f32x4_t* pwq = reinterpret_cast<const f32x4_t*>(xch);
+                f32x4_t acc_a = {0.0f, 0.0f, 0.0f, 0.0f}, acc_b = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4_t pa = pwq[sa + i], pb = pwq[sb + i];
+                    acc_a = __builtin_elementwise_fma(pa, f32x4_t{wa[i], wa[i], wa[i], wa[i]}, acc_a);
+                    acc_b = __builtin_elementwise_fma(pb, f32x4_t{wb[i], wb[i], wb[i], wb[i]}, acc_b);
+                }
+#pragma unroll 1
+                for (int i = 8; i < na; ++i) acc_a += pwq[sa + i] * fb_w[lane * fb_stride + i];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc_b[f] += __shfl_xor(acc_b[f], 1, 64);
+                if ((lane & 1) == 0)
+#pragma unroll 1
+                    for (int i = 16; i < nb; ++i) acc_b += pwq[sb + i] * fb_w[mbnd * fb_stride + i];
+                const int tl = wv * 16 + quad * 4;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    otile[lane * MEL_OUT_LD + tl + f] = __builtin_fmaf(mel_log2(__builtin_fmaf(acc_a[f], ls4, 1.0f)), out_mul, out_add);
+                    if ((lane & 1) == 0)
+                        otile[mbnd * MEL_OUT_LD + tl + f] = __builtin_fmaf(mel_log2(__builtin_fmaf(acc_b[f], ls4, 1.0f)), out_mul, out_add);
+                }
+            }
+            wave_lds_sync();       // pw / the exchange tile are rewritten by the next four frames
+        }
+    };
+    if (interior) frames(std::true_type{});
+    else frames(std::false_type{});
+    __syncthreads();
+    // ---- coalesced store of the [96][64] tile: thread = frame tid & 63 of bands (tid >> 6) + 4 j (256-byte runs along T)
+    {
+        const int tl = threadIdx.x & 63, m0 = threadIdx.x >> 6;
+        if (t0 + tl < T) {
+            float* dst = out + ((int64_t)b * MEL_BANDS + m0) * T + t0 + tl;
+            const float* src = otile + m0 * MEL_OUT_LD + tl;
+#pragma unroll
+            for (int j = 0; j < MEL_BANDS / 4; ++j) dst[(int64_t)4 * j * T] = src[4 * j * MEL_OUT_LD];
+        }
     }
 }
 
@@ -368,7 +371,7 @@ extern "C" int maest_logmel(const float* wave, int B, int S, const float* window
     MAEST_REQUIRE(B > 0 && S > MEL_NFFT / 2, "maest_logmel: bad shape B=%d S=%d (reflect padding needs S > 256)", B, S);
     MAEST_REQUIRE(fb_stride > 0, "maest_logmel: bad fb_stride");
     const int T = 1 + S / MEL_HOP;
-    const int smem_bytes = (512 + 512 + 512 + MEL_BANDS * 16 + MEL_BANDS * MEL_OUT_LD) * 4 + 4 * 4 * MEL_XFRAME;
+    const int smem_bytes = (512 + 512 + 512 + MEL_BANDS * MEL_OUT_LD) * 4 + 4 * 4 * MEL_XFRAME;
     dim3 grid((T + MEL_FRAMES_PER_BLOCK - 1) / MEL_FRAMES_PER_BLOCK, B);
     static DeviceOnce once;                       // 70 KiB of dynamic LDS: above the 64 KiB a kernel gets without the attribute
     ensure_dynamic_lds(once, &logmel_kernel, smem_bytes);
