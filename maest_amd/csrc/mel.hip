@@ -13,7 +13,8 @@
 // <= fb_stride consecutive bins): the four frames' power spectra lie bin-major in LDS, a lane forms one band and one half
 // band of all four frames from 16-byte reads with its weights in registers.  All arithmetic is fp32.  (Rounds 1-2: one
 // frame per wave, four radix-4 stages through LDS, ~800 instructions per frame and wave = 0.11 of the HBM roofline; round 3:
-// 16 x 16 with a per-frame projection, ~440 = 0.17; round 5: ~280 = 0.23 -- DESIGN.md section 4.)
+// 16 x 16 with a per-frame projection, ~440 = 0.17; round 5: the projection over four frames at once, ~280 = 0.23, then the FFT
+// stages and the unpack in packed fp32 instructions with explicit operand modifiers, ~165 = 0.31 -- DESIGN.md section 4.)
 #include <type_traits>
 
 #include "common.h"
@@ -84,15 +85,29 @@ __device__ __forceinline__ int rev4_256(int k) {  // reverse the four base-4 dig
 
 __device__ __forceinline__ float mel_log2(float x) { return __builtin_amdgcn_logf(x); }       // v_log_f32
 
-// The value lane (16 - l) mod 16 of the same 16-lane row holds (l = lane mod 16): two DPP moves on the device -- rotate the row by one,
-// mirror it: no LDS crossbar, no wait --, a lane permutation under the host emulator.
-__device__ __forceinline__ float mel_row_partner(float x, int src_lane) {
+// The value lane (16 - l) mod 16 of the same 16-lane row holds (l = lane mod 16) = mirror(next(x)): two DPP moves on the device -- rotate the
+// row by one, mirror it: no LDS crossbar, no wait --, lane permutations under the host emulator.  (Two functions: a DPP move wants its source
+// written two instructions earlier, so the callers issue them in batches.)
+__device__ __forceinline__ float mel_row_next(float x, int lane) {          // the value of lane (l + 1) mod 16
 #if defined(__AMDGCN__)
-    int t = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x12f /* row_ror:15 */, 0xf, 0xf, false);
-    t = __builtin_amdgcn_mov_dpp(t, 0x140 /* row_mirror */, 0xf, 0xf, false);
-    return __builtin_bit_cast(float, t);
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x12f /* row_ror:15 */, 0xf, 0xf, false));
 #else
-    return __shfl(x, src_lane, 64);
+    return __shfl(x, (lane & 48) | ((lane + 1) & 15), 64);
+#endif
+}
+__device__ __forceinline__ float mel_row_mirror(float x, int lane) {        // the value of lane 15 - l
+#if defined(__AMDGCN__)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x140 /* row_mirror */, 0xf, 0xf, false));
+#else
+    return __shfl(x, (lane & 48) | (15 - (lane & 15)), 64);
+#endif
+}
+
+__device__ __forceinline__ float mel_lane_xor1(float x) {                   // the value of lane ^ 1
+#if defined(__AMDGCN__)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+#else
+    return __shfl_xor(x, 1, 64);
 #endif
 }
 
@@ -183,7 +198,7 @@ constexpr int MEL_PWBINS = 272;                   // 257 bins + 15 zero bins (a 
 // registers), ONE exchange through LDS (lane n2 writes column n2, lane k1 reads row k1), a 16-point DFT over n2 in registers.
 // The real-FFT unpack needs Z[256 - k], which lives in lane 16 - l of the same group: one lane permutation per value.  The
 // mel projection runs over the four frames at once (a band and a half band per lane, filter weights in registers).  Per frame and
-// wave ~280 instructions (counted in the code object: 1120 per four frames) against ~800 for four radix-4 stages through LDS with
+// wave ~165 instructions (counted in the code object: ~650 per four frames) against ~800 for four radix-4 stages through LDS with
 // one frame per wave.
 __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict__ wave_in, int S, int T,
                                                      const float* __restrict__ window,
@@ -279,15 +294,23 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
             // register-resident weights run past its last bin (weight 0) and must meet finite values there.
             float* pw = reinterpret_cast<float*>(xch);
             if (lane < 4 * (MEL_PWBINS - MEL_NBINS)) pw[4 * MEL_NBINS + lane] = 0.0f;
-            const int src = (lane & 48) | ((16 - l) & 15);
-            // Z[256 - k] sits in lane 16 - l, slot 15 - k2 (lane 0 pairs with itself: slot (16 - k2) mod 16): the partner values of all 16 slots
+                // Z[256 - k] sits in lane 16 - l, slot 15 - k2 (lane 0 pairs with itself: slot (16 - k2) mod 16): the partner values of all 16 slots
             // first (selects and lane moves: plain statements, scheduled by hipcc), then the packed arithmetic four slots at a time
             cplx pz[16];
 #pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) {
-                const cplx za = v[rev16((16 - k2) & 15)], zb = v[rev16(15 - k2)];      // (selected per component: a select between
-                const float sr = l == 0 ? MEL_RE(za) : MEL_RE(zb), si = l == 0 ? MEL_IM(za) : MEL_IM(zb);      //  two array elements would pin v[] to scratch)
-                pz[k2] = cplx{mel_row_partner(sr, src), mel_row_partner(si, src)};
+            for (int hf = 0; hf < 2; ++hf) {          // eight slots at a time: selects, then the rotations, then the mirrors
+                float sr[8], si[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k2 = 8 * hf + i;
+                    const cplx za = v[rev16((16 - k2) & 15)], zb = v[rev16(15 - k2)];      // (selected per component: a select between
+                    sr[i] = l == 0 ? MEL_RE(za) : MEL_RE(zb);                               //  two array elements would pin v[] to scratch)
+                    si[i] = l == 0 ? MEL_IM(za) : MEL_IM(zb);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { sr[i] = mel_row_next(sr[i], lane); si[i] = mel_row_next(si[i], lane); }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pz[8 * hf + i] = cplx{mel_row_mirror(sr[i], lane), mel_row_mirror(si[i], lane)};
             }
             if (l == 0) {
                 const float x256 = 2.0f * (MEL_RE(v[rev16(0)]) - MEL_IM(v[rev16(0)]));      // 2 X[256] = 2 (Re Z[0] - Im Z[0])
@@ -330,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
 #pragma unroll 1
                 for (int i = 8; i < na; ++i) acc_a += pwq[sa + i] * fb_w[lane * fb_stride + i];
 #pragma unroll
-                for (int f = 0; f < 4; ++f) acc_b[f] += __shfl_xor(acc_b[f], 1, 64);
+                for (int f = 0; f < 4; ++f) acc_b[f] += mel_lane_xor1(acc_b[f]);
                 if ((lane & 1) == 0)
 #pragma unroll 1
                     for (int i = 16; i < nb; ++i) acc_b += pwq[sb + i] * fb_w[mbnd * fb_stride + i];
