@@ -194,6 +194,8 @@ def test_mel():
     KC.case_mel(DEV, 2, 160000)
     KC.case_mel(DEV, 1, 480000, seed=81)
     KC.case_mel(DEV, 1, 5000, seed=82)
+    KC.case_mel(DEV, 3, 40001, seed=83)      # odd clip length: clips 1, 2 start off the 8-byte grid (the element-wise fetch form inside the clip too)
+    KC.case_mel(DEV, 2, 16640, seed=84)      # T = 66: one full block of 64 frames + two frames
 
 
 def test_melfile(tmp_path):
