@@ -188,6 +188,12 @@ def test_emu_mel(emu):
     KC.case_mel(emu, 1, 2560)
 
 
+def test_emu_mel_interior_blocks(emu):
+    """193 frames = four 64-frame blocks: the two middle ones take the aligned 8-byte fetch form (the packed-math twins of the FFT stages run
+    under both forms), the second clip starts off the 8-byte grid (odd length) and takes the element-wise form throughout."""
+    KC.case_mel(emu, 2, 49153, seed=85)
+
+
 def test_emu_melfile(emu, tmp_path):
     KC.case_melfile(emu, tmp_path)
 
