@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MAEST_ABI_VERSION 6
+#define MAEST_ABI_VERSION 7
 
 #define MAEST_OK 0
 #define MAEST_ERR_INVALID 1 /* bad argument (shape / alignment / dtype) */
@@ -77,6 +77,7 @@ const char* maest_last_error(void);
  * replaced (same results: the forms are bit-equal for the GEMMs, equal to rounding for the attention forward).  *mask = OR of: */
 #define MAEST_FORM_GEMM_NT_OW 1  /* gemm_nt_ow.hip: bf16 NT GEMM, one wave per SIMD (else the eight-wave kernel)            */
 #define MAEST_FORM_GEMM_TN_OW 2  /* gemm_tn_ow.hip: bf16 wgrad GEMM, one wave per SIMD (else the eight-wave kernel)         */
+#define MAEST_FORM_GEMM_NT_OWD 8 /* gemm_nt_owd.hip: the bf16 NT GEMM with the deferred C-tile store (else gemm_nt_ow.hip's kernel)           */
 #define MAEST_FORM_ATTN_FWD_PW 4 /* attn_fwd_pw.hip: persistent bf16 attention forward for N > 320 (else four-wave LDS-DMA) */
 int maest_kernel_forms(int* mask);
 
@@ -120,9 +121,22 @@ int maest_kernel_forms(int* mask);
                                at most n workgroups, workgroup b walking tiles b, b + n, ... with the next tile's first operand units
                                requested from inside the epilogue (256 = one per CU; small values make a workgroup walk several tiles
                                at test shapes) */
+#define MAEST_OPT_GEMM_PANEL 10 /* env MAEST_GEMM_PANEL, default 0: the bf16 NT GEMMs (gemm_nt_ow.hip, gemm_nt_owd.hip) walk their tiles row-major
+                                  inside an XCD's range; -1: in column panels where a traffic estimate says so (B larger than ~3 MB: N = 3072
+                                  at K = 768 in panels of 6, N = 2304 in 5 + 4); n > 0: panels of n tiles.  Results do not depend on it.
+                                  Measured (profiles/r06_gemm_panels.txt): fabric reads of fc1 5.8 -> 4.0 x the operand bytes, time equal
+                                  (they are Infinity-Cache hits), inference step +0.4 % -- hence off by default. */
+#define MAEST_OPT_GEMM_DEFER 11 /* env MAEST_GEMM_DEFER, default 1: plain bf16-output NT GEMMs with complete tile rows (M % 256 == 0, K >= 384)
+                                  run gemm_nt256d_kernel (gemm_nt_owd.hip: the C tile is packed to bf16 registers at the end of its K loop
+                                  and stored from inside the next tile's main loop); 0: gemm_nt256o_kernel for those too (bit-equal). */
 #define MAEST_OPT_LN_BWD_BLOCKS 4 /* env MAEST_LN_BWD_BLOCKS, default 1024: workgroup cap of the LayerNorm backward grid */
 int maest_set_option(int opt, int value, int restore_default);
 int maest_get_option(int opt, int* value);
+/* ABI 7: an override of one switch for the CALLING THREAD only (clear != 0 removes it; `value` is then ignored).  Launches made by this
+ * thread see the override, every other thread the process-wide value; maest_get_option on this thread returns the override.  The
+ * engine sets the launch form of a forward / backward pass this way (maest_amd/maest.py: _gemm_form), so that two models driven
+ * from two threads of one process cannot change each other's launches. */
+int maest_set_option_thread(int opt, int value, int clear);
 
 /* ---- K8, K10-K12, K13 head, K4 (im2col form) and their dgrad / wgrad ---------------------------
  * nn.Linear: models/maest.py:353,355,361,376 ; :197-199,203-206 ; :572,579 ; nn.Conv2d :238-240.

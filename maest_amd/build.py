@@ -8,11 +8,11 @@ if os.path.dirname(HERE) not in sys.path:
     sys.path.insert(0, os.path.dirname(HERE))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmaest_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "gemm_nt_ow.hip", "gemm_tn_ow.hip", "norm.hip", "attention.hip", "attn_fwd_pw.hip", "embed.hip", "misc.hip", "mel.hip", "mel2.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "gemm_nt_ow.hip", "gemm_nt_owd.hip", "gemm_tn_ow.hip", "norm.hip", "attention.hip", "attn_fwd_pw.hip", "embed.hip", "misc.hip", "mel.hip", "mel2.hip"]
 
 
 # sources whose inline asm owns fixed registers: {file: (first, last owned arch VGPR)}; all accumulator registers are owned too
-AUDITED = {"attn_fwd_pw.hip": (96, 245), "gemm_nt_ow.hip": (188, 255, True), "gemm_tn_ow.hip": (176, 255, True)}
+AUDITED = {"attn_fwd_pw.hip": (96, 245), "gemm_nt_ow.hip": (188, 255, True), "gemm_nt_owd.hip": (64, 255), "gemm_tn_ow.hip": (176, 255, True)}
 
 
 def _hipcc():
@@ -118,7 +118,13 @@ def build(force=False, verbose=True, leave_out=(), lib=None):
     objs = {}
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    import glob
     for s in srcs:
+        if os.path.basename(s) in AUDITED:
+            # an assembly file left by an EARLIER build must never be what the audit reads (a hipcc that names its -save-temps output
+            # differently, or writes none, would otherwise pass on the old compiler's code): remove it before compiling
+            for old in glob.glob(os.path.join(HERE, "build", os.path.splitext(os.path.basename(s))[0] + "*.s")):
+                os.remove(old)
         o = os.path.join(HERE, "build", os.path.basename(s) + (".off.o" if os.path.basename(s) in leave_out else ".o"))
         objs[os.path.basename(s)] = o
         cmd = _compile_cmd(s, o, owned_disabled=os.path.basename(s) in leave_out)

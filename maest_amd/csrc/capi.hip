@@ -28,12 +28,12 @@ int check_launch(const char* what) {
 }
 
 // ---- process-wide switches: environment read ONCE (first use), then lock-free atomics
-static constexpr int kNumOptions = 10;
-static const int kOptionDefault[kNumOptions] = {8192, 0, -1, 0, 1024, 1, 0, 0, 0, 0};
+static constexpr int kNumOptions = 12;
+static const int kOptionDefault[kNumOptions] = {8192, 0, -1, 0, 1024, 1, 0, 0, 0, 0, 0, 1};
 static const char* const kOptionEnv[kNumOptions] = {"MAEST_GEMM_MIN_M", "MAEST_GEMM_VARIANT", "MAEST_GEMM_EPILOGUE",
                                                   "MAEST_ATTN_BWD", "MAEST_LN_BWD_BLOCKS", "MAEST_GEMM_TAIL",
                                                   "MAEST_ATTN_FWD", "MAEST_ATTN_FWD_WAVES",
-                                                  "MAEST_TN_REDUCE", "MAEST_GEMM_WGS"};
+                                                  "MAEST_TN_REDUCE", "MAEST_GEMM_WGS", "MAEST_GEMM_PANEL", "MAEST_GEMM_DEFER"};
 static std::atomic<int> g_option[kNumOptions];
 static int g_option_env[kNumOptions];
 static std::once_flag g_option_once;
@@ -48,7 +48,13 @@ static void options_init() {
     });
 }
 
+// per-thread overrides (maest_set_option_thread): a pass that wants its own launch form sets them on the thread that launches its
+// kernels -- two engines on two threads of one process then never see each other's choice
+static thread_local int t_option[kNumOptions];
+static thread_local unsigned t_option_mask = 0;
+
 int option(int opt) {
+    if ((t_option_mask >> opt) & 1u) return t_option[opt];
     options_init();
     return g_option[opt].load(std::memory_order_relaxed);
 }
@@ -61,6 +67,15 @@ extern "C" int maest_set_option(int opt, int value, int restore_default) {
     maest::g_option[opt].store(restore_default ? maest::g_option_env[opt] : value, std::memory_order_relaxed);
     return MAEST_OK;
 }
+extern "C" int maest_set_option_thread(int opt, int value, int clear) {
+    MAEST_REQUIRE(opt >= 0 && opt < maest::kNumOptions, "maest_set_option_thread: unknown option %d", opt);
+    if (clear) maest::t_option_mask &= ~(1u << opt);
+    else {
+        maest::t_option[opt] = value;
+        maest::t_option_mask |= 1u << opt;
+    }
+    return MAEST_OK;
+}
 extern "C" int maest_get_option(int opt, int* value) {
     MAEST_REQUIRE(opt >= 0 && opt < maest::kNumOptions && value, "maest_get_option: unknown option %d", opt);
     *value = maest::option(opt);
@@ -69,12 +84,13 @@ extern "C" int maest_get_option(int opt, int* value) {
 
 namespace maest {
 bool gemm_nt256o_available();   // gemm_nt_ow.hip
+bool gemm_nt256d_available();   // gemm_nt_owd.hip
 bool gemm_tn256o_available();   // gemm_tn_ow.hip
 bool attn_fwd_pw_available();   // attn_fwd_pw.hip
 }  // namespace maest
 extern "C" int maest_kernel_forms(int* mask) {
     MAEST_REQUIRE(mask, "maest_kernel_forms: null pointer");
-    *mask = (maest::gemm_nt256o_available() ? MAEST_FORM_GEMM_NT_OW : 0) | (maest::gemm_tn256o_available() ? MAEST_FORM_GEMM_TN_OW : 0) |
+    *mask = (maest::gemm_nt256o_available() ? MAEST_FORM_GEMM_NT_OW : 0) | (maest::gemm_nt256d_available() ? MAEST_FORM_GEMM_NT_OWD : 0) | (maest::gemm_tn256o_available() ? MAEST_FORM_GEMM_TN_OW : 0) |
             (maest::attn_fwd_pw_available() ? MAEST_FORM_ATTN_FWD_PW : 0);
     return MAEST_OK;
 }

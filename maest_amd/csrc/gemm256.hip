@@ -996,7 +996,7 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
     p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux;
     p.M = M; p.N = N; p.K = K; p.out_dtype = out_dtype; p.epi = epi;
-    p.rowdot = rowdot; p.ntok = ntok > 0 ? ntok : 1; p.row0 = 0;
+    p.rowdot = rowdot; p.ntok = ntok > 0 ? ntok : 1; p.row0 = 0; p.panel_w = 0;
     p.tiles_m = (M + 255) / 256;
     // Measured (scratch/gemm_ab.py): the one-workgroup-per-CU 256x256 kernel wins on every ViT shape but the
     // value-only GELU epilogue; the 256x128 two-per-CU kernel serves N % 256 != 0 and MAEST_GEMM_VARIANT=2.

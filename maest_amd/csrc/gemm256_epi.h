@@ -20,6 +20,7 @@ struct Gemm256Params {
     float* rowdot;      // MAEST_EPI_ROWDOT: fp32 [rows / ntok, N / 64, ntok]
     int ntok;
     int row0;           // row of the whole problem this launch's row 0 is (second launch of a split problem)
+    int panel_w;        // gemm_nt256o_kernel: > 0 = tiles are walked in column panels of this many tiles (gemm_nt_ow.hip: tile_of)
 };
 
 // The second operand of the RESIDUAL / MUL epilogues (aux_in, 16 bytes per output chunk) for one staging pass, fetched
@@ -167,5 +168,9 @@ bool gemm_tn256o_available();   // false in a build whose register audit failed 
 // output for the GELU + GELU' pair)
 int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream);
 bool gemm_nt256o_available();
+// gemm_nt_owd.hip: the same kernel with the C tile's store deferred into the next tile's main loop (plain bf16 outputs)
+bool gemm_nt256d_available();
+bool gemm_nt256d_takes(const Gemm256Params& p);
+int gemm_nt256d_launch(Gemm256Params& p, hipStream_t stream);
 
 }  // namespace maest

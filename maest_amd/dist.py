@@ -88,6 +88,11 @@ class GradReducer:
         self._pending = [0] * len(self.buckets)
         self.reduced_this_step = 0
         self._works = []
+        # timing = True: every bucket's all-reduce is bracketed by two events on the stream that launches it (the engine's dedicated
+        # communication stream), launch -> complete; bucket_times() reads them back (bench.py prints them per bucket on the --gpus N line,
+        # so that a scaling record can be read against DESIGN.md section 6's prediction).  Costs two event records per bucket.
+        self.timing = False
+        self._events = []
         self.reset()
 
     def reset(self):
@@ -110,14 +115,38 @@ class GradReducer:
         self._pending[b] -= 1
         return b if (self._pending[b] == 0 and self.collective) else None
 
-    def reduce_bucket(self, b: int):
+    def reduce_bucket(self, b: int, dedicated_stream: bool = False):
         """Launch the asynchronous all-reduce of bucket `b`.  It is ordered after the stream that is current at the call:
         the caller makes that stream wait for every stream that wrote gradients of the bucket (maest.py: a dedicated
         stream that waits for the dgrad and the wgrad stream ONCE PER BUCKET -- neither of them is held up)."""
         bk = self.buckets[b]
+        timed = self.timing and dedicated_stream and self.flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         w = dist.all_reduce(self.flat[bk["start"]:bk["end"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if timed:
+            w.wait()            # a STREAM-side wait of the launching (communication) stream, which has nothing else to do; not a host wait
+            e1.record()
+            self._events.append((b, e0, e1))
+            if len(self._events) > 64 * len(self.buckets):
+                del self._events[:len(self.buckets)]
         self._works.append(w)
         self.reduced_this_step += 1
+
+    def bucket_times(self, clear: bool = True):
+        """[{bucket, mb, all_reduces, launch_to_complete_ms (mean), max_ms}] over the all-reduces timed since the last call (timing = True;
+        synchronizes the device)."""
+        if not self._events:
+            return []
+        torch.cuda.synchronize(self.flat.device)
+        acc = {}
+        for b, e0, e1 in self._events:
+            acc.setdefault(b, []).append(e0.elapsed_time(e1))
+        if clear:
+            self._events = []
+        return [{"bucket": b, "mb": round((self.buckets[b]["end"] - self.buckets[b]["start"]) * 4 / 2 ** 20, 1), "all_reduces": len(v),
+                 "launch_to_complete_ms": round(sum(v) / len(v), 3), "max_ms": round(max(v), 3)} for b, v in sorted(acc.items())]
 
     def on_grad(self, name):
         """note_grad + reduce_bucket on the current stream (callers with a single stream: the host-logic tests)."""

@@ -132,8 +132,14 @@ class _Weights:
     def _srows(self, p, dtype):
         return self.scaled_rows.get(id(p), 0) if dtype != torch.float32 else 0
 
+    def _key(self, p, dtype, transposed, pad_cols_to=0):
+        # a row-scaled plain copy is keyed by its scaling, so that it coexists with the unscaled copy of the same parameter (alternating
+        # bf16 and fp32 / bf16x3 forwards on one model then drop nothing, and captured evaluation graphs stay valid: ADVICE r5)
+        rows = 0 if transposed else self._srows(p, dtype)
+        return (id(p), dtype, transposed, pad_cols_to) if rows == 0 else (id(p), dtype, transposed, pad_cols_to, rows, self.row_scale)
+
     def get(self, p: torch.Tensor, dtype, transposed=False, pad_cols_to: int = 0):
-        key = (id(p), dtype, transposed, pad_cols_to)
+        key = self._key(p, dtype, transposed, pad_cols_to)
         ver = p._version
         hit = self._fresh(key, p)
         if hit is not None:
@@ -172,7 +178,7 @@ class _Weights:
         stale = []
         for p in params:
             for tr in ((False, True) if with_t else (False,)):
-                if self._fresh((id(p), dtype, tr, 0), p) is None:
+                if self._fresh(self._key(p, dtype, tr), p) is None:
                     stale.append(p)
                     break
         if not stale:
@@ -181,9 +187,9 @@ class _Weights:
                                       scaled_rows=[self._srows(p, dtype) for p in stale], row_scale=self.row_scale)
         for p, (o, ot) in zip(stale, outs):
             if o is not None:
-                self._cache[(id(p), dtype, False, 0)] = (p._version, o, weakref.ref(p))
+                self._cache[self._key(p, dtype, False)] = (p._version, o, weakref.ref(p))
             if ot is not None:
-                self._cache[(id(p), dtype, True, 0)] = (p._version, ot, weakref.ref(p))
+                self._cache[self._key(p, dtype, True)] = (p._version, ot, weakref.ref(p))
 
     def split3(self, params):
         """MAEST_SPLIT3_B copies (bf16 [out, 3 * in]: hi | lo | hi) of fp32 weight matrices, stale ones rebuilt in one launch; cached
@@ -199,13 +205,14 @@ class _Weights:
     def scaled_biases(self, biases, rows: int):
         """fp32 copies of `biases` with the first `rows` entries multiplied by row_scale (the q part of the qkv biases beside the
         row-scaled weight copies), all in one launch; cached like the weight copies."""
-        stale = [b for b in biases if self._fresh((id(b), "scaled-bias", False, rows), b) is None]
+        bkey = lambda b: (id(b), "scaled-bias", False, rows, self.row_scale)
+        stale = [b for b in biases if self._fresh(bkey(b), b) is None]
         if stale:
             outs = ops.cast_weights_multi([b.detach().reshape(-1, 1) for b in stale], torch.float32, want=True, want_t=False,
                                           scaled_rows=[rows] * len(stale), row_scale=self.row_scale)
             for b, (o, _) in zip(stale, outs):
-                self._cache[(id(b), "scaled-bias", False, rows)] = (b._version, o.reshape(-1), weakref.ref(b))
-        return [self._cache[(id(b), "scaled-bias", False, rows)][1] for b in biases]
+                self._cache[bkey(b)] = (b._version, o.reshape(-1), weakref.ref(b))
+        return [self._cache[bkey(b)][1] for b in biases]
 
     def clear(self):
         self._cache.clear()
@@ -285,6 +292,13 @@ class _Engine:
         # MAEST_WGRAD_WGS = 0: the kernel's plan.  Without the side stream (serialized passes) the plan is the kernel's.
         self.wgrad_wgs = int(os.environ.get("MAEST_WGRAD_WGS", "128"))
         self.bwd_gemm_wgs = int(os.environ.get("MAEST_BWD_GEMM_WGS", "256"))     # persistent workgroups of the dgrad GEMMs (A/B)
+        # Data-parallel backward (a gradient sink is attached and exchanges buckets): RCCL's kernels hold a CU per channel while a bucket
+        # is in flight, and a wgrad workgroup needs a WHOLE CU (512 registers per lane, 160 KiB of LDS) -- a plan wider than 256 - c
+        # workgroups would run a second round for the c that found no CU.  The wgrad launches of such a pass are therefore at most
+        # 256 - MAEST_WGRAD_RESERVE_CUS wide (default: NCCL_MAX_NCHANNELS if the job sets it, else 32); with the default 128-wide
+        # side-stream launches this only binds serialized passes and MAEST_WGRAD_WGS = 0 / > 224.  Never measured on a multi-GPU box:
+        # the knob exists so that the first one can tune it.
+        self.wgrad_reserve_cus = max(0, min(192, int(os.environ.get("MAEST_WGRAD_RESERVE_CUS", os.environ.get("NCCL_MAX_NCHANNELS", "32")))))
         self._inflight = collections.deque()
 
     def throttle(self):
@@ -332,7 +346,8 @@ class _Engine:
         be re-dealt around them).  Explicit MAEST_GEMM_WGS / MAEST_GEMM_TAIL settings (set_option) are left alone."""
         if not self.persistent_gemm or shared or ops.get_option("gemm_wgs") != 0:
             return contextlib.nullcontext()
-        return ops.options(gemm_wgs=wgs, gemm_tail=0) if ops.get_option("gemm_tail") == 1 else ops.options(gemm_wgs=wgs)
+        # (per-thread overrides: the forward thread and the autograd thread of ANOTHER model in this process keep their own form)
+        return ops.thread_options(gemm_wgs=wgs, gemm_tail=0) if ops.get_option("gemm_tail") == 1 else ops.thread_options(gemm_wgs=wgs)
 
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, *args, **kw):
@@ -367,11 +382,13 @@ class _Engine:
         scale = m.blocks[0].attn.scale
         qs = bool(self.fold_qscale) and dt == torch.bfloat16
         want_rows = {id(blk.attn.qkv.weight): EMBED_DIM for blk in m.blocks} if qs else {}
-        if want_rows != W.scaled_rows or (qs and W.row_scale != scale * LOG2E):
-            W.clear()
-            W.scaled_rows, W.row_scale = want_rows, scale * LOG2E
+        W.scaled_rows, W.row_scale = want_rows, scale * LOG2E      # (scaled and unscaled copies are cached under different keys)
         W.refresh(mats, dt, with_t=save)
-        qkv_bias = W.scaled_biases([blk.attn.qkv.bias for blk in m.blocks], EMBED_DIM) if qs else [blk.attn.qkv.bias for blk in m.blocks]
+        qkv_bias = [blk.attn.qkv.bias for blk in m.blocks]
+        if qs and any(b is not None for b in qkv_bias):      # (qkv_bias=False models have no bias to scale)
+            have = [b for b in qkv_bias if b is not None]
+            scaled = iter(W.scaled_biases(have, EMBED_DIM))
+            qkv_bias = [next(scaled) if b is not None else None for b in qkv_bias]
         fast3 = bool(self.x3_fast) and x3m and not save
         if fast3:
             w3 = W.split3([lin.weight for blk in m.blocks for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)])
@@ -553,9 +570,14 @@ class _Engine:
                     comm.wait_stream(main)
                     comm.wait_stream(side)
                     with torch.cuda.stream(comm):
-                        sink.reduce_bucket(b)
+                        sink.reduce_bucket(b, dedicated_stream=True)
                 else:
                     sink.reduce_bucket(b)
+
+        # launch width of this pass's wgrads (0 = the kernel's one-round plan of <= 256 workgroups)
+        wg_w = self.wgrad_wgs if side is not None else 0
+        if sink is not None and getattr(sink, "collective", False):
+            wg_w = min(wg_w if wg_w > 0 else 256, 256 - self.wgrad_reserve_cus)
 
         def wgrad(name_w, name_b, dy, x, n_out, k_out, w_shape=None):
             gw, gb = buf(name_w, n_out, k_out), buf(name_b, n_out)
@@ -564,11 +586,11 @@ class _Engine:
                 ev.record(main)            # dy, x and the zeroed destinations are ready at this point
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    _wgrad(dy, x, n_out, k_out, gw, gb, x3m, wgs=self.wgrad_wgs)
+                    _wgrad(dy, x, n_out, k_out, gw, gb, x3m, wgs=wg_w)
                 for t in (dy, x, gw, gb):
                     t.record_stream(side)  # keep the caching allocator from recycling them under the side stream
             else:
-                _wgrad(dy, x, n_out, k_out, gw, gb, x3m)
+                _wgrad(dy, x, n_out, k_out, gw, gb, x3m, wgs=wg_w)
             done(name_w, gw if w_shape is None else gw.view(w_shape))
             done(name_b, gb)
 

@@ -584,6 +584,23 @@ def get_option(name: str) -> int:
     return v
 
 
+class thread_options:
+    """``with ops.thread_options(gemm_wgs=256): ...`` -- override switches for launches made by THIS thread inside the block
+    (maest_set_option_thread); other threads, and this thread afterwards, see the process-wide values.  Not re-entrant per switch."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            call("maest_set_option_thread", _lib.OPTIONS[k], int(v), 0)
+        return self
+
+    def __exit__(self, *a):
+        for k in self.kw:
+            call("maest_set_option_thread", _lib.OPTIONS[k], 0, 1)
+
+
 class options:
     """``with ops.options(gemm_min_m=512): ...`` -- set switches for a block, restore the previous values after."""
 

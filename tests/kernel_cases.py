@@ -76,7 +76,7 @@ def case_gemm(dev, dtype, M, N, K, seed=0, identity=True):
     close(acc, ref - bias, rt, at * math.sqrt(K / 64), "gemm split-k")
 
 
-def case_gemm_one_wave_per_simd(dev, M, N, K, seed=11, only=None, pair=True):
+def case_gemm_one_wave_per_simd(dev, M, N, K, seed=11, only=None, pair=True, both_bias=False, defer_ab=False):
     """gemm_nt256o_kernel (gemm_nt_ow.hip: bf16 operands, the default of the 256 x 256 path) against the 8-wave kernel it replaces
     (gemm_variant = 3): the same products summed in the same order and the same epilogue arithmetic -- bit for bit, in every
     epilogue form, ragged last tile row included -- and against the oracle's fp32 matmul."""
@@ -94,11 +94,15 @@ def case_gemm_one_wave_per_simd(dev, M, N, K, seed=11, only=None, pair=True):
     for name, kw in forms:
         if only is not None and name not in only:
             continue
-        for b in ((bias, None) if only is None else (bias,)):
+        for b in ((bias, None) if (only is None or both_bias) else (bias,)):
             new = ops.gemm_nt(a, w, b, **kw)
             with ops.options(gemm_variant=3):
                 old = ops.gemm_nt(a, w, b, **kw)
             assert torch.equal(new, old), f"one-wave-per-SIMD GEMM differs from the 8-wave kernel: {name}, bias {b is not None}"
+            if defer_ab:        # (plain bf16 outputs on complete tile rows take gemm_nt256d_kernel by default: the same call on gemm_nt256o_kernel)
+                with ops.options(gemm_defer=0):
+                    other = ops.gemm_nt(a, w, b, **kw)
+                assert torch.equal(new, other), f"deferred-store kernel differs from gemm_nt256o_kernel: {name}, bias {b is not None}"
     c = ops.gemm_nt(a, w, bias, out_dtype=torch.float32)
     close(c, ref, 1e-5, 4e-7 * K, "one-wave-per-SIMD GEMM vs fp32 matmul")
     if not pair:

@@ -67,6 +67,20 @@ def test_emu_gemm_one_wave_per_simd_kernel(emu, gemm_options):
     # start, and behind the last pass's operand fetch in the RESIDUAL form --, A_1 / B_1 behind it, stage 0 without its own A_0 / B_0)
     gemm_options(gemm_wgs=1)
     KC.case_gemm_one_wave_per_simd(emu, 520, 256, 128, only=("none -> bf16", "residual -> fp32"), pair=False)
+    # tile order in column panels (tile_of): 2 x 3 tiles walked as panels of 2 + 1
+    gemm_options(gemm_wgs=0, gemm_panel=2)
+    KC.case_gemm_one_wave_per_simd(emu, 512, 768, 64, only=("none -> bf16",), pair=False)
+
+
+def test_emu_gemm_deferred_store_kernel(emu, gemm_options):
+    """gemm_nt256d_kernel's host twin (gemm_nt_owd.hip: plain bf16 outputs on complete tile rows; the C tile packed to bf16 registers at the
+    end of its K loop and stored from inside the next tile's stages 0 .. 3): 6 and 7 K stages, with and without bias, one workgroup per
+    tile (pack + immediate stores) and ONE workgroup walking three tiles (deferred stores, the bias registers aliasing the packed tile's
+    last four) -- bit for bit against the 8-wave kernel, and against gemm_nt256o_kernel (gemm_defer = 0)"""
+    gemm_options(gemm_min_m=512, gemm_tail=0)
+    KC.case_gemm_one_wave_per_simd(emu, 512, 256, 384, only=("none -> bf16",), pair=False, both_bias=True)
+    gemm_options(gemm_wgs=1)
+    KC.case_gemm_one_wave_per_simd(emu, 768, 256, 448, only=("none -> bf16",), pair=False, both_bias=True, defer_ab=True)
 
 
 @pytest.mark.parametrize("dtype", DT_BIG)

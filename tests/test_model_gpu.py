@@ -354,6 +354,24 @@ def test_grad_sink_path_equals_autograd_path():
         assert d <= 1e-5 * max(ref[n].abs().max().item(), 1e-6) + 1e-7, (n, d)   # atomics: order-only noise
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_model_without_qkv_bias(precision):
+    """MAEST(qkv_bias=False) is a constructor option (models/maest.py:470): in bf16 mode the softmax scale is folded into the qkv operand
+    copies and into a copy of the qkv BIASES -- a model without them must run and equal the model whose biases are zero"""
+    from maest_amd.maest import MAEST
+    torch.manual_seed(3)
+    a = MAEST(img_size=(96, 625), qkv_bias=False, precision=precision).to(DEV).eval()
+    b = MAEST(img_size=(96, 625), qkv_bias=True, precision=precision).to(DEV).eval()
+    sd = a.state_dict()
+    for i in range(12):
+        sd[f"blocks.{i}.attn.qkv.bias"] = torch.zeros(2304, device=DEV)
+    b.load_state_dict(sd)
+    x = torch.randn((2, 96, 626), device=DEV)
+    with torch.no_grad():
+        la, lb = a(x.clone())[0], b(x.clone())[0]
+    assert torch.equal(la, lb)
+
+
 def test_hip_graph_captured_inference_is_bit_identical():
     """north_star configs[4]: the eval forward replayed from a HIP graph equals the eager launches bit for bit,
     for successive inputs, and is re-captured after a parameter update."""
