@@ -77,7 +77,6 @@ const char* maest_last_error(void);
  * replaced (same results: the forms are bit-equal for the GEMMs, equal to rounding for the attention forward).  *mask = OR of: */
 #define MAEST_FORM_GEMM_NT_OW 1  /* gemm_nt_ow.hip: bf16 NT GEMM, one wave per SIMD (else the eight-wave kernel)            */
 #define MAEST_FORM_GEMM_TN_OW 2  /* gemm_tn_ow.hip: bf16 wgrad GEMM, one wave per SIMD (else the eight-wave kernel)         */
-#define MAEST_FORM_GEMM_NT_OWD 8 /* gemm_nt_owd.hip: the bf16 NT GEMM with the deferred C-tile store (else gemm_nt_ow.hip's kernel)           */
 #define MAEST_FORM_ATTN_FWD_PW 4 /* attn_fwd_pw.hip: persistent bf16 attention forward for N > 320 (else four-wave LDS-DMA) */
 int maest_kernel_forms(int* mask);
 
@@ -121,14 +120,11 @@ int maest_kernel_forms(int* mask);
                                at most n workgroups, workgroup b walking tiles b, b + n, ... with the next tile's first operand units
                                requested from inside the epilogue (256 = one per CU; small values make a workgroup walk several tiles
                                at test shapes) */
-#define MAEST_OPT_GEMM_PANEL 10 /* env MAEST_GEMM_PANEL, default 0: the bf16 NT GEMMs (gemm_nt_ow.hip, gemm_nt_owd.hip) walk their tiles row-major
+#define MAEST_OPT_GEMM_PANEL 10 /* env MAEST_GEMM_PANEL, default 0: the bf16 NT GEMM (gemm_nt_ow.hip) walks its tiles row-major
                                   inside an XCD's range; -1: in column panels where a traffic estimate says so (B larger than ~3 MB: N = 3072
                                   at K = 768 in panels of 6, N = 2304 in 5 + 4); n > 0: panels of n tiles.  Results do not depend on it.
                                   Measured (profiles/r06_gemm_panels.txt): fabric reads of fc1 5.8 -> 4.0 x the operand bytes, time equal
                                   (they are Infinity-Cache hits), inference step +0.4 % -- hence off by default. */
-#define MAEST_OPT_GEMM_DEFER 11 /* env MAEST_GEMM_DEFER, default 1: plain bf16-output NT GEMMs with complete tile rows (M % 256 == 0, K >= 384)
-                                  run gemm_nt256d_kernel (gemm_nt_owd.hip: the C tile is packed to bf16 registers at the end of its K loop
-                                  and stored from inside the next tile's main loop); 0: gemm_nt256o_kernel for those too (bit-equal). */
 #define MAEST_OPT_LN_BWD_BLOCKS 4 /* env MAEST_LN_BWD_BLOCKS, default 1024: workgroup cap of the LayerNorm backward grid */
 int maest_set_option(int opt, int value, int restore_default);
 int maest_get_option(int opt, int* value);

@@ -68,11 +68,11 @@ SIGNATURES = {
     "maest_set_option_thread": [_I, _I, _I],
     "maest_kernel_forms": [_P],
 }
-FORM_GEMM_NT_OW, FORM_GEMM_TN_OW, FORM_ATTN_FWD_PW, FORM_GEMM_NT_OWD = 1, 2, 4, 8
+FORM_GEMM_NT_OW, FORM_GEMM_TN_OW, FORM_ATTN_FWD_PW = 1, 2, 4
 
 ABI_VERSION = 7
 OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "ln_bwd_blocks": 4, "gemm_tail": 5, "attn_fwd": 6, "attn_fwd_waves": 7,
-           "tn_reduce": 8, "gemm_wgs": 9, "gemm_panel": 10, "gemm_defer": 11}
+           "tn_reduce": 8, "gemm_wgs": 9, "gemm_panel": 10}
 
 _lib = None
 _host_emulation = False  # set only by tests/emu

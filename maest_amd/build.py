@@ -8,11 +8,11 @@ if os.path.dirname(HERE) not in sys.path:
     sys.path.insert(0, os.path.dirname(HERE))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmaest_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "gemm_nt_ow.hip", "gemm_nt_owd.hip", "gemm_tn_ow.hip", "norm.hip", "attention.hip", "attn_fwd_pw.hip", "embed.hip", "misc.hip", "mel.hip", "mel2.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "gemm_nt_ow.hip", "gemm_tn_ow.hip", "norm.hip", "attention.hip", "attn_fwd_pw.hip", "embed.hip", "misc.hip", "mel.hip", "mel2.hip"]
 
 
 # sources whose inline asm owns fixed registers: {file: (first, last owned arch VGPR)}; all accumulator registers are owned too
-AUDITED = {"attn_fwd_pw.hip": (96, 245), "gemm_nt_ow.hip": (188, 255, True), "gemm_nt_owd.hip": (64, 255), "gemm_tn_ow.hip": (176, 255, True)}
+AUDITED = {"attn_fwd_pw.hip": (96, 245), "gemm_nt_ow.hip": (124, 255, True), "gemm_tn_ow.hip": (176, 255, True)}
 
 
 def _hipcc():

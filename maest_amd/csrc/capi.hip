@@ -28,12 +28,12 @@ int check_launch(const char* what) {
 }
 
 // ---- process-wide switches: environment read ONCE (first use), then lock-free atomics
-static constexpr int kNumOptions = 12;
-static const int kOptionDefault[kNumOptions] = {8192, 0, -1, 0, 1024, 1, 0, 0, 0, 0, 0, 1};
+static constexpr int kNumOptions = 11;
+static const int kOptionDefault[kNumOptions] = {8192, 0, -1, 0, 1024, 1, 0, 0, 0, 0, 0};
 static const char* const kOptionEnv[kNumOptions] = {"MAEST_GEMM_MIN_M", "MAEST_GEMM_VARIANT", "MAEST_GEMM_EPILOGUE",
                                                   "MAEST_ATTN_BWD", "MAEST_LN_BWD_BLOCKS", "MAEST_GEMM_TAIL",
                                                   "MAEST_ATTN_FWD", "MAEST_ATTN_FWD_WAVES",
-                                                  "MAEST_TN_REDUCE", "MAEST_GEMM_WGS", "MAEST_GEMM_PANEL", "MAEST_GEMM_DEFER"};
+                                                  "MAEST_TN_REDUCE", "MAEST_GEMM_WGS", "MAEST_GEMM_PANEL"};
 static std::atomic<int> g_option[kNumOptions];
 static int g_option_env[kNumOptions];
 static std::once_flag g_option_once;
@@ -84,13 +84,12 @@ extern "C" int maest_get_option(int opt, int* value) {
 
 namespace maest {
 bool gemm_nt256o_available();   // gemm_nt_ow.hip
-bool gemm_nt256d_available();   // gemm_nt_owd.hip
 bool gemm_tn256o_available();   // gemm_tn_ow.hip
 bool attn_fwd_pw_available();   // attn_fwd_pw.hip
 }  // namespace maest
 extern "C" int maest_kernel_forms(int* mask) {
     MAEST_REQUIRE(mask, "maest_kernel_forms: null pointer");
-    *mask = (maest::gemm_nt256o_available() ? MAEST_FORM_GEMM_NT_OW : 0) | (maest::gemm_nt256d_available() ? MAEST_FORM_GEMM_NT_OWD : 0) | (maest::gemm_tn256o_available() ? MAEST_FORM_GEMM_TN_OW : 0) |
+    *mask = (maest::gemm_nt256o_available() ? MAEST_FORM_GEMM_NT_OW : 0) | (maest::gemm_tn256o_available() ? MAEST_FORM_GEMM_TN_OW : 0) |
             (maest::attn_fwd_pw_available() ? MAEST_FORM_ATTN_FWD_PW : 0);
     return MAEST_OK;
 }

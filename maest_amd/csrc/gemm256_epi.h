@@ -168,9 +168,5 @@ bool gemm_tn256o_available();   // false in a build whose register audit failed 
 // output for the GELU + GELU' pair)
 int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream);
 bool gemm_nt256o_available();
-// gemm_nt_owd.hip: the same kernel with the C tile's store deferred into the next tile's main loop (plain bf16 outputs)
-bool gemm_nt256d_available();
-bool gemm_nt256d_takes(const Gemm256Params& p);
-int gemm_nt256d_launch(Gemm256Params& p, hipStream_t stream);
 
 }  // namespace maest

@@ -7,20 +7,32 @@
 // fragment reads behind the other wave group's MFMAs with four barriers per stage.  Its removal ablation
 // (profiles/r02c_nt_mainloop_ablation.txt) puts the MFMA stream alone and the load stream alone at 60 % of the kernel each: what is
 // lost is their overlap.  Here a workgroup is FOUR waves, one per SIMD, each owning 128 x 128 outputs:
-//   * the 256 fp32 accumulators of a wave live in the accumulator half of the register file (a0 .. a255), the fragments of two
-//     16-deep k-steps in v192 .. v255; both ranges are owned by this file -- touched only by the inline asm below, audited in the
-//     code object by maest_amd/build.py (maest_amd/pw_audit.py), exactly as attn_fwd_pw.hip does it;
-//   * per K stage a wave reads 32 KiB of fragments for 64 MFMAs (LDS: 512 + 512 cycles against 2048), two ds_read_b128 per four
-//     MFMAs, issued one k-step ahead in the shadow of the MFMAs of the running k-step: the statements below execute in program
-//     order, so the source is the schedule -- one instruction stream per SIMD, no wave to take turns with, ONE barrier per stage;
+//   * the 256 fp32 accumulators of a wave live in the accumulator half of the register file (a0 .. a255), the fragments of the two
+//     k32 halves of a stage in v128 .. v255; both ranges are owned by this file -- touched only by the inline asm of gemm_nt_ow.h,
+//     audited in the code object by maest_amd/build.py (maest_amd/pw_audit.py), exactly as attn_fwd_pw.hip does it;
+//   * the matrix instruction is v_mfma_f32_16x16x32_bf16 (round 6; rounds 4 - 5: 32x32x16).  The kernel is bound by the clock the power
+//     limit leaves, and the 16 x 16 shape costs less energy per flop: back-to-back MFMAs on random operands sustain 2090 against 1825
+//     TFLOP/s, this kernel gained 3 - 6 % (profiles/r06_mfma_shape_power.txt; the vendor library's kernels at these shapes are 16 x 16
+//     kernels and clock 9 % higher than the 32 x 32 form did: profiles/r06_gemm_vs_library.txt).  64 blocks of 16 x 16 per wave;
+//   * per K stage a wave reads 32 KiB of fragments for 128 MFMAs (LDS: 512 + 512 cycles against 2048): one ds_read_b128 per three
+//     MFMAs during the first 46 slots of a half, a whole half ahead of their use; the statements execute in program order, so the
+//     source is the schedule -- one instruction stream per SIMD, no wave to take turns with, ONE barrier per stage (between its halves);
+//   * an MFMA and what rides in its shadow are ONE asm statement (hipcc puts a wait state behind every asm statement, and a 16-cycle
+//     MFMA has four issue slots);
 //   * the operand ring is gemm_nt256w_kernel's: 128-byte rows (whole cache lines), units A_j / B_j of 256 rows = 32 KiB through five
-//     buffers, source-side swizzle  chunk ^= (row >> 1) & 7,  LDS-DMA requests dealt out between the MFMAs (four per k-step), a
-//     counted vmcnt(8) in front of the barrier (only the unit requested last may fly);
+//     buffers, source-side swizzle  chunk ^= (row >> 1) & 7  (conflict-free for the 16-row x 4-chunk fragment reads too), LDS-DMA
+//     requests dealt out between the MFMAs (four per quarter stage), a counted vmcnt(8) in front of the barrier (only the unit
+//     requested last may fly);
 //   * the stage loop is unrolled over the ring's period with one body per stage kind, so that a stage boundary costs a counter, a
-//     compare and a branch not taken: with one wave per SIMD every scalar instruction in front of an MFMA is a bubble in the pipe;
-//   * the first k-step's MFMAs take the constant 0 as their C operand (no clearing pass over 256 registers).
-// The C tile leaves through LDS in four 64-row passes, double buffered, with the bias / GELU / GELU' / residual / multiply
-// epilogues of gemm256_epi.h.
+//     compare and a branch not taken;
+//   * the first half's MFMAs of a tile take the constant 0 as their C operand (no clearing pass over 256 registers).
+// The C tile leaves through LDS in four 64-row passes with the bias / GELU / GELU' / multiply / row-dot epilogues of gemm256_epi.h; 16-bit
+// outputs only (bf16, split rows) -- fp32 outputs of bf16 operands stay with gemm_nt256w_kernel.  Results: the products of a k32 half are
+// rounded together where the 32 x 32 kernels round per 16: last-bit differences in fp32, at most one bf16 ulp in < 2 % of the outputs
+// (tests/kernel_cases.py: _same_products); bit-equal to the 8-wave kernel in the host emulator, whose MFMA twins add term by term.
+// Measured and dropped in round 6: the C tile packed to bf16 registers and stored from inside the next tile's main loop
+// (profiles/r06_gemm_deferred_store.txt: register-direct row-piece stores are slower than the LDS-staged whole lines; full overlap would be
+// worth 16 - 19 % at K = 768), column-panel tile order (MAEST_GEMM_PANEL: fewer fabric reads, no time).
 #include "gemm256_epi.h"
 
 #ifdef MAEST_OWNED_DISABLED
@@ -36,7 +48,7 @@ int gemm_nt256o_launch(Gemm256Params&, hipStream_t) {
 #else
 
 #define OW_PROF_VAR 1       // (this file defines the profiling variable of OW_PROF builds)
-#include "gemm_nt_ow.h"     // the ring, the register map and the main-loop statements (shared with gemm_nt_owd.hip)
+#include "gemm_nt_ow.h"     // the ring, the register map and the main-loop statements 
 
 namespace maest {
 
@@ -64,65 +76,64 @@ __device__ __forceinline__ void ow_epilogue_run(char* smem0, OwCtx& c, const Gem
     char* smem = smem0 + OW_EPI0;                               // (the ring's first two units stay free for the next tile's A_0 B_0)
     constexpr int NCH = 32 * E::CPR / 256;                      // 16-byte chunks per thread and 32-row group: 4 / 8
     constexpr int RS = 256 / E::CPR;                            // rows between a thread's consecutive chunks: 8 / 4
-    const int h = lane >> 5;
-    // this lane's bias quadruples (columns 128 wn + 32 nt + 8 g + 4 h ..+3) come out of LDS one n-tile ahead of their use (4 registers x
-    // 4 instead of 64 held through the epilogue: the persistent loop needs the registers)
-    auto bias_tile = [&](int nt, f32x4_t (&b)[4]) {
+    const int q16 = lane >> 4;
+    // Accumulator block (n16, m16) of the 16 x 16 MFMA: this lane holds row 16 m16 + (lane & 15), columns 16 n16 + 4 q16 ..+3 of the wave's
+    // 128 x 128.  A pass stages the wave's rows 32 ps ..+31 = the blocks m16 = 2 ps, 2 ps + 1 of all eight n16; this lane's bias quadruple of
+    // a 16-column block (columns 128 wn + 16 n16 + 4 q16 ..+3) comes out of LDS one block ahead of its use.
+    auto bias_blk = [&](int n16) { return *reinterpret_cast<const f32x4_t*>(smem + BIAS0 + (wn * 128 + n16 * 16 + 4 * q16) * 4); };
+    auto stage_blk = [&](auto n_tag, auto m_tag, char* row, const f32x4_t& b4) {
+        constexpr int N16 = decltype(n_tag)::value, M16 = decltype(m_tag)::value;
+        const f32x4_t t = ow_acc_read<N16, M16>(c);
+        float v[4], d[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4_t*>(smem + BIAS0 + (wn * 128 + nt * 32 + 8 * g + 4 * h) * 4);
-    };
-    auto stage_tile = [&](auto nt_tag, auto ps_tag, char* row, const f32x4_t (&b4)[4]) {
-        constexpr int NT = decltype(nt_tag)::value, PS = decltype(ps_tag)::value;
-        const f32x16_t t = ow_acc_read<NT, PS>(c);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float v[4], d[4];
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                const f32x2_t xv = {t[4 * g + e] + b4[g][e], t[4 * g + e + 1] + b4[g][e + 1]};
-                f32x2_t gv = xv, dv = {0.0f, 0.0f};
-                if (GMODE != 0) gelu_pair2<false>(xv, gv, dv);
-                v[e] = gv[0]; v[e + 1] = gv[1];
-                d[e] = dv[0]; d[e + 1] = dv[1];
-            }
-            char* dst = row + (NT * 32 + 8 * g) * OSZ;
-            if (OSZ == 4) {
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                if (PAIR) *reinterpret_cast<float4*>(dst + REGION) = make_float4(d[0], d[1], d[2], d[3]);
-            } else {
-                chunk8 o;
-                if (SPLIT) {
-                    uint32_t h0, l0, h1, l1;
-                    split_bf2(v[0], v[1], h0, l0);
-                    split_bf2(v[2], v[3], h1, l1);
-                    o[0] = h0; o[1] = h1;
-                    *reinterpret_cast<chunk8*>(dst) = o;
-                    const chunk8 q = {l0, l1};
-                    *reinterpret_cast<chunk8*>(dst + REGION) = q;
-                    continue;
-                }
-                o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
+        for (int e = 0; e < 4; e += 2) {
+            const f32x2_t xv = {t[e] + b4[e], t[e + 1] + b4[e + 1]};
+            f32x2_t gv = xv, dv = {0.0f, 0.0f};
+            if (GMODE != 0) gelu_pair2<false>(xv, gv, dv);
+            v[e] = gv[0]; v[e + 1] = gv[1];
+            d[e] = dv[0]; d[e + 1] = dv[1];
+        }
+        char* dst = row + (N16 * 16) * OSZ;
+        if (OSZ == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            if (PAIR) *reinterpret_cast<float4*>(dst + REGION) = make_float4(d[0], d[1], d[2], d[3]);
+        } else {
+            chunk8 o;
+            if (SPLIT) {
+                uint32_t h0, l0, h1, l1;
+                split_bf2(v[0], v[1], h0, l0);
+                split_bf2(v[2], v[3], h1, l1);
+                o[0] = h0; o[1] = h1;
                 *reinterpret_cast<chunk8*>(dst) = o;
-                if (PAIR) {
-                    chunk8 q;
-                    q[0] = pack_bf2(d[0], d[1]); q[1] = pack_bf2(d[2], d[3]);
-                    *reinterpret_cast<chunk8*>(dst + REGION) = q;
-                }
+                const chunk8 q = {l0, l1};
+                *reinterpret_cast<chunk8*>(dst + REGION) = q;
+                return;
+            }
+            o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
+            *reinterpret_cast<chunk8*>(dst) = o;
+            if (PAIR) {
+                chunk8 q;
+                q[0] = pack_bf2(d[0], d[1]); q[1] = pack_bf2(d[2], d[3]);
+                *reinterpret_cast<chunk8*>(dst + REGION) = q;
             }
         }
     };
     auto stage = [&](auto ps_tag, char* buf) {
         using std::integral_constant;
-        char* row = buf + (wm * 32 + (lane & 31)) * E::PITCH + (wn * 128 + 4 * h) * OSZ;
-        f32x4_t b0[4], b1[4];
-        bias_tile(0, b0);
-        bias_tile(1, b1);
-        stage_tile(integral_constant<int, 0>{}, ps_tag, row, b0);
-        bias_tile(2, b0);
-        stage_tile(integral_constant<int, 1>{}, ps_tag, row, b1);
-        bias_tile(3, b1);
-        stage_tile(integral_constant<int, 2>{}, ps_tag, row, b0);
-        stage_tile(integral_constant<int, 3>{}, ps_tag, row, b1);
+        constexpr int PS = decltype(ps_tag)::value;
+        char* row0 = buf + (wm * 32 + (lane & 15)) * E::PITCH + (wn * 128 + 4 * q16) * OSZ;
+        char* row1 = row0 + 16 * E::PITCH;
+        constexpr integral_constant<int, 2 * PS> M0{};
+        constexpr integral_constant<int, 2 * PS + 1> M1{};
+        f32x4_t b = bias_blk(0), bn = bias_blk(1);
+        stage_blk(integral_constant<int, 0>{}, M0, row0, b); stage_blk(integral_constant<int, 0>{}, M1, row1, b); b = bias_blk(2);
+        stage_blk(integral_constant<int, 1>{}, M0, row0, bn); stage_blk(integral_constant<int, 1>{}, M1, row1, bn); bn = bias_blk(3);
+        stage_blk(integral_constant<int, 2>{}, M0, row0, b); stage_blk(integral_constant<int, 2>{}, M1, row1, b); b = bias_blk(4);
+        stage_blk(integral_constant<int, 3>{}, M0, row0, bn); stage_blk(integral_constant<int, 3>{}, M1, row1, bn); bn = bias_blk(5);
+        stage_blk(integral_constant<int, 4>{}, M0, row0, b); stage_blk(integral_constant<int, 4>{}, M1, row1, b); b = bias_blk(6);
+        stage_blk(integral_constant<int, 5>{}, M0, row0, bn); stage_blk(integral_constant<int, 5>{}, M1, row1, bn); bn = bias_blk(7);
+        stage_blk(integral_constant<int, 6>{}, M0, row0, b); stage_blk(integral_constant<int, 6>{}, M1, row1, b);
+        stage_blk(integral_constant<int, 7>{}, M0, row0, bn); stage_blk(integral_constant<int, 7>{}, M1, row1, bn);
     };
     // drain: thread t moves chunk cc = t % CPR of rows r0 + RS i (r0 = t / CPR) of a 32-row group; its pointers into C / aux are
     // formed once, a group's rows are wave-uniform multiples of the row pitch away.  Rows beyond M exist in the last tile row only.
@@ -179,7 +190,10 @@ __device__ __forceinline__ void ow_epilogue_run(char* smem0, OwCtx& c, const Gem
             }
             // streaming output: written once, re-read by a later kernel after > L2-size of other traffic
             if (full || m0 + r0 + ro0 + i * RS < p.M)
-                __builtin_nontemporal_store(o, reinterpret_cast<chunk16*>(dthr + (ro0 + i * RS) * drow));
+            {
+                if (OW_ABLATE & 128) *reinterpret_cast<chunk16*>(dthr + (ro0 + i * RS) * drow) = o;       // (A/B: plain instead of streaming stores)
+                else __builtin_nontemporal_store(o, reinterpret_cast<chunk16*>(dthr + (ro0 + i * RS) * drow));
+            }
         }
     };
     auto drain = [&](int ps, const char* buf) {
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
     const int wm = wave >> 1, wn = wave & 1;
 #if OW_DEV
     // the registers this file owns (the clobber makes the kernel descriptor allocate them)
-    asm volatile("" : : : "a0", "a255", "v192", "v255");
+    asm volatile("" : : : "a0", "a255", "v124", "v255");
 #endif
     const int nwg = p.tiles_m * p.tiles_n;
     const int nstages = p.K >> 6;
@@ -267,13 +281,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
     c.lds = smem;
 #endif
     {
-        const int ra = wm * 128 + (lane & 31), rb = wn * 128 + (lane & 31);
+        // this lane's fragment chunk: row (lane & 15) of a 16-row block, 16-byte k chunk 4 kk + (lane >> 4) of the stage's 128-byte row, at the
+        // place the source-side swizzle put it (chunk ^ (row >> 1) & 7; the block's first row is a multiple of 16, so only the lane enters)
+        const int ra = wm * 128 + (lane & 15), rb = wn * 128 + (lane & 15);
+        const int sw = (lane & 15) >> 1, q = lane >> 4;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                c.pa[g][ks] = c.lds0 + (uint32_t)(g * 2 * OW_UNIT + ra * 128 + ((((2 * ks) | h) ^ ((ra >> 1) & 7)) << 4));
-                c.pb[g][ks] = c.lds0 + (uint32_t)(g * 2 * OW_UNIT + rb * 128 + ((((2 * ks) | h) ^ ((rb >> 1) & 7)) << 4));
+                c.pa[g][kk] = c.lds0 + (uint32_t)(g * 2 * OW_UNIT + ra * 128 + ((((4 * kk) | q) ^ sw) << 4));
+                c.pb[g][kk] = c.lds0 + (uint32_t)(g * 2 * OW_UNIT + rb * 128 + ((((4 * kk) | q) ^ sw) << 4));
             }
         }
     }
@@ -339,72 +356,60 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
     set_sources(m0, n0);
     bool fresh = true;                // this tile's A_0 / B_0 are still to be requested (the first tile of the workgroup)
     for (;;) {
-    // prologue: A_0 B_0 (a later tile finds them requested by the previous tile's epilogue), then A_1 and the first half of B_1 (unit 2 j + (B ? 1 : 0) lives in buffer unit % 5) -- what stage 0 would
-    // find requested by a stage "-1"; everything else rides in stage 0's k-steps like in any other stage.  (All five units up front
-    // cost 160 requests of the CU's memory front end before the first MFMA: 30 % more prologue for nothing.)
+    // prologue: A_0 B_0 (a later tile finds them requested by the previous tile's epilogue), then A_1 and B_1 (unit 2 j + (B ? 1 : 0) lives in
+    // buffer unit % 5) -- what stage 0 would find requested by the stages "-2" and "-1"; A_2 rides in stage 0 like in any other stage.
     if (fresh) {
         request(abase, voa, integral_constant<int, 0>{});
         request(bbase, vob, integral_constant<int, 1>{});
     }
     if (nstages > 1) {
         request(abase, voa, integral_constant<int, 2>{});
-        ow_dma<3 * OW_UNIT + 0 * 1024>(bbase, vob[0], piece0, c); ow_dma<3 * OW_UNIT + 1 * 1024>(bbase, vob[1], piece0, c);
-        ow_dma<3 * OW_UNIT + 2 * 1024>(bbase, vob[2], piece0, c); ow_dma<3 * OW_UNIT + 3 * 1024>(bbase, vob[3], piece0, c);
-        ow_wait_vm<12>();             // stage 0 has landed (this wave's share): A_1 and half of B_1 may fly
+        request(bbase, vob, integral_constant<int, 3>{});
+        ow_wait_vm<16>();             // stage 0 has landed (this wave's share): A_1 and B_1 may fly
     } else {
         ow_wait_vm<0>();
     }
     ow_barrier();
-    {
+    {                                 // fragment set 0 <- k32 half 0 of stage 0
         const uint32_t la = c.pa[0][0], lb = c.pb[0][0];
         ow_read<0, 0, false>(c, la); ow_read<0, 1, false>(c, la); ow_read<0, 2, false>(c, la); ow_read<0, 3, false>(c, la);
+        ow_read<0, 4, false>(c, la); ow_read<0, 5, false>(c, la); ow_read<0, 6, false>(c, la); ow_read<0, 7, false>(c, la);
         ow_read<0, 0, true, OW_UNIT>(c, lb); ow_read<0, 1, true, OW_UNIT>(c, lb); ow_read<0, 2, true, OW_UNIT>(c, lb); ow_read<0, 3, true, OW_UNIT>(c, lb);
+        ow_read<0, 4, true, OW_UNIT>(c, lb); ow_read<0, 5, true, OW_UNIT>(c, lb); ow_read<0, 6, true, OW_UNIT>(c, lb); ow_read<0, 7, true, OW_UNIT>(c, lb);
     }
     const float* bias_src = p.bias != nullptr ? p.bias + n0 + 4 * lane : nullptr;
     const uint32_t bias_dst = c.lds0 + (uint32_t)(OW_EPI0 + OW_BIAS0 + lane * 16);
     ow_bias_load(c, bias_src);
     OW_TICK(10);                      // (prologue)
-    // Stage j = four k-steps.  k-step s multiplies the fragments of set s & 1 and reads those of the next k-step (the next stage's
-    // first one behind the stage's barrier; the last stage reads the ring's next buffers there: stale bytes nobody multiplies).
-    // The barrier b_j stands between k-steps 2 and 3: in front of it every wave has read its last fragments of stage j
-    // (lgkmcnt(0)) and has seen its pieces of stage j + 1 land (vmcnt(8): only A_{j+2}, requested last, may fly), so behind it
-    // stage j + 1 may be read and stage j's two buffers refilled, four requests per k-step (the memory front end takes a request
-    // per ~30 cycles and CU: a burst of 8 per wave parks the waves in its queue, measured +100 cycles per stage):
-    //   k-step 3 of stage j:           first half of B_{j+2} -> A_j's buffer
-    //   k-step 0 of stage j+1:         second half of B_{j+2}
-    //   k-steps 1, 2 of stage j+1:     A_{j+3} -> B_j's buffer
-    // i.e. a request has at least 2.5 k-steps to land.  Stage 0 is a stage like any other (its first MFMAs take C = 0).
-    // The stage loop is unrolled over the ring's period (PH = j % 5): buffer addresses are constants, the per-stage scalar work is
-    // a counter and two compares -- with one wave per SIMD every scalar instruction in front of an MFMA is a bubble in the pipe.
-    // KIND 2: the units A_{j+2}, B_{j+2} exist (j + 2 < nstages); 1: the last stage but one (B_{j+1}'s second half is still to be
-    // requested); 0: the last stage.  The last two stages wait for everything in front of their barrier.
+    // Stage j = two k32 halves of 64 MFMAs.  Half 0 multiplies fragment set 0 (read during the previous stage's half 1) and reads set 1 =
+    // the stage's second k32 half; half 1 multiplies set 1 and reads set 0 = the NEXT stage's first half (the last stage reads the ring's next
+    // buffers there: stale bytes nobody multiplies).  The stage's one barrier b_j stands BETWEEN the halves: in front of it every wave has read
+    // its last fragments of stage j (the reads ride in the first 46 slots of half 0; lgkmcnt(0)) and has seen its pieces of stage j + 1 land
+    // (vmcnt(8): only A_{j+2}, requested last, may fly), so behind it stage j + 1 may be read and stage j's two buffers refilled.  Requests, four
+    // per 32-slot quarter (the memory front end takes a request per ~30 cycles and CU):
+    //   half 0 of stage j:   A_{j+2} -> B_{j-1}'s buffer (free since b_{j-1})
+    //   half 1 of stage j:   B_{j+2} -> A_j's buffer (free since b_j)
+    // i.e. a request has at least a half stage (A: a whole one) to land.  Stage 0 is a stage like any other (its first half's MFMAs take C = 0).
+    // The stage loop is unrolled over the ring's period (PH = j % 5): buffer addresses are constants, the per-stage scalar work is a counter and
+    // two compares.  KIND 2: the units A_{j+2}, B_{j+2} exist (j + 2 < nstages); 0: the last two stages (no requests; they wait for everything).
     auto stage_body = [&](auto ph_tag, auto first_tag, auto kind_tag) {
         constexpr int PH = decltype(ph_tag)::value, KIND = decltype(kind_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int ABUF = (2 * PH) % 5, BBUF = (2 * PH + 1) % 5, ABUF_N = (2 * PH + 2) % 5, BBUF_N = (2 * PH + 3) % 5;
         constexpr int BBUF_P = (2 * PH + 4) % 5;             // B_{j-1}'s buffer
+        constexpr int ND = KIND == 2 ? 4 : 0;
         OW_TICK(0);
-        ow_wait_lds();
+        ow_wait_lds();                // set 0 is in the registers
         OW_TICK(1);
-        // B_{j+1}'s second half -> A_{j-1}'s buffer (= B_{j+1}'s), then A_{j+2} -> B_{j-1}'s buffer in k-steps 1 and 2, B_{j+2}'s first half
-        // -> A_j's buffer in k-step 3
-        ow_step<0, FIRST, (KIND >= 1 ? 4 : 0), 4, ABUF, BBUF, 1, BBUF_N>(c, bbase, vob, piece0);
+        ow_half<0, FIRST, ABUF, BBUF, 1, ND, 0, BBUF_P, 4, BBUF_P>(c, abase, voa, abase, voa, piece0);
         OW_TICK(2);
-        ow_wait_lds();
+        ow_wait_lds();                // set 1 is in the registers (its reads are >= 16 slots old)
         OW_TICK(3);
-        ow_step<1, false, (KIND == 2 ? 4 : 0), 0, ABUF, BBUF, 2, BBUF_P>(c, abase, voa, piece0);
-        OW_TICK(4);
-        ow_wait_lds();
-        OW_TICK(5);
-        ow_step<2, false, (KIND == 2 ? 4 : 0), 4, ABUF, BBUF, 3, BBUF_P>(c, abase, voa, piece0);
-        OW_TICK(6);
-        ow_wait_lds();
-        OW_TICK(7);
         ow_wait_vm<(KIND == 2 ? 8 : 0)>();
         OW_TICK(8);
         ow_barrier();                 // b_j
         OW_TICK(9);
-        ow_step<3, false, (KIND == 2 ? 4 : 0), 0, ABUF_N, BBUF_N, 0, ABUF>(c, bbase, vob, piece0);
+        ow_half<1, false, ABUF_N, BBUF_N, 0, ND, 0, ABUF, 4, ABUF>(c, bbase, vob, bbase, vob, piece0);
     };
     // stages [j, jend) starting at ring phase ph (= j % 5), all of one kind; steady state: a counter, a compare, a branch not taken
     auto run = [&](auto kind_tag, int& j, int jend, int& ph) {
@@ -420,15 +425,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256o_kernel(Gemm256Params p) {
     };
     {
         if (nstages > 2) stage_body(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, 2>{});
-        else if (nstages > 1) stage_body(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, 1>{});
         else stage_body(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, 0>{});
         int j = 1, ph = 1;
         run(integral_constant<int, 2>{}, j, nstages - 2, ph);
-        run(integral_constant<int, 1>{}, j, nstages - 1, ph);
         run(integral_constant<int, 0>{}, j, nstages, ph);
     }
 
-    OW_TICK(0);                       // (the last k-step 3 counts as "step 3" = slot 0 of the next stage)
+    OW_TICK(0);                       // (the last half 1 counts as slot 0 of the next stage)
     ow_wait_vm<0>();
     ow_wait_lds();
     ow_barrier();                     // the ring is drained and read: LDS becomes the C staging area
@@ -516,16 +519,14 @@ int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream) {
         }
     }
     p.panel_w = pw > 0 && pw < p.tiles_n ? pw : 0;
-    // plain bf16 outputs on complete tile rows: the kernel that stores the C tile from inside the next tile's main loop (gemm_nt_owd.hip;
-    // MAEST_OPT_GEMM_DEFER = 0 keeps this file's kernel: A/B, tests)
-    if (option(MAEST_OPT_GEMM_DEFER) != 0 && gemm_nt256d_available() && gemm_nt256d_takes(p)) return gemm_nt256d_launch(p, stream);
     if (gelu && p.aux_out == nullptr && p.out_dtype == MAEST_SPLIT3_A) return launch256o<2, 4, 0>(p, stream);
+    // (16-bit outputs only: the fp32-output forms -- the patch embedding once per step, the RESIDUAL form of MAEST_SPLIT_ADD = 0 -- stay with the
+    // eight-wave kernel; with 128 fragment registers owned here their epilogues spilled, round 6)
     if (gelu && p.aux_out != nullptr && bf) return launch256o<2, 3, 0>(p, stream);
-    if (p.epi == MAEST_EPI_RESIDUAL && !bf) return launch256o<4, 0, 1>(p, stream);
-    if (p.epi == MAEST_EPI_MUL) return bf ? launch256o<2, 0, 2>(p, stream) : launch256o<4, 0, 2>(p, stream);
-    if (gelu && p.aux_out == nullptr) return bf ? launch256o<2, 1, 0>(p, stream) : launch256o<4, 1, 0>(p, stream);
-    if (p.epi == MAEST_EPI_ROWDOT) return bf ? launch256o<2, 0, 3>(p, stream) : launch256o<4, 0, 3>(p, stream);
-    if (p.epi == MAEST_EPI_NONE) return bf ? launch256o<2, 0, 0>(p, stream) : launch256o<4, 0, 0>(p, stream);
+    if (p.epi == MAEST_EPI_MUL && bf) return launch256o<2, 0, 2>(p, stream);
+    if (gelu && p.aux_out == nullptr && bf) return launch256o<2, 1, 0>(p, stream);
+    if (p.epi == MAEST_EPI_ROWDOT && bf) return launch256o<2, 0, 3>(p, stream);
+    if (p.epi == MAEST_EPI_NONE && bf) return launch256o<2, 0, 0>(p, stream);
     set_error("maest_gemm_nt(256o): epilogue %d with output dtype %d is not served by this kernel", p.epi, p.out_dtype);
     return MAEST_ERR_INVALID;
 }

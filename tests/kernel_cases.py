@@ -76,7 +76,26 @@ def case_gemm(dev, dtype, M, N, K, seed=0, identity=True):
     close(acc, ref - bias, rt, at * math.sqrt(K / 64), "gemm split-k")
 
 
-def case_gemm_one_wave_per_simd(dev, M, N, K, seed=11, only=None, pair=True, both_bias=False, defer_ab=False):
+def _same_products(new, old, exact, what, K=64):
+    """The one-wave-per-SIMD GEMM against the 8-wave kernel on the same operands.  `exact` (the host emulator, whose MFMA twins add the k terms
+    one by one in both shapes): bit for bit.  On the device the two kernels use different matrix instructions since round 6 (16x16x32 against
+    32x32x16: 32 against 16 products per rounding step), so their fp32 sums differ in the last bits: fp32 outputs within 4e-7 sqrt(K) of the output
+    scale, bf16 outputs within one bf16 ulp and at most 2 % of the elements different at all."""
+    if exact:
+        assert torch.equal(new, old), what
+        return
+    a, b = new.float(), old.float()
+    scale = float(b.abs().max()) + 1e-30
+    diff = (a - b).abs()
+    if new.dtype == torch.float32:
+        assert float(diff.max()) <= 4e-7 * math.sqrt(K) * scale + 1e-30, f"{what}: max |diff| {float(diff.max()):.3e} of scale {scale:.3e}"
+    else:
+        ulp = 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-30          # one bf16 ulp is 2^-8 .. 2^-7 of the value
+        assert bool((diff <= ulp).all()), f"{what}: more than one bf16 ulp apart (max ratio {float((diff / ulp).max()):.2f})"
+        assert float((diff > 0).float().mean()) <= 0.02, f"{what}: {100 * float((diff > 0).float().mean()):.2f} % of the elements differ"
+
+
+def case_gemm_one_wave_per_simd(dev, M, N, K, seed=11, only=None, pair=True, both_bias=False):
     """gemm_nt256o_kernel (gemm_nt_ow.hip: bf16 operands, the default of the 256 x 256 path) against the 8-wave kernel it replaces
     (gemm_variant = 3): the same products summed in the same order and the same epilogue arithmetic -- bit for bit, in every
     epilogue form, ragged last tile row included -- and against the oracle's fp32 matmul."""
@@ -98,11 +117,7 @@ def case_gemm_one_wave_per_simd(dev, M, N, K, seed=11, only=None, pair=True, bot
             new = ops.gemm_nt(a, w, b, **kw)
             with ops.options(gemm_variant=3):
                 old = ops.gemm_nt(a, w, b, **kw)
-            assert torch.equal(new, old), f"one-wave-per-SIMD GEMM differs from the 8-wave kernel: {name}, bias {b is not None}"
-            if defer_ab:        # (plain bf16 outputs on complete tile rows take gemm_nt256d_kernel by default: the same call on gemm_nt256o_kernel)
-                with ops.options(gemm_defer=0):
-                    other = ops.gemm_nt(a, w, b, **kw)
-                assert torch.equal(new, other), f"deferred-store kernel differs from gemm_nt256o_kernel: {name}, bias {b is not None}"
+            _same_products(new, old, str(dev) == "cpu", f"one-wave-per-SIMD GEMM differs from the 8-wave kernel: {name}, bias {b is not None}", K)
     c = ops.gemm_nt(a, w, bias, out_dtype=torch.float32)
     close(c, ref, 1e-5, 4e-7 * K, "one-wave-per-SIMD GEMM vs fp32 matmul")
     if not pair:
@@ -112,7 +127,8 @@ def case_gemm_one_wave_per_simd(dev, M, N, K, seed=11, only=None, pair=True, bot
     g_n = ops.gemm_nt(a, w, bias, out_dtype=dt, epi=ops.EPI_GELU, aux_out=aux_n)
     with ops.options(gemm_variant=3):
         g_o = ops.gemm_nt(a, w, bias, out_dtype=dt, epi=ops.EPI_GELU, aux_out=aux_o)
-    assert torch.equal(g_n, g_o) and torch.equal(aux_n, aux_o), "GELU + GELU' pair differs between the two 256 x 256 kernels"
+    _same_products(g_n, g_o, str(dev) == "cpu", "GELU of the pair form differs between the two 256 x 256 kernels", K)
+    _same_products(aux_n, aux_o, str(dev) == "cpu", "GELU' of the pair form differs between the two 256 x 256 kernels", K)
     close(g_n, F.gelu(ref), 1e-2, 1e-2 * math.sqrt(K / 64), "one-wave-per-SIMD GEMM: gelu")
 
 
@@ -136,7 +152,8 @@ def case_gemm_rowdot(dev, dtype, M, N, K, ntok, seed=7):
         # same arithmetic in the same order
         with ops.options(gemm_variant=3):
             c3, rd3 = ops.gemm_nt_rowdot(a.to(dev), b.to(dev), other.to(dev), ntok, out_dtype=dtype, bias=bias.to(dev))
-        assert torch.equal(c, c3) and torch.equal(rd, rd3), "row-dot epilogue: one-wave-per-SIMD and 8-wave kernels differ"
+        _same_products(c, c3, str(dev) == "cpu", "row-dot epilogue: C differs between the one-wave-per-SIMD and 8-wave kernels", K)
+        close(rd, rd3, 1e-2, 1e-2 * math.sqrt(64) * float(c.float().abs().max()) * 2.0 ** -7, "row-dot epilogue: dot products of the two kernels")
 
 
 def case_gemm_tn(dev, dtype, K, M, N, seed=3, lda_pad=0, splits=(1, 3, 0)):

@@ -331,7 +331,7 @@ def test_failed_register_audit_leaves_the_kernel_out_instead_of_failing_the_buil
         B.audit_or_leave_out("gemm_nt_ow.hip", str(tmp_path / "x.o"), verbose=False)
     # and the product build has all three
     if os.path.exists(_lib.LIB_PATH):
-        assert _lib.kernel_forms() == _lib.FORM_GEMM_NT_OW | _lib.FORM_GEMM_TN_OW | _lib.FORM_ATTN_FWD_PW | _lib.FORM_GEMM_NT_OWD
+        assert _lib.kernel_forms() == _lib.FORM_GEMM_NT_OW | _lib.FORM_GEMM_TN_OW | _lib.FORM_ATTN_FWD_PW
 
 
 def test_run_ahead_bound_is_host_logic():

@@ -72,17 +72,6 @@ def test_emu_gemm_one_wave_per_simd_kernel(emu, gemm_options):
     KC.case_gemm_one_wave_per_simd(emu, 512, 768, 64, only=("none -> bf16",), pair=False)
 
 
-def test_emu_gemm_deferred_store_kernel(emu, gemm_options):
-    """gemm_nt256d_kernel's host twin (gemm_nt_owd.hip: plain bf16 outputs on complete tile rows; the C tile packed to bf16 registers at the
-    end of its K loop and stored from inside the next tile's stages 0 .. 3): 6 and 7 K stages, with and without bias, one workgroup per
-    tile (pack + immediate stores) and ONE workgroup walking three tiles (deferred stores, the bias registers aliasing the packed tile's
-    last four) -- bit for bit against the 8-wave kernel, and against gemm_nt256o_kernel (gemm_defer = 0)"""
-    gemm_options(gemm_min_m=512, gemm_tail=0)
-    KC.case_gemm_one_wave_per_simd(emu, 512, 256, 384, only=("none -> bf16",), pair=False, both_bias=True)
-    gemm_options(gemm_wgs=1)
-    KC.case_gemm_one_wave_per_simd(emu, 768, 256, 448, only=("none -> bf16",), pair=False, both_bias=True, defer_ab=True)
-
-
 @pytest.mark.parametrize("dtype", DT_BIG)
 def test_emu_gemm_128_row_tiles_of_the_last_partial_round(emu, dtype, gemm_options):
     """gemm_nt256w_kernel<MTW = 2>: 128 x 256 tiles (A units of 128 rows in the same ring, vmcnt(2) waits, one-pass

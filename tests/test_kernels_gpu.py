@@ -73,24 +73,6 @@ def test_gemm_column_panels_chosen_for_the_wide_shapes(gemm_options):
         gemm_options(gemm_panel=-1)
 
 
-@pytest.mark.parametrize("wgs", [0, 1, 8, 24, 256])
-@pytest.mark.parametrize("shape", [(2560, 768, 768), (8448, 2304, 384), (5120, 768, 3072), (33 * 256, 256, 448)])
-def test_gemm_deferred_store_kernel(shape, wgs, gemm_options):
-    """gemm_nt256d_kernel (gemm_nt_owd.hip: plain bf16 outputs on complete tile rows, the default for them) with 10 .. 297 tiles on one
-    workgroup per tile / 1 / 8 / 24 / 256 persistent workgroups, 6 .. 48 K stages, with and without bias: bit for bit against the 8-wave
-    kernel and against gemm_nt256o_kernel (gemm_defer = 0)"""
-    gemm_options(gemm_min_m=512, gemm_tail=0, gemm_wgs=wgs)
-    KC.case_gemm_one_wave_per_simd(DEV, *shape, only=("none -> bf16",), pair=False, both_bias=True, defer_ab=True)
-
-
-def test_gemm_deferred_store_kernel_production_shapes(gemm_options):
-    """the shapes the model gives it, as the engine launches them (256 persistent workgroups, no tail launch): qkv / proj / fc2 of the
-    training and inference steps"""
-    gemm_options(gemm_wgs=256, gemm_tail=0)
-    for M, N, K in ((74240, 2304, 768), (74240, 768, 768), (74240, 768, 3072), (143360, 768, 768), (112000, 768, 2304)):
-        KC.case_gemm_one_wave_per_simd(DEV, M, N, K, only=("none -> bf16",), pair=False, both_bias=True, defer_ab=True)
-
-
 def test_gemm_eight_wave_kernel_still_serves_bf16(gemm_options):
     """gemm_variant = 3: gemm_nt256w_kernel<bf16> (the A/B reference of the kernel above) against the oracle on its own"""
     gemm_options(gemm_min_m=512, gemm_variant=3)
