@@ -419,7 +419,7 @@ def flop_counts(case, precision):
     tail_on = bool(getattr(net._engine, "head_tail", False))
     # (training at shapes the fused attention backward does not serve keeps the last block's attention complete)
     attn_rows = min(32, N) if (not train or ops.attn_bwd_rows_supported(
-        torch.bfloat16 if precision == "bf16" else torch.float32, N)) else N
+        torch.bfloat16 if precision in ("bf16", "fp16") else torch.float32, N)) else N
     skipped = (3 if train else 1) * flops_per_clip_fwd_not_executed(N, attn_rows) * B if tail_on else 0
     return step_flops, skipped, attn_rows, tail_on
 
@@ -434,12 +434,12 @@ def kernel_report(case, timer, steps, precision, with_traffic, live_traffic=None
     if g and g["ms"] > 0:
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12
         # bf16x3 spends 3 bf16 MFMAs per product: its algorithmic rate is priced against a third of the bf16 peak
-        peak = {"bf16": PEAK_BF16_TFLOPS, "bf16x3": round(PEAK_BF16_TFLOPS / 3, 1)}.get(precision, 157.3)
+        peak = {"bf16": PEAK_BF16_TFLOPS, "fp16": PEAK_BF16_TFLOPS, "bf16x3": round(PEAK_BF16_TFLOPS / 3, 1)}.get(precision, 157.3)
         from maest_amd import _lib as _L
         ow = bool(_L.kernel_forms() & _L.FORM_GEMM_NT_OW)      # (False: a build whose register audit failed keeps the eight-wave kernel)
         out["roofline"] = {"bound": "mfma", "kernel": (("maest_gemm_nt (gemm_nt256o_kernel, bf16, one wave per SIMD -- plus gemm_nt256w_kernel<bf16, 2> for the 128-row tail tiles: every token-major GEMM of the blocks; the head and the last block's head-token rows, M <= 512, run gemm_nt_kernel and are listed as maest_gemm_nt_small)"
                                                        if ow else "maest_gemm_nt (gemm_nt256w_kernel<bf16>, eight waves: this build left the one-wave-per-SIMD kernel out -- maest_kernel_forms())")
-                                                      if precision == "bf16" else
+                                                      if precision in ("bf16", "fp16") else
                                                       ("maest_gemm_nt (3 bf16 MFMAs per fp32 product: all four linears of a block as ONE bf16 GEMM over 3 K on gemm_nt256o_kernel -- "
                                                        "split operand rows, MAEST_SPLIT3_A x MAEST_SPLIT3_B --, the last block's head rows on gemm_nt256w_kernel<float, X3>; "
                                                        "algorithmic flops 2 M N K)"
@@ -618,8 +618,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 for the 10 s configs, 128 for ts)")
     ap.add_argument("--frames", type=int, default=None, help="mel frames per clip (10 s @ 16 kHz -> 626; 30 s -> 1876)")
     ap.add_argument("--patchout", type=int, default=None)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"],
-                    help="bf16: perf mode (the headline number); fp32: exact-fp32 MFMA parity mode; bf16x3: split-bf16 parity mode")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "fp16"],
+                    help="bf16: perf mode (the headline number); fp32: exact-fp32 MFMA parity mode; bf16x3: split-bf16 parity mode; "
+                         "fp16: the perf mode's kernels on IEEE-half operands (evaluation forwards only: --mode infer)")
     ap.add_argument("--mode", default="train", choices=["train", "infer", "ts"],
                     help="train: BASELINE configs[2] (the headline metric); infer: configs[1]; ts: configs[4] "
                          "(teacher-student, waveform -> HIP log-mel on the fly -> mixup -> 519-way separated heads, 30 s)")
@@ -790,6 +791,13 @@ def main():
                                                 "model.eval()(x) takes by default)", precision="bf16x3")
             except Exception as e:  # pragma: no cover
                 out["infer_parity"] = {"error": repr(e)}
+            try:
+                out["infer_fp16"] = side_case(args, dev, "infer", 626, 256, 0, max(args.steps, 20), 3,
+                                              "configs[1] in precision \"fp16\": the perf mode's kernels and schedules on IEEE-half operands "
+                                              "(libmaest_hip_f16.so) -- the fast path INSIDE north_star's 1e-3 logits gate (`deviation_vs_fp32`)",
+                                              precision="fp16")
+            except Exception as e:  # pragma: no cover
+                out["infer_fp16"] = {"error": repr(e)}
             try:
                 out["ts"] = side_case(args, dev, "ts", 1876, 128, 90, 10, 2,
                                       "discogs-maest-30s-pw-73e-ts teacher-student training step (BASELINE configs[4], per-GPU "

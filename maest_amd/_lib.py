@@ -75,7 +75,34 @@ OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3
            "tn_reduce": 8, "gemm_wgs": 9, "gemm_panel": 10}
 
 _lib = None
+_lib_f16 = None
 _host_emulation = False  # set only by tests/emu
+# The library's second build: the same sources with IEEE half as the 16-bit operand type (csrc/common.h: MAEST_16BIT_F16).  A thread selects it
+# for the calls it makes inside `with flavour("f16"):` (maest.py: precision="fp16" evaluation forwards); tensors keep the bf16 dtype TAG -- a
+# 16-bit container whose bits the kernels of the selected build interpret.
+LIB_PATH_F16 = os.environ.get("MAEST_HIP_LIB_F16") or os.path.join(_HERE, "libmaest_hip_f16.so")
+import threading as _threading
+_tls = _threading.local()
+
+
+class flavour:
+    """``with _lib.flavour("f16"): ...`` -- C-ABI calls of this thread go to libmaest_hip_f16.so inside the block."""
+
+    def __init__(self, name):
+        assert name in ("bf16", "f16")
+        self.name = name
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "flavour", "bf16")
+        _tls.flavour = self.name
+        return self
+
+    def __exit__(self, *a):
+        _tls.flavour = self.prev
+
+
+def current_flavour():
+    return getattr(_tls, "flavour", "bf16")
 
 
 class MaestHipError(RuntimeError):
@@ -95,8 +122,17 @@ def _bind(lib):
 
 
 def load():
-    """Load (once) and return the bound library; raise loudly when it is absent."""
-    global _lib
+    """Load (once) and return the bound library -- the build the calling thread's flavour selects; raise loudly when it is absent."""
+    global _lib, _lib_f16
+    if getattr(_tls, "flavour", "bf16") == "f16" and not _host_emulation:
+        if _lib_f16 is None:
+            if not os.path.exists(LIB_PATH_F16):
+                raise MaestHipError(f"{LIB_PATH_F16} not found: precision=\"fp16\" needs the half-precision build of the kernels "
+                                    "(`python -c 'import __graft_entry__ as g; g.build()'` builds both).")
+            _lib_f16 = _bind(ctypes.CDLL(LIB_PATH_F16))
+            if _lib_f16.maest_version() != ABI_VERSION:
+                raise MaestHipError("libmaest_hip_f16.so ABI version mismatch")
+        return _lib_f16
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise MaestHipError(

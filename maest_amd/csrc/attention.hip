@@ -774,8 +774,8 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16
                     float d = 0.0f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        d += u2f(v[e] << 16) * u2f(f.o[k][e] << 16);
-                        d += u2f(v[e] & 0xffff0000u) * u2f(f.o[k][e] & 0xffff0000u);
+                        d += lo16f(v[e]) * lo16f(f.o[k][e]);
+                        d += hi16f(v[e]) * hi16f(f.o[k][e]);
                     }
                     d += __shfl_xor(d, 1, 64);
                     d += __shfl_xor(d, 2, 64);

@@ -298,7 +298,7 @@ __device__ __forceinline__ void pw_q_read(PwCtx& c, uint32_t addr) {
 __device__ __forceinline__ chunk16 pw_scale_chunk(const chunk16& raw, float c2) {
     chunk16 r;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = pack_bf2(u2f(raw[e] << 16) * c2, u2f(raw[e] & 0xffff0000u) * c2);
+    for (int e = 0; e < 4; ++e) r[e] = pack_bf2(lo16f(raw[e]) * c2, hi16f(raw[e]) * c2);
     return r;
 }
 
@@ -370,21 +370,21 @@ __device__ __forceinline__ void pw_s_mfma(PwCtx& c) {
     constexpr int KF = (SET ? PW_A_K2 : PW_A_K) + (4 * KB + J) * 4, Q = PW_A_Q + (4 * I + J) * 4, S = PW_V_S + (2 * BUF + KB) * 16, NM = PW_V_NM + 16 * I;
     if constexpr (J == 0 && TILE0) {
         if constexpr (K == 0)
-            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], 0" : : "i"(S), "i"(S + 15), "i"(KF), "i"(KF + 3), "i"(Q), "i"(Q + 3));
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_" MAEST_T16 " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], 0" : : "i"(S), "i"(S + 15), "i"(KF), "i"(KF + 3), "i"(Q), "i"(Q + 3));
         else
-            asm volatile("v_mfma_f32_32x32x16_bf16 v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], 0" : : "i"(S), "i"(S + 15), "i"(KF), "i"(KF + 3), "i"(Q), "i"(Q + 3));
+            asm volatile("v_mfma_f32_32x32x16_" MAEST_T16 " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], 0" : : "i"(S), "i"(S + 15), "i"(KF), "i"(KF + 3), "i"(Q), "i"(Q + 3));
     } else if constexpr (J == 0) {
         if constexpr (K == 0)
-            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]"
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_" MAEST_T16 " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]"
                          : : "i"(S), "i"(S + 15), "i"(KF), "i"(KF + 3), "i"(Q), "i"(Q + 3), "i"(NM), "i"(NM + 15));
         else
-            asm volatile("v_mfma_f32_32x32x16_bf16 v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]"
+            asm volatile("v_mfma_f32_32x32x16_" MAEST_T16 " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]"
                          : : "i"(S), "i"(S + 15), "i"(KF), "i"(KF + 3), "i"(Q), "i"(Q + 3), "i"(NM), "i"(NM + 15));
     } else if constexpr (K == 7 && (NOPS || PW_TAILNOP)) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]\n\ts_nop 7\n\ts_nop 3"
+        asm volatile("v_mfma_f32_32x32x16_" MAEST_T16 " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]\n\ts_nop 7\n\ts_nop 3"
                      : : "i"(S), "i"(S + 15), "i"(KF), "i"(KF + 3), "i"(Q), "i"(Q + 3));
     } else {
-        asm volatile("v_mfma_f32_32x32x16_bf16 v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]"
+        asm volatile("v_mfma_f32_32x32x16_" MAEST_T16 " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]"
                      : : "i"(S), "i"(S + 15), "i"(KF), "i"(KF + 3), "i"(Q), "i"(Q + 3));
     }
 #else
@@ -393,7 +393,7 @@ __device__ __forceinline__ void pw_s_mfma(PwCtx& c) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) cin[r] = TILE0 ? 0.0f : c.negm[I][r];
     }
-    c.s[BUF][KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, c.kf[SET][KB][J]), __builtin_bit_cast(bf16x8_t, c.qf[I][J]), cin, 0, 0, 0);
+    c.s[BUF][KB] = MAEST_MFMA_32X32X16(__builtin_bit_cast(bf16x8_t, c.kf[SET][KB][J]), __builtin_bit_cast(bf16x8_t, c.qf[I][J]), cin, 0, 0, 0);
 #endif
 }
 // One MFMA of O^T[d][q] += V^T[d][key] P^T[key][q] for query block I (K = 0 .. 7: key block K >> 2, k step (K >> 1) & 1, d block
@@ -406,20 +406,20 @@ __device__ __forceinline__ void pw_pv_mfma(PwCtx& c) {
     if (PW_ABLATE & 8) return;
     constexpr int O = PW_A_O + (2 * I + DB) * 16, V = PW_A_V + ((2 * KB + DB) * 2 + S2) * 4, P = PW_V_PK + ((2 * BUF + KB) * 2 + S2) * 4;
     if constexpr (TILE0 && FIRSTOF && K == 0)
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], 0" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_" MAEST_T16 " a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], 0" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
     else if constexpr (TILE0 && FIRSTOF)
-        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], 0" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
+        asm volatile("v_mfma_f32_32x32x16_" MAEST_T16 " a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], 0" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
     else if constexpr (K == 0)
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_" MAEST_T16 " a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
     else
-        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
+        asm volatile("v_mfma_f32_32x32x16_" MAEST_T16 " a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" : : "i"(O), "i"(O + 15), "i"(V), "i"(V + 3), "i"(P), "i"(P + 3));
 #else
     f32x16_t cin = c.o[I][DB];
     if (TILE0 && FIRSTOF) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) cin[r] = 0.0f;
     }
-    c.o[I][DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, c.vf[KB][DB][S2]), __builtin_bit_cast(bf16x8_t, c.pk[BUF][KB][S2]), cin, 0, 0, 0);
+    c.o[I][DB] = MAEST_MFMA_32X32X16(__builtin_bit_cast(bf16x8_t, c.vf[KB][DB][S2]), __builtin_bit_cast(bf16x8_t, c.pk[BUF][KB][S2]), cin, 0, 0, 0);
 #endif
 }
 template <int I, int BUF, bool TILE0, int... K>
@@ -492,15 +492,15 @@ __device__ __forceinline__ void pw_sm_fin(PwCtx& c) {
     if (PW_ABLATE & (4 | 512)) return;
     constexpr int P = PW_V_PK + ((2 * BUF + KB) * 2 + (R >> 3)) * 4 + ((R & 7) >> 1), T0 = PW_V_T + 4 * (K & 1), A0 = PW_V_T + 2;
     if constexpr (PW_SUM == 1)
-        asm volatile("v_cvt_pk_bf16_f32 v%c4, v%c0, v%c1\n\tv_dot2c_f32_bf16 v%c2, v%c4, v%c3"
+        asm volatile("v_cvt_pk_" MAEST_T16 "_f32 v%c4, v%c0, v%c1\n\tv_dot2c_f32_" MAEST_T16 " v%c2, v%c4, v%c3"
                      : : "i"(T0), "i"(T0 + 1), "i"(A0), "i"(A0 + 1), "i"(P));
     else
-        asm volatile("v_add_f32 v%c2, v%c2, v%c0\n\tv_add_f32 v%c3, v%c3, v%c1\n\tv_cvt_pk_bf16_f32 v%c4, v%c0, v%c1"
+        asm volatile("v_add_f32 v%c2, v%c2, v%c0\n\tv_add_f32 v%c3, v%c3, v%c1\n\tv_cvt_pk_" MAEST_T16 "_f32 v%c4, v%c0, v%c1"
                      : : "i"(T0), "i"(T0 + 1), "i"(A0), "i"(A0 + 1), "i"(P));
 #else
     const uint32_t w = pack_bf2(c.t[K & 1][0], c.t[K & 1][1]);
     c.pk[BUF][KB][R >> 3][(R & 7) >> 1] = w;
-    c.a0 += PW_SUM == 1 ? u2f(w << 16) + u2f(w & 0xffff0000u) : c.t[K & 1][0] + c.t[K & 1][1];
+    c.a0 += PW_SUM == 1 ? lo16f(w) + hi16f(w) : c.t[K & 1][0] + c.t[K & 1][1];
 #endif
 }
 // a whole unit, outside the pipeline (the rescale path): exp(0) | exp(1) fin(0) | ... | fin(15)

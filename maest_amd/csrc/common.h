@@ -10,21 +10,47 @@
 namespace maest {
 
 // ------------------------------------------------------------------ element types
-typedef uint16_t bf16_t;  // raw bfloat16 bits; all conversions are explicit integer ops
+typedef uint16_t bf16_t;  // raw 16-bit operand bits; all conversions are explicit
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+// THE 16-BIT FLAVOUR.  The library is built twice from these sources (maest_amd/build.py): libmaest_hip.so, in which the 16-bit operand type
+// (dtype code MAEST_BF16, `bf16_t` here) is bfloat16 -- the training mode --, and libmaest_hip_f16.so (-DMAEST_16BIT_F16), in which the same code
+// paths run on IEEE half: v_mfma_*_f16, v_cvt_pk_f16_f32, the same layouts and schedules.  fp16 has 11 significand bits against 8: logits
+// 6e-4 .. 8e-4 from fp32 where bf16 is at 5e-3 .. 8e-3 (scratch/fp16_operand_sim.py, confirmed on the GPU), i.e. INSIDE north_star's 1e-3, at the
+// bf16 kernels' speed -- and it is the reference's own GPU arithmetic (precision="16-mixed", ex_maest.py:51).  Evaluation forwards only
+// (precision="fp16"): gradients in half need loss scaling, the training path stays bf16.  Everything that interprets the 16 bits goes through
+// the few definitions below (and MAEST_T16 in the asm mnemonics of gemm_nt_ow.h / attn_fwd_pw.hip).
+#ifdef MAEST_16BIT_F16
+#define MAEST_T16 "f16"
+typedef _Float16 native16_t;
+#define MAEST_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define MAEST_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
+#define MAEST_T16 "bf16"
+typedef __bf16 native16_t;
+#define MAEST_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define MAEST_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
+
+typedef __attribute__((ext_vector_type(8))) native16_t bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ float bf2f(bf16_t h) {
+#ifdef MAEST_16BIT_F16
+    return (float)__builtin_bit_cast(_Float16, h);
+#else
     uint32_t u = ((uint32_t)h) << 16;
     return __builtin_bit_cast(float, u);
+#endif
 }
+// the low / high 16-bit element of a packed pair as fp32
+__device__ __forceinline__ float lo16f(uint32_t w) { return bf2f((bf16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float hi16f(uint32_t w) { return bf2f((bf16_t)(w >> 16)); }
 // fp32 -> bf16, round-to-nearest-even: the gfx950 hardware conversion (v_cvt_pk_bf16_f32).  The integer
 // emulation this replaces compiled to ~8 VALU ops and an exec-mask branch PER VALUE, which made every
 // bf16 epilogue and the attention probability tiles VALU-bound.
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) native16_t bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
@@ -74,7 +100,7 @@ __device__ __forceinline__ void mma_chunk(f32x16_t& acc, const chunk16& a, const
 
 template <>
 __device__ __forceinline__ void mma_chunk<bf16_t>(f32x16_t& acc, const chunk16& a, const chunk16& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+    acc = MAEST_MFMA_32X32X16(__builtin_bit_cast(bf16x8_t, a),
                                                   __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 template <>
@@ -100,7 +126,7 @@ __device__ __forceinline__ void split_bf16x8(const chunk16& c0, const chunk16& c
         for (int e = 0; e < 2; ++e) {
             const float x0 = u2f(c[2 * e]), x1 = u2f(c[2 * e + 1]);
             const uint32_t hb = pack_bf2(x0, x1);
-            const float r0 = x0 - u2f(hb << 16), r1 = x1 - u2f(hb & 0xffff0000u);   // exact in fp32
+            const float r0 = x0 - lo16f(hb), r1 = x1 - hi16f(hb);   // exact in fp32
             h[2 * j + e] = hb;
             l[2 * j + e] = pack_bf2(r0, r1);
         }
@@ -111,7 +137,7 @@ __device__ __forceinline__ void split_bf16x8(const chunk16& c0, const chunk16& c
 // (a, b) -> the packed bf16 pair of their hi parts and the pair of their lo parts (the split of split_bf16x8)
 __device__ __forceinline__ void split_bf2(float a, float b, uint32_t& hi, uint32_t& lo) {
     hi = pack_bf2(a, b);
-    lo = pack_bf2(a - u2f(hi << 16), b - u2f(hi & 0xffff0000u));
+    lo = pack_bf2(a - lo16f(hi), b - hi16f(hi));
 }
 template <typename T, bool X3>
 __device__ __forceinline__ void mma_chunk2(f32x16_t& acc, const chunk16& a0, const chunk16& a1, const chunk16& b0,
@@ -121,9 +147,9 @@ __device__ __forceinline__ void mma_chunk2(f32x16_t& acc, const chunk16& a0, con
         bf16x8_t ah, al, bh, bl;
         split_bf16x8(a0, a1, ah, al);
         split_bf16x8(b0, b1, bh, bl);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);     // small terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        acc = MAEST_MFMA_32X32X16(al, bh, acc, 0, 0, 0);     // small terms first
+        acc = MAEST_MFMA_32X32X16(ah, bl, acc, 0, 0, 0);
+        acc = MAEST_MFMA_32X32X16(ah, bh, acc, 0, 0, 0);
     } else {
         mma_chunk<T>(acc, a0, b0);
         mma_chunk<T>(acc, a1, b1);

@@ -150,7 +150,7 @@ __device__ __forceinline__ void drain256(const char* smem, void* dst, int64_t ld
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (OSZ == 4) d += u2f(v[e]) * u2f(r[e]);
-                else d += u2f(v[e] << 16) * u2f(r[e] << 16) + u2f(v[e] & 0xffff0000u) * u2f(r[e] & 0xffff0000u);
+                else d += lo16f(v[e]) * lo16f(r[e]) + hi16f(v[e]) * hi16f(r[e]);
             }
             constexpr int GL = 64 * OSZ / 16;          // lanes per 64-column group: 8 / 16
 #pragma unroll
@@ -1273,7 +1273,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTn256Params p) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const uint32_t w = fa[ks][a][e];
-                                if (C::ELT == 2) cs += u2f(w << 16) + u2f(w & 0xffff0000u);
+                                if (C::ELT == 2) cs += lo16f(w) + hi16f(w);
                                 else cs += u2f(w);
                             }
                     }

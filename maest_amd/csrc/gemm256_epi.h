@@ -55,8 +55,8 @@ __device__ __forceinline__ chunk16 apply_aux(chunk16 v, const chunk16& r) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t vw = v[e], rw = r[e];
-            const float lo = u2f(vw << 16) * u2f(rw << 16);
-            const float hi = u2f(vw & 0xffff0000u) * u2f(rw & 0xffff0000u);
+            const float lo = lo16f(vw) * lo16f(rw);
+            const float hi = hi16f(vw) * hi16f(rw);
             v[e] = pack_bf2(lo, hi);
         }
     }
@@ -138,8 +138,8 @@ __device__ __forceinline__ void drainT(const char* smem, int rows, void* dst, in
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t vw = v[e], rw = r[e];
-                    const float lo = u2f(vw << 16) * u2f(rw << 16);
-                    const float hi = u2f(vw & 0xffff0000u) * u2f(rw & 0xffff0000u);
+                    const float lo = lo16f(vw) * lo16f(rw);
+                    const float hi = hi16f(vw) * hi16f(rw);
                     v[e] = pack_bf2(lo, hi);
                 }
             }

@@ -74,15 +74,15 @@ struct OwCtx {
 
 // ---- the pieces of a slot, as assembler text (device) ...
 // MFMA of block (N16, M16) on fragment set SET: rows of the result block = output columns n (4 consecutive per lane), lane & 15 = row m
-#define OW_MFMA_ACC "v_mfma_f32_16x16x32_bf16 a[%c0:%c0+3], v[%c1:%c1+3], v[%c2:%c2+3], a[%c0:%c0+3]"
-#define OW_MFMA_ZERO "v_mfma_f32_16x16x32_bf16 a[%c0:%c0+3], v[%c1:%c1+3], v[%c2:%c2+3], 0"
+#define OW_MFMA_ACC "v_mfma_f32_16x16x32_" MAEST_T16 " a[%c0:%c0+3], v[%c1:%c1+3], v[%c2:%c2+3], a[%c0:%c0+3]"
+#define OW_MFMA_ZERO "v_mfma_f32_16x16x32_" MAEST_T16 " a[%c0:%c0+3], v[%c1:%c1+3], v[%c2:%c2+3], 0"
 
 // ... and as C++ (host emulator)
 template <int SET, int N16, int M16, bool ZERO>
 __device__ __forceinline__ void ow_mfma_twin(OwCtx& c) {
 #if !OW_DEV
     if (ZERO) c.acc[N16][M16] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-    c.acc[N16][M16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, c.fb[SET][N16]), __builtin_bit_cast(bf16x8_t, c.fa[SET][M16]),
+    c.acc[N16][M16] = MAEST_MFMA_16X16X32(__builtin_bit_cast(bf16x8_t, c.fb[SET][N16]), __builtin_bit_cast(bf16x8_t, c.fa[SET][M16]),
                                                               c.acc[N16][M16], 0, 0, 0);
 #endif
 }
@@ -141,10 +141,10 @@ __device__ __forceinline__ void ow_slot_dma(OwCtx& c, const char* base, uint32_t
         return;
     }
     if constexpr (ZERO)
-        asm volatile("s_add_u32 m0, %2, %c3\n\t" "v_mfma_f32_16x16x32_bf16 a[%c4:%c4+3], v[%c5:%c5+3], v[%c6:%c6+3], 0" "\n\tglobal_load_lds_dwordx4 %0, %1\n\tv_add_u32 %0, 0x80, %0"
+        asm volatile("s_add_u32 m0, %2, %c3\n\t" "v_mfma_f32_16x16x32_" MAEST_T16 " a[%c4:%c4+3], v[%c5:%c5+3], v[%c6:%c6+3], 0" "\n\tglobal_load_lds_dwordx4 %0, %1\n\tv_add_u32 %0, 0x80, %0"
                      : "+v"(voff) : "s"(base), "s"(lds), "i"(DST), "i"(D), "i"(B), "i"(A) : "memory", "scc", OW_FRAGS);
     else
-        asm volatile("s_add_u32 m0, %2, %c3\n\t" "v_mfma_f32_16x16x32_bf16 a[%c4:%c4+3], v[%c5:%c5+3], v[%c6:%c6+3], a[%c4:%c4+3]" "\n\tglobal_load_lds_dwordx4 %0, %1\n\tv_add_u32 %0, 0x80, %0"
+        asm volatile("s_add_u32 m0, %2, %c3\n\t" "v_mfma_f32_16x16x32_" MAEST_T16 " a[%c4:%c4+3], v[%c5:%c5+3], v[%c6:%c6+3], a[%c4:%c4+3]" "\n\tglobal_load_lds_dwordx4 %0, %1\n\tv_add_u32 %0, 0x80, %0"
                      : "+v"(voff) : "s"(base), "s"(lds), "i"(DST), "i"(D), "i"(B), "i"(A) : "memory", "scc", OW_FRAGS);
 #else
     ow_mfma_twin<SET, N16, M16, ZERO>(c);

@@ -177,7 +177,7 @@ __device__ __forceinline__ void ow_epilogue_run(char* smem0, OwCtx& c, const Gem
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (OSZ == 4) d += u2f(o[e]) * u2f(r[e]);
-                    else d += u2f(o[e] << 16) * u2f(r[e] << 16) + u2f(o[e] & 0xffff0000u) * u2f(r[e] & 0xffff0000u);
+                    else d += lo16f(o[e]) * lo16f(r[e]) + hi16f(o[e]) * hi16f(r[e]);
                 }
                 constexpr int GL = 64 * OSZ / 16;
 #pragma unroll

@@ -95,10 +95,10 @@ __device__ __forceinline__ void tw_mfma(TwCtx& c) {
     constexpr int D = 16 * (4 * A + B), FA = TW_V_F + 32 * SET + 4 * A, FB = TW_V_F + 32 * SET + 16 + 4 * B;
     if (TW_ABLATE & 4) return;
     if constexpr (ZERO)
-        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], 0"
+        asm volatile("v_mfma_f32_32x32x16_" MAEST_T16 " a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], 0"
                      : : "i"(D), "i"(D + 15), "i"(FA), "i"(FA + 3), "i"(FB), "i"(FB + 3) : TW_FRAGS);
     else
-        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], a[%c0:%c1]"
+        asm volatile("v_mfma_f32_32x32x16_" MAEST_T16 " a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], a[%c0:%c1]"
                      : : "i"(D), "i"(D + 15), "i"(FA), "i"(FA + 3), "i"(FB), "i"(FB + 3) : TW_FRAGS);
 #else
     if (ZERO) {
@@ -168,7 +168,7 @@ __device__ __forceinline__ f32x16_t tw_acc_read(TwCtx& c) {
 template <int SET, int A0>
 __device__ __forceinline__ void tw_colsum(TwCtx& c) {
 #if TW_DEV
-#define TW_DOT(BLK, E) asm volatile("v_dot2c_f32_bf16 v%c0, v%c1, v%c2" : : "i"(TW_V_CS + 4 * (BLK) + (E)), \
+#define TW_DOT(BLK, E) asm volatile("v_dot2c_f32_" MAEST_T16 " v%c0, v%c1, v%c2" : : "i"(TW_V_CS + 4 * (BLK) + (E)), \
                                     "i"(TW_V_F + 32 * SET + 4 * (A0 + (BLK)) + (E)), "i"(TW_V_ONE))
     TW_DOT(0, 0); TW_DOT(0, 1); TW_DOT(0, 2); TW_DOT(0, 3);
     TW_DOT(1, 0); TW_DOT(1, 1); TW_DOT(1, 2); TW_DOT(1, 3);
@@ -179,7 +179,7 @@ __device__ __forceinline__ void tw_colsum(TwCtx& c) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t w = c.fa[SET][A0 + blk][e];
-            c.cs[blk][e] += u2f(w << 16) + u2f(w & 0xffff0000u);
+            c.cs[blk][e] += lo16f(w) + hi16f(w);
         }
 #endif
 }

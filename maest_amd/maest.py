@@ -23,6 +23,9 @@ Numeric modes (``model.precision``):
   "bf16x3" fast parity mode: fp32 tensors everywhere, the linear layers and the attention forward as three bf16
           MFMAs on hi/lo splits of the fp32 operands (SURVEY H1 "split-bf16"): meets the same 1e-3 gate as "fp32"
           at 2-2.5x its speed (forward and backward; small / ragged GEMMs stay exact fp32);
+  "fp16"  fast parity mode for EVALUATION (round 6): the "bf16" kernels' schedules with IEEE-half operands (v_mfma_*_f16; the library's second
+          build, libmaest_hip_f16.so) -- the reference's own GPU arithmetic (16-mixed autocast) --: logits 6e-4 .. 8e-4 from fp32, inside the
+          1e-3 gate, at the bf16 mode's speed.  Forwards that record a graph raise (gradients in half need loss scaling: train in bf16);
   "auto"  (default) bf16 for a training forward that records a graph; every other forward -- eval(), no_grad,
           predict_labels -- runs "bf16x3" (the reference computes inference in fp32; the split products meet the
           same 1e-3 / identical-ranking gates at twice the speed of the exact ones; precision="fp32" selects those).
@@ -123,6 +126,7 @@ class _Weights:
 
     def __init__(self):
         self._cache = {}
+        self.seen_train = 0     # _Engine._train_forwards at the last clear()
         self.epoch = 0          # bumped whenever every copy is dropped (part of the hipGraph cache key)
         # {id(parameter): rows}: parameters whose PLAIN low-precision copy carries `row_scale` on its first `rows` rows (the q rows of
         # the qkv projections in bf16 mode: include/maest_hip.h MAEST_BF16_QS); the transposed copies (dgrad) stay unscaled
@@ -245,6 +249,7 @@ class _Engine:
     def __init__(self, model: "MAEST"):
         self.m = model
         self.w = _Weights()
+        self.w_f16 = _Weights()          # operand copies of precision="fp16" forwards (made by the half-precision build of the kernels)
         self.overlap_wgrad = True
         # The head reads two tokens (cls, dist) of the last block's output (models/maest.py:819-826), and everything in a
         # block after the attention's key / value side is per token: the last block therefore evaluates its attention
@@ -276,6 +281,7 @@ class _Engine:
         self.split_add = int(os.environ.get("MAEST_SPLIT_ADD", "1"))
         self.split_add_eval = int(os.environ.get("MAEST_SPLIT_ADD_EVAL", os.environ.get("MAEST_SPLIT_ADD", "1")))
         self._weights_dirty = False
+        self._train_forwards = 0         # training-mode forwards so far: an operand-copy cache made before the latest one is stale (see _forward)
         self._side = {}
         # Training steps in flight: the host enqueues a step in ~10 ms, the GPU runs it in ~47, and nothing in a bare training loop makes
         # the host wait -- so it runs ahead, and blocks the caching allocator is asked for while their previous use (recorded on the side
@@ -350,15 +356,19 @@ class _Engine:
         return ops.thread_options(gemm_wgs=wgs, gemm_tail=0) if ops.get_option("gemm_tail") == 1 else ops.thread_options(gemm_wgs=wgs)
 
     # ---- forward ----------------------------------------------------------------------------
-    def forward(self, *args, **kw):
+    def forward(self, *args, f16: bool = False, **kw):
+        if f16:      # precision="fp16": the same sequence of C-ABI calls, served by libmaest_hip_f16.so for this thread (maest_amd/_lib.py: flavour)
+            from . import _lib as _L
+            with _L.flavour("f16"), self._gemm_form(shared=False):
+                return self._forward(*args, f16=True, **kw)
         with self._gemm_form(shared=False):
             return self._forward(*args, **kw)
 
     def _forward(self, x3: torch.Tensor, dt, *, toffset: int, tok_ft: torch.Tensor, perm, lam, stripes=None,
-                 stop_block: int = -1, return_self_attention: bool = False, save: bool = False, x3m=None):
+                 stop_block: int = -1, return_self_attention: bool = False, save: bool = False, x3m=None, f16: bool = False):
         """x3: fp32 [B, F, T] on the device; tok_ft: int32 [P, 2] kept patch tokens.  Returns (outputs, ctx).
         x3m: split-bf16 products on the fp32 tensors (the model's resolved mode; None: model.precision == "bf16x3")."""
-        m, W = self.m, self.w
+        m, W = self.m, (self.w_f16 if f16 else self.w)
         if x3m is None:
             x3m = m.precision == "bf16x3"
         x3m = bool(x3m) and dt == torch.float32      # an explicit argument of every product
@@ -372,8 +382,11 @@ class _Engine:
         # fused=True), multi-tensor kernels in general) update parameters in place WITHOUT bumping them -- a stale
         # bf16 copy then keeps training on the initial weights.  So every training-mode forward recasts everything
         # (one 0.24 ms launch for the 48 block matrices), and the first eval forward after one does too.
-        if save or self._weights_dirty:
+        if save:
+            self._train_forwards += 1
+        if save or W.seen_train != self._train_forwards:
             W.clear()
+            W.seen_train = self._train_forwards
         self._weights_dirty = bool(save)
         mats = [lin.weight for blk in m.blocks for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)]
         mats += [m.patch_embed.proj.weight, m.head[1].weight]
@@ -875,10 +888,19 @@ class MAEST(nn.Module):
             return "bf16x3"
         if p in ("bf16", "bfloat16"):
             return "bf16"
-        raise ValueError(f"precision must be 'auto', 'fp32', 'bf16x3' or 'bf16', got {self.precision!r}")
+        if p in ("fp16", "float16", "half"):
+            # IEEE half operands: the bf16 kernels' schedules on v_mfma_*_f16 (libmaest_hip_f16.so: the same sources, csrc/common.h
+            # MAEST_16BIT_F16) -- the reference's own GPU arithmetic (16-mixed autocast, ex_maest.py:51), 6e-4 .. 8e-4 from fp32 where bf16 is at
+            # 5e-3 .. 8e-3, at the bf16 mode's speed.  Evaluation only: gradients in half need loss scaling, training stays bf16.
+            if recording:
+                raise NotImplementedError('precision="fp16" serves forwards that record no graph (eval() / no_grad / predict_labels); '
+                                          'train in "bf16" (or "auto", which does)')
+            return "fp16"
+        raise ValueError(f"precision must be 'auto', 'fp32', 'bf16x3', 'bf16' or 'fp16', got {self.precision!r}")
 
     def _compute_dtype(self, recording: bool = True):
-        return torch.bfloat16 if self._resolve_precision(recording) == "bf16" else torch.float32
+        # ("fp16": the kernels' 16-bit container carries the bfloat16 dtype TAG; the half-precision build interprets the bits)
+        return torch.bfloat16 if self._resolve_precision(recording) in ("bf16", "fp16") else torch.float32
 
     # ---- input handling (maest.py:855-895) --------------------------------------------------
     def _prepare_input(self, x, melspectrogram_input):
@@ -996,6 +1018,9 @@ class MAEST(nn.Module):
         x3 = x3.contiguous()
         need_grad = (transformer_block == -1 and torch.is_grad_enabled()
                      and any(p.requires_grad for p in self.parameters()))
+        if need_grad and not self.training and self.precision in ("fp16", "float16", "half"):
+            need_grad = False     # precision="fp16" is an evaluation mode: eval() forwards record no graph even outside no_grad (a backward
+                                  # through them fails loudly on outputs that do not require grad); a train() forward raises, see _resolve_precision
         dt = self._compute_dtype(need_grad)
 
         Fp = (F - PATCH) // self.patch_embed.stride[0] + 1
@@ -1028,8 +1053,10 @@ class MAEST(nn.Module):
         if _specmask is not None:
             stripes = tuple(None if t is None else t.to(device=x3.device, dtype=torch.int32).contiguous()
                             for t in _specmask)
-        kw = dict(toffset=int(toffset), tok_ft=tok_ft, perm=perm, lam=lam, stripes=stripes,
-                  x3m=self._resolve_precision(need_grad) == "bf16x3")
+        mode = self._resolve_precision(need_grad)
+        kw = dict(toffset=int(toffset), tok_ft=tok_ft, perm=perm, lam=lam, stripes=stripes, x3m=mode == "bf16x3")
+        if mode == "fp16":
+            kw["f16"] = True
 
         if transformer_block != -1:
             with torch.no_grad():
@@ -1065,11 +1092,13 @@ class MAEST(nn.Module):
         return self
 
     def _graph_forward(self, x3, dt, kw):
-        if self._engine._weights_dirty:                  # a training step happened since the last eval forward
-            self._engine.w.clear()
+        wc = self._engine.w_f16 if kw.get("f16") else self._engine.w
+        if wc.seen_train != self._engine._train_forwards:    # a training step happened since this cache was filled
+            wc.clear()
+            wc.seen_train = self._engine._train_forwards
             self._engine._weights_dirty = False
-        key = (tuple(x3.shape), x3.dtype, dt, self.precision, kw["x3m"], kw["toffset"], int(kw["tok_ft"].shape[0]), str(x3.device),
-               sum(p._version for p in self.parameters()), self._engine.w.epoch)
+        key = (tuple(x3.shape), x3.dtype, dt, self.precision, kw["x3m"], bool(kw.get("f16")), kw["toffset"], int(kw["tok_ft"].shape[0]), str(x3.device),
+               sum(p._version for p in self.parameters()), wc.epoch)
         st = self._graphs.get(key)
         if st is None:                                   # first call: eager (fills the operand-copy caches)
             if len(self._graphs) >= 8:
@@ -1138,6 +1167,7 @@ class MAEST(nn.Module):
                             for k, v in st["wcache"].items()}
             eng.w.epoch += 1
             eng._weights_dirty = True
+            eng._train_forwards += 1          # (the operand copies of other caches predate this step's weights)
         lease = _GraphLease()
         st["lease"] = weakref.ref(lease)
         st["graph"].replay()

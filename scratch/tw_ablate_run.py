@@ -18,6 +18,7 @@ res = {(n, s): [] for n, _ in libs for s in shapes}
 for rnd in range(3):
     for name, lib in libs:
         _lib._lib = lib
+        ops._option_cache.clear()
         with ops.options(gemm_variant=(3 if name.startswith("old") else 0)):
             for s in shapes:
                 a, b, o, c = data[s]

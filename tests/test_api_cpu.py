@@ -311,7 +311,7 @@ def test_failed_register_audit_leaves_the_kernel_out_instead_of_failing_the_buil
     monkeypatch.setattr(pw_audit, "audit", lambda *a, **k: ([(7, "owned arch VGPR outside the asm blocks", "v_mov_b32 v200, v1")], 200, {}))
     o = str(tmp_path / "attn_fwd_pw.o"); objs.append(o)
     assert "owns by hand" in B.audit_or_leave_out("attn_fwd_pw.hip", o, verbose=False)
-    monkeypatch.setattr(B, "_device_asm", lambda name: None)
+    monkeypatch.setattr(B, "_device_asm", lambda name, bdir="build": None)
     o = str(tmp_path / "gemm_nt_ow.o"); objs.append(o)
     assert "cannot audit" in B.audit_or_leave_out("gemm_nt_ow.hip", o, verbose=False)
     o = str(tmp_path / "gemm_tn_ow.o"); objs.append(o)

@@ -124,6 +124,52 @@ def test_g1_eval_bf16x3_meets_the_parity_gate():
     assert rel_err(dict(net.named_parameters())["blocks.0.attn.qkv.weight"].grad[:16, :16], g5["grad_qkv0"]) < 1e-3
 
 
+def test_g1_eval_fp16_meets_the_logits_gate_at_the_fast_kernels():
+    """precision="fp16" (round 6): the perf mode's kernels and schedules on IEEE-half operands (libmaest_hip_f16.so, the second build of the same
+    sources) -- the reference's own GPU arithmetic (16-mixed autocast, ex_maest.py:51).  north_star's gate for the fast path: logits and features
+    within 1e-3 of the reference fixture, bit-exact top-10 label indices; the full 400-way ranking is NOT claimed (bf16x3 / fp32 hold that).
+    The early-exit embedding, the 30 s architecture with chunking, and the captured-graph replay go through the same mode; a forward that
+    records a graph must refuse."""
+    from maest_amd import _lib
+    g = np.load(os.path.join(GOLD, "g1_eval_10s.npz"))
+    m = build("discogs-maest-10s-pw-129e", 625, precision="fp16").eval()
+    x = randn((2, 96, 626), 7).to(DEV)
+    logits, feats = m(x.clone())
+    assert _lib._lib_f16 is not None, "the half-precision build was not loaded"
+    e1, e2 = rel_err(logits, g["logits"]), rel_err(feats, g["features"])
+    print(f"G1 fp16: logits rel err {e1:.2e}, features rel err {e2:.2e}")
+    assert e1 < 1e-3 and e2 < 1e-3
+    _, emb6 = m(x.clone(), transformer_block=6)
+    assert rel_err(emb6, g["emb6"]) < 1e-3
+    act, _ = m.predict_labels(x.clone())
+    assert np.abs(act - g["activations"]).max() < 5e-4       # (sigmoid of logits that are within 1e-3 of scale ~1)
+    assert (np.argsort(-act)[:10] == g["top10"]).all(), "top-10 label indices must be bit-exact"
+    # the bf16 flavour of the same forward on the same model: an order of magnitude further away, and its operand copies coexist
+    m.precision = "bf16"
+    e_bf = rel_err(m(x.clone())[0], g["logits"])
+    m.precision = "fp16"
+    assert e_bf > 2 * e1 and rel_err(m(x.clone())[0], g["logits"]) == e1
+    # captured graph: bit-identical replay
+    m.enable_hip_graph()
+    a = m(x.clone())[0]; b = m(x.clone())[0]; c = m(x.clone())[0]
+    assert torch.equal(a, logits) and torch.equal(b, logits) and torch.equal(c, logits)
+    m.enable_hip_graph(False)
+    # 30 s architecture, 519 labels, 2-D mel input chunked into a batch (fixture G2)
+    g2 = np.load(os.path.join(GOLD, "g2_eval_30s_519.npz"))
+    m30 = build("discogs-maest-30s-pw-129e-519l", 1875, precision="fp16").eval()
+    l30, f30 = m30(randn((1, 96, 1876), 9).to(DEV))
+    assert rel_err(l30, g2["logits"]) < 1e-3 and rel_err(f30, g2["features"]) < 1e-3
+    lc, fc = m30(randn((96, 3752), 10).to(DEV), melspectrogram_input=True)
+    assert rel_err(lc, g2["chunk_logits"]) < 1e-3 and rel_err(fc, g2["chunk_features"]) < 1e-3
+    # training in half is refused (gradients would need loss scaling): the message says what to use
+    assert not logits.requires_grad          # (an eval() forward in this mode records no graph, inside no_grad or not)
+    m.train()
+    with pytest.raises(NotImplementedError, match="bf16"):
+        m(x.clone())
+    with torch.no_grad():                    # (a train-mode forward that records nothing -- predict_labels on a fresh model -- is served)
+        m(x.clone())
+
+
 @pytest.mark.parametrize("precision", EVAL_MODES)
 def test_g1b_mel_like_input_fp32(precision):
     g = np.load(os.path.join(GOLD, "g1b_eval_10s_mellike.npz"))
