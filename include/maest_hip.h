@@ -86,8 +86,8 @@ int maest_kernel_forms(int* mask);
  *   MAEST_OPT_GEMM_VARIANT  (env MAEST_GEMM_VARIANT,  default 0):    0 = full-line 256x256 kernels (bf16 operands, every epilogue
  *                            form incl. row-dot: four waves, one per SIMD, 128 x 128 outputs each -- gemm_nt_ow.hip / gemm_tn_ow.hip;
  *                            fp32 / split-bf16 operands and the 128-row tail tiles: eight waves -- gemm256.hip),
- *                            1 = 64-byte-slice 256x256, 2 = 256x128 two-per-CU, 3 = as 0 with the eight-wave kernels for bf16 too
- *                            (A/B, tests), 4 = 256-tile TN kernel at any qualifying shape
+ *                            3 = as 0 with the eight-wave kernels for bf16 too (A/B, tests), 4 = 256-tile TN kernel at any qualifying
+ *                            shape (1 / 2 selected two earlier 256-row kernels, removed in round 6)
  *   MAEST_OPT_GEMM_EPILOGUE (env MAEST_GEMM_EPILOGUE, default -1):   -1 = per-epilogue choice, 0/1/2 force a C-tile
  *                            epilogue form of the eight-wave full-line kernel (ignored by the one-wave-per-SIMD kernel, i.e. for
  *                            bf16 operands under MAEST_OPT_GEMM_VARIANT = 0) */
@@ -96,7 +96,7 @@ int maest_kernel_forms(int* mask);
 #define MAEST_OPT_GEMM_EPILOGUE 2
 #define MAEST_OPT_ATTN_BWD 3 /* env MAEST_ATTN_BWD, default 0: fused one-pass attention backward where it applies
                                 (bf16, N <= 320), query tiles fed by LDS-DMA; 1 = always the two-kernel dK/dV + dQ
-                                form; 2 = the fused form with register-fed tiles and the delta computed in flight;
+                                form; (2 selected the register-fed fused form, removed in round 6: now as 0;)
                                 3 = as 0 without the persistent form (one workgroup per (batch, head) at every shape).
                                 4 = as 1 with the register-staged padded tiles (the bf16 two-kernel form otherwise streams its
                                 tiles by LDS-DMA, bit-equal; A/B and tests).

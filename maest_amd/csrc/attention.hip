@@ -603,246 +603,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
 // multiplies zeros) and their dK / dV rows are never stored.  dK / dV leave through LDS as whole 128-byte rows.
 constexpr int FB_MAXW = 12;                       // 10 key waves + 2 aux waves -> 3 waves per SIMD, <= 168 VGPRs
 constexpr int FB_DS_PITCH = 72;                   // dS exchange tile [key][32 q] bf16: 64 B + 8 (conflict-free 8-byte stores)
-__global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv,
-                                                                       const bf16_t* __restrict__ o,
-                                                                       const bf16_t* __restrict__ dout,
-                                                                       const float* __restrict__ lse,
-                                                                       bf16_t* __restrict__ dqkv, int B, int N,
-                                                                       float sc_c2, float sc_dq, float sc_dk) {
-    using T = bf16_t;
-    using C = AttnCfg<T>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nkw = (N + 31) >> 5;                 // key waves = key blocks = query tiles
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nthreads = blockDim.x;
-    // LDS map: K [nkw*32][64] | 2 x dS [nkw*32][32 q] | 2 x { Q tile [32][64], dO tile [32][64], lse[32], delta[32] }
-    constexpr int QT = 32 * C::PITCH;              // one 32-row tile
-    constexpr int QBUF = 2 * QT + 256;
-    const int DSBUF = nkw * 32 * FB_DS_PITCH;
-    char* k_lds = smem;
-    char* ds0 = smem + nkw * 32 * C::PITCH;
-    char* qbuf0 = ds0 + 2 * DSBUF;
-
-    const int bh = xcd_remap(blockIdx.x, B * NHEADS);
-    const int head = bh % NHEADS, b = bh / NHEADS;
-    const T* qbase = qkv + (int64_t)b * N * QKV_LD + head * HD;
-    const T* kbase = qbase + NHEADS * HD;
-    const T* vbase = qbase + 2 * NHEADS * HD;
-    const T* dobase = dout + (int64_t)b * N * OUT_LD + head * HD;
-    const T* obase = o + (int64_t)b * N * OUT_LD + head * HD;
-    const float* lse_b = lse + ((int64_t)b * NHEADS + head) * N;
-    T* dq_out = dqkv + (int64_t)b * N * QKV_LD + head * HD;
-
-    const bool key_wave = wave < nkw;
-    const int aux = wave - nkw;                    // 0: Q feeder + dQ[:, 0:32], 1: dO feeder + dQ[:, 32:64]; >= 2: filler
-
-    // ---- prologue, all threads: K of every key block -> LDS (rows >= N zero); up to 4 loads in flight per thread
-    {
-        const int total = nkw * 32 * 8;
-        for (int i0 = tid; i0 < total; i0 += 4 * nthreads) {
-            chunk16 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = i0 + k * nthreads;
-                const int r = i >> 3, c = i & 7;
-                v[k] = chunk16{0u, 0u, 0u, 0u};
-                if (i < total && r < N) v[k] = *reinterpret_cast<const chunk16*>(kbase + (uint32_t)(r * QKV_LD + c * 8));
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = i0 + k * nthreads;
-                if (i < total) *reinterpret_cast<chunk16*>(k_lds + (i >> 3) * C::PITCH + (i & 7) * 16) = v[k];
-            }
-        }
-    }
-
-    if (key_wave) {
-        // =============================================================================== key waves
-        const int key = wave * 32 + (lane & 31);
-        const f32x2_t c2v = {sc_c2, sc_c2};
-        chunk16 kf[C::STEPS], vf[C::STEPS];
-        row_frags_load<T>(kf, kbase, QKV_LD, key, N, h);
-        row_frags_load<T>(vf, vbase, QKV_LD, key, N, h);
-        f32x16_t dk[2], dv[2];
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dk[db][r] = 0.0f; dv[db][r] = 0.0f; }
-        __syncthreads();                                   // K in LDS, query tile 0 staged
-        for (int t = 0; t < nkw; ++t) {
-            const char* q_lds = qbuf0 + (t & 1) * QBUF;
-            const char* do_lds = q_lds + QT;
-            const float* lse_lds = reinterpret_cast<const float*>(q_lds + 2 * QT);
-            const float* dl_lds = lse_lds + 32;
-            {
-                f32x16_t s, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
-                mma_rows<T>(s, q_lds, 0, lane, kf);      // S[q][key]
-                mma_rows<T>(dp, do_lds, 0, lane, vf);    // dP[q][key]
-                char* ds_row = ds0 + (t & 1) * DSBUF + key * FB_DS_PITCH;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ql = 8 * g + 4 * h;        // local q of register 4g (4 consecutive rows)
-                    const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_lds + ql);
-                    const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dl_lds + ql);
-#pragma unroll
-                    for (int e = 0; e < 4; e += 2) {
-                        const int r = 4 * g + e;
-                        const f32x2_t sv = {s[r], s[r + 1]}, nl = {-l4[e], -l4[e + 1]};
-                        const f32x2_t dpv = {dp[r], dp[r + 1]}, dl = {d4[e], d4[e + 1]};
-                        const f32x2_t ev = __builtin_elementwise_fma(sv, c2v, nl);
-                        const f32x2_t pv = {fast_exp2<T>(ev[0]), fast_exp2<T>(ev[1])};
-                        const f32x2_t dsv = pv * (dpv - dl);
-                        s[r] = pv[0]; s[r + 1] = pv[1];       // P
-                        dp[r] = dsv[0]; dp[r + 1] = dsv[1];   // dS (unscaled)
-                    }
-                    chunk8 w;
-                    w[0] = pack_bf2(dp[4 * g], dp[4 * g + 1]);
-                    w[1] = pack_bf2(dp[4 * g + 2], dp[4 * g + 3]);
-                    *reinterpret_cast<chunk8*>(ds_row + ql * 2) = w;
-                }
-                mma_transposed<T>(dv, do_lds, 0, lane, s);    // dV^T[d][key] += dO^T[d][q] P[q][key]
-                mma_transposed<T>(dk, q_lds, 0, lane, dp);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
-            }
-            __syncthreads();
-        }
-        __syncthreads();                                   // the aux waves are done with K and the last dS tile
-        // dK / dV: registers -> this wave's private LDS patch (row = key, 128 B of d) -> whole rows, 16 B per lane
-        char* patch = smem + wave * (2 * 32 * C::PITCH);
-#pragma unroll
-        for (int tsel = 0; tsel < 2; ++tsel)
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x16_t& a = tsel == 0 ? dk[db] : dv[db];
-                    const float m = tsel == 0 ? sc_dk : 1.0f;
-                    chunk8 w;
-                    w[0] = pack_bf2(a[4 * g] * m, a[4 * g + 1] * m);
-                    w[1] = pack_bf2(a[4 * g + 2] * m, a[4 * g + 3] * m);
-                    *reinterpret_cast<chunk8*>(patch + tsel * 32 * C::PITCH + (lane & 31) * C::PITCH +
-                                               (db * 32 + 8 * g + 4 * h) * 2) = w;
-                }
-        __syncthreads();
-#pragma unroll
-        for (int tsel = 0; tsel < 2; ++tsel)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = lane + 64 * j, r = i >> 3, c = i & 7;
-                const int krow = wave * 32 + r;
-                if (krow < N) {
-                    const chunk16 v = *reinterpret_cast<const chunk16*>(patch + tsel * 32 * C::PITCH + r * C::PITCH + c * 16);
-                    *reinterpret_cast<chunk16*>(dq_out + (uint32_t)(krow * QKV_LD + (1 + tsel) * NHEADS * HD + c * 8)) = v;
-                }
-            }
-    } else {
-        // =============================================================================== aux (and filler) waves
-        // feeder: lane handles chunks i = lane + 64 k (k = 0..3) of its 32 x 8-chunk tile: row i >> 3, chunk i & 7
-        // Every load is UNCONDITIONAL per lane (clamped row, wave-uniform base): a load under a lane condition merges
-        // with a default value at the join, which makes the compiler wait for it right there; and nothing consumes a
-        // loaded value before feed_store.  Rows >= N are zeroed when the tile is written to LDS.
-        struct Feed { chunk16 c[4]; chunk16 o[4]; float l; };
-        const T* fbase = aux == 0 ? qbase : dobase;        // wave-uniform
-        const int fld = aux == 0 ? QKV_LD : OUT_LD;
-        auto feed_load = [&](Feed& f, int t) {
-            if (t >= nkw || aux > 1) return;               // (wave-uniform)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = lane + 64 * k, c = i & 7;
-                int row = t * 32 + (i >> 3);
-                row = row < N ? row : N - 1;
-                f.c[k] = *reinterpret_cast<const chunk16*>(fbase + (uint32_t)(row * fld + c * 8));
-                f.o[k] = *reinterpret_cast<const chunk16*>(obase + (uint32_t)(row * OUT_LD + c * 8));
-            }
-            int lrow = t * 32 + (lane & 31);
-            lrow = lrow < N ? lrow : N - 1;
-            f.l = lse_b[lrow];
-        };
-        auto feed_store = [&](const Feed& f, int t) {
-            if (t >= nkw || aux > 1) return;               // (wave-uniform)
-            char* base = qbuf0 + (t & 1) * QBUF;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = lane + 64 * k, r = i >> 3, c = i & 7;
-                const bool live = t * 32 + r < N;
-                chunk16 v = f.c[k];
-                if (!live) v = chunk16{0u, 0u, 0u, 0u};
-                *reinterpret_cast<chunk16*>(base + (aux == 0 ? 0 : QT) + r * C::PITCH + c * 16) = v;
-                if (aux == 1) {                            // delta = rowsum(dO * O); the 8 chunks of a row sit in 8 consecutive lanes
-                    float d = 0.0f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        d += lo16f(v[e]) * lo16f(f.o[k][e]);
-                        d += hi16f(v[e]) * hi16f(f.o[k][e]);
-                    }
-                    d += __shfl_xor(d, 1, 64);
-                    d += __shfl_xor(d, 2, 64);
-                    d += __shfl_xor(d, 4, 64);
-                    if (c == 0) reinterpret_cast<float*>(base + 2 * QT)[32 + r] = d;
-                }
-            }
-            if (aux == 0 && lane < 32)                     // padded rows: lse = +BIG -> P = 2^(-BIG) = 0
-                reinterpret_cast<float*>(base + 2 * QT)[lane] = t * 32 + lane < N ? f.l * LOG2E : -NEG_BIG;
-        };
-        auto dq_job = [&](int t) {      // dQ[:, 32 aux ..] of query tile t from the dS tile in ds0 + (t & 1) * DSBUF
-            if (aux > 1) return;
-            const char* ds = ds0 + (t & 1) * DSBUF;
-            f32x16_t acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            // two key blocks per trip, all 16 transpose reads issued before the 4 MFMAs that consume them (the chain on
-            // `acc` is serial anyway; what must overlap is the LDS latency)
-            for (int kb = 0; kb < nkw; kb += 2) {
-                const int kb1 = kb + 1 < nkw ? kb + 1 : kb;     // odd count: the last trip re-reads a block, weight 0
-                chunk16 a[4], bq[4];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    a[s] = frag_from_rows_bf16<C::PITCH>(k_lds, kb * 32, s, aux, lane);         // K^T[d][key]
-                    bq[s] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb * 32, s, 0, lane);          // dS^T[key][q]
-                    a[2 + s] = frag_from_rows_bf16<C::PITCH>(k_lds, kb1 * 32, s, aux, lane);
-                    bq[2 + s] = frag_from_rows_bf16<FB_DS_PITCH>(ds, kb1 * 32, s, 0, lane);
-                }
-                if (kb + 1 >= nkw) { bq[2] = chunk16{0u, 0u, 0u, 0u}; bq[3] = chunk16{0u, 0u, 0u, 0u}; }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mma_chunk<T>(acc, a[j], bq[j]);
-            }
-            const int q = t * 32 + (lane & 31);
-            if (q < N) {
-                T* row = dq_out + (uint32_t)(q * QKV_LD + aux * 32);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    store4<T>(row + 8 * g + 4 * h, acc[4 * g] * sc_dq, acc[4 * g + 1] * sc_dq, acc[4 * g + 2] * sc_dq,
-                              acc[4 * g + 3] * sc_dq);
-            }
-        };
-        Feed f0, f1;
-        feed_load(f0, 0);
-        feed_load(f1, 1);                                  // in flight across the first barrier
-        feed_store(f0, 0);
-        __syncthreads();                                   // K in LDS, query tile 0 staged
-        for (int t = 0; t < nkw; t += 2) {
-            // even step t: f1 carries tile t + 1; tile t + 2 goes into f0
-            feed_load(f0, t + 2);
-            if (t > 0) dq_job(t - 1);
-            feed_store(f1, t + 1);
-            __syncthreads();
-            if (t + 1 < nkw) {   // odd step t + 1: f0 carries tile t + 2; tile t + 3 goes into f1
-                feed_load(f1, t + 3);
-                dq_job(t);
-                feed_store(f0, t + 2);
-                __syncthreads();
-            }
-        }
-        dq_job(nkw - 1);
-        __syncthreads();                                   // LDS may be reused by the key waves' epilogue
-        __syncthreads();
-    }
-}
+// (The first, register-fed form of this kernel -- query tiles staged through registers by the aux waves, delta computed in flight: MAEST_ATTN_BWD = 2 --
+// was removed in round 6: superseded since round 2 by the DMA-fed forms below, which are 9 % faster with the separate delta pass.)
 
 // =================================================================================== fused backward, DMA-fed (bf16, N <= 320)
-// The same decomposition as attn_bwd_fused_kernel, with the aux waves relieved of the tile staging (their loop was the
+// The decomposition above, with the aux waves relieved of the tile staging (their loop was the
 // critical path: 260 us of staging + dQ against 240 us of key-wave work): K (resident) and the Q / dO query tiles are
 // UNPADDED 128-byte-row tiles filled by LDS-DMA (no register round trip, no ds_write pass; two tiles ahead, three
 // buffers), with the bank swizzle  chunk ^= row[1] row[2] row[3]  applied on the DMA source address so that the
@@ -1582,7 +1347,7 @@ __global__ __launch_bounds__(FB_MAXW * 64) void attn_bwd_fused2_kernel(const bf1
             char* dst = qbuf0 + (t % 3) * F2_QBUF + (aux == 0 ? 0 : 32 * 128);
             dma_rows128(dst, fbase, fld, t * 32, 0, 4, 1, N, lane);
         };
-        auto stat_load = [&](int t) -> float {             // (unconditional, clamped: see attn_bwd_fused_kernel)
+        auto stat_load = [&](int t) -> float {             // (unconditional, clamped: a conditional load would make hipcc wait for it at the join)
             int row = t * 32 + (lane & 31);
             row = row < N ? row : N - 1;
             return (t < nqt && aux <= 1) ? sbase[row] : 0.0f;
@@ -1986,11 +1751,6 @@ static int attn_bwd_fused3_smem(int N) {
     return 2 * nkw * 32 * 128 + 2 * nkw * 32 * FB_DS_PITCH + 3 * F2_QBUF;
 }
 
-static int attn_bwd_fused_smem(int N) {
-    const int nkw = (N + 31) / 32;
-    return nkw * 32 * AttnCfg<bf16_t>::PITCH + 2 * (2 * 32 * AttnCfg<bf16_t>::PITCH + 256) + 2 * nkw * 32 * FB_DS_PITCH;
-}
-
 // Waves (= 32-query blocks) per workgroup of attn_fwd_dma_kernel.  MAEST_OPT_ATTN_FWD_WAVES forces 4 / 5 / 6 / 8; 0 = by shape.
 static int attn_fwd_waves(int N, int q_rows) {
     const int forced = option(MAEST_OPT_ATTN_FWD_WAVES);
@@ -2079,19 +1839,6 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
                   "MAEST_OPT_ATTN_BWD = 0 or 3)", q_rows, N, 32 * (FB_MAXW - 2));
         return MAEST_ERR_INVALID;
     }
-    if constexpr (sizeof(T) == 2) {
-        const int nkw = (N + 31) / 32;
-        if (nkw + 2 <= FB_MAXW && option(MAEST_OPT_ATTN_BWD) == 2) {     // register-fed form (delta fused)
-            const int smem_f = attn_bwd_fused_smem(N);
-            const int waves = nkw + 2 < 8 ? 8 : nkw + 2;      // the staging step wants 512 threads (one chunk each)
-            static DeviceOnce once_f;
-            ensure_dynamic_lds(once_f, &attn_bwd_fused_kernel, attn_bwd_fused_smem(32 * (FB_MAXW - 2)));
-            hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * NHEADS), dim3(waves * 64), smem_f, st,
-                               (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N,
-                               sc.c2, sc.dq, sc.dk);
-            return check_launch("maest_attn_bwd(fused)");
-        }
-    }
     if constexpr (sizeof(T) == 2 && !X3) {
         if (option(MAEST_OPT_ATTN_BWD) != 4) {                            // DMA-fed tiles (4 = register-staged padded tiles: A/B, tests)
             constexpr int smem_da = 2 * (2 * 64 * 128 + 512), smem_db = 4 * 64 * 128;
@@ -2162,8 +1909,6 @@ extern "C" int maest_attn_bwd_rows(const void* qkv, const void* out, const void*
                                    float* delta, void* dqkv, int B, int N, int dtype, float scale, int q_rows,
                                    void* stream) {
     MAEST_REQUIRE(qkv && dout && lse && delta && dqkv, "maest_attn_bwd: null pointer");
-    MAEST_REQUIRE(out != nullptr || option(MAEST_OPT_ATTN_BWD) != 2,
-                  "maest_attn_bwd: out = NULL (delta given) is not served by the register-fed fused form (MAEST_OPT_ATTN_BWD = 2)");
     MAEST_REQUIRE(B > 0 && N > 0, "maest_attn_bwd: bad shape B=%d N=%d", B, N);
     MAEST_REQUIRE(q_rows > 0 && q_rows <= N, "maest_attn_bwd_rows: q_rows = %d outside 1..N", q_rows);
     MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16 || dtype == MAEST_F32X3 || dtype == MAEST_BF16_QS,

@@ -216,167 +216,8 @@ __device__ __forceinline__ void epilogue256(char* smem, const f32x16_t (&acc)[2]
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(512) void gemm_nt256_kernel(Gemm256Params p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;          // 0..7
-    const int wm = wave >> 2, wn = wave & 3;
-    const int h = lane >> 5;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = wg / p.tiles_n;
-    const int tile_n = wg - tile_m * p.tiles_n;
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
-
-    constexpr int ELT = (int)sizeof(T);
-    constexpr int KS = G2_ROWB / ELT;        // 32 / 16 elements per slice
-    const int nslices = p.K / KS;
-
-    // LDS-DMA map: wave-instruction (wave, i) fills rows [(wave*2+i)*16, +16) of a tile; lane -> (row, position)
-    const char* a_src[2];
-    const char* b_src[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (wave * 2 + i) * 16 + (lane >> 2);
-        const int csrc = (lane & 3) ^ ((r >> 2) & 3);        // source-side swizzle
-        int ra = m0 + r;
-        if (ra > p.M - 1) ra = p.M - 1;
-        int rb = n0 + r;
-        if (rb > p.N - 1) rb = p.N - 1;
-        a_src[i] = p.A + (int64_t)ra * p.lda * ELT + csrc * 16;
-        b_src[i] = p.B + (int64_t)rb * p.ldb * ELT + csrc * 16;
-    }
-    const int dma_off = wave * 2 * 1024;
-
-    f32x16_t acc[2][4];   // [nt][mt]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // half h2 (0/1) of the 4 LDS-DMA instructions this wave owes to slice s: one A piece + one B piece
-    auto issue_half = [&](int s, int h2) {
-        const int sc = s < nslices ? s : nslices - 1;        // past-the-end issues re-load the last slice into a dead
-        char* la = smem + (s & (G2_STAGES - 1)) * 2 * G2_TILE + dma_off;   // buffer: keeps the vmcnt arithmetic uniform
-        char* lb = la + G2_TILE;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[h2] + (int64_t)sc * G2_ROWB),
-                                         (__attribute__((address_space(3))) void*)(la + h2 * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[h2] + (int64_t)sc * G2_ROWB),
-                                         (__attribute__((address_space(3))) void*)(lb + h2 * 1024), 16, 0, 0);
-    };
-    auto issue = [&](int s) { issue_half(s, 0); issue_half(s, 1); };
-
-    int a_off[4], b_off[2], a_swz[4], b_swz[2];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int row = wm * 128 + mt * 32 + (lane & 31);
-        a_off[mt] = row * G2_ROWB;
-        a_swz[mt] = (row >> 2) & 3;
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int row = wn * 64 + nt * 32 + (lane & 31);
-        b_off[nt] = row * G2_ROWB;
-        b_swz[nt] = (row >> 2) & 3;
-    }
-
-    // ---- main loop: two phases per slice, LOAD (LDS -> fragment registers, issue the DMA of slice s+3) and
-    // COMPUTE (16 MFMAs, no memory traffic), separated by raw barriers.  The second wave group (wm == 1)
-    // runs ONE BARRIER BEHIND the first, so on every SIMD one wave is in COMPUTE while its partner is in
-    // LOAD: the matrix pipe never waits for ds_read / DMA issue, and those never wait for the pipe.
-    //   barrier 2s   : A: LOAD(s)     B: COMPUTE(s-1)
-    //   barrier 2s+1 : A: COMPUTE(s)  B: LOAD(s)
-    // Slice s is resident before anybody reads it: every wave ends LOAD(s-1) with vmcnt(8) (slices s+1, s+2
-    // may still fly) and the barrier(s) in between publish that to the other group.  DMA of slice s+3
-    // overwrites buffer (s-1)&3, whose last reader (B's LOAD(s-1)) finished before barrier 2s.
-    // DMA issue order.  One LDS-DMA instruction reads 16 rows x 64 B: HALF of each 128-byte line it touches;
-    // the other half belongs to the next K slice.  Issued three slices apart, the two halves were two separate
-    // L2 -> L1 line fills (the CU streams 64 KiB of lines per slice pair through a 32 KiB L1), and the measured
-    // L2 -> LDS rate (18 B/clk/CU) capped the loop at ~1250 TFLOP/s while the same loop without DMA ran at 2200.
-    // So slices are issued in PAIRS, row piece by row piece: (piece, slice s+2) immediately followed by
-    // (piece, slice s+3) -- the same sixteen lines back to back.  Even iterations issue 8 loads, odd ones none.
-    chunk16 fa[2][4], fb[2][2];
-    auto issue_pair = [&](int s) {
-        issue_half(s, 0); issue_half(s + 1, 0);
-        issue_half(s, 1); issue_half(s + 1, 1);
-    };
-    auto compute = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#ifndef MAEST_ABLATE_NO_MFMA
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
-#else
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[0][mt][ks] += u2f(fa[ks][mt][0] ^ fb[ks][mt & 1][1]);
-#endif
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto load_frags = [&](int s) {
-        const char* la = smem + (s & (G2_STAGES - 1)) * 2 * G2_TILE;
-        const char* lb = la + G2_TILE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int kc = 2 * ks + h;
-#ifdef MAEST_ABLATE_NO_DSREAD
-            if (s > 0) continue;
-#endif
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                fa[ks][mt] = *reinterpret_cast<const chunk16*>(la + a_off[mt] + ((kc ^ a_swz[mt]) << 4));
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                fb[ks][nt] = *reinterpret_cast<const chunk16*>(lb + b_off[nt] + ((kc ^ b_swz[nt]) << 4));
-        }
-    };
-    issue_pair(0);                   // slices 0, 1
-    MAEST_WAIT_VMCNT(0);
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger (wave-uniform)
-    // iteration s (even): slice s+1 (4 loads, issued at s-2 / in the prologue) may still fly; issue s+2, s+3;
-    //   vmcnt(8) retires slice s+1.   iteration s+1 (odd): s+2, s+3 fly; vmcnt(4) retires s+2.
-    for (int s = 0; s < nslices; s += 2) {
-        load_frags(s);
-#ifndef MAEST_ABLATE_NO_DMA
-        issue_pair(s + 2);
-#endif
-        __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        compute();
-        __builtin_amdgcn_s_barrier();
-        if (s + 1 < nslices) {
-            load_frags(s + 1);
-            __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0)
-            __builtin_amdgcn_s_barrier();
-            compute();
-            __builtin_amdgcn_s_barrier();
-        }
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();          // un-stagger
-    MAEST_WAIT_VMCNT(0);   // drain the past-the-end loads before LDS is reused
-    __syncthreads();   // every wave is done with the operand buffers: LDS becomes the C staging area
-    if (p.out_dtype == MAEST_BF16) epilogue256<2, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
-    else epilogue256<4, sizeof(T) == 4>(smem, acc, p, m0, n0, wm, wn, lane, tid);
-}
-
-template <typename T>
-static int launch256(Gemm256Params& p, hipStream_t stream) {
-    static DeviceOnce once;
-    ensure_dynamic_lds(once, &gemm_nt256_kernel<T>, G2_SMEM);
-    hipLaunchKernelGGL(gemm_nt256_kernel<T>, dim3(p.tiles_m * p.tiles_n), dim3(512), G2_SMEM, stream, p);
-    return check_launch("maest_gemm_nt(256)");
-}
-
+// (gemm_nt256_kernel -- the first 256 x 256 kernel, K in 64-byte slices through a four-deep ring: MAEST_GEMM_VARIANT = 1 -- was removed in round 6;
+// gemm_nt256w_kernel below, whole-line stages, has served every shape since round 2.  Its epilogue forms above are gemm_nt256w_kernel's too.)
 
 template <int OSZ, bool EXACT, int TNC, int NTH>
 __device__ __forceinline__ void epilogueT(char* smem, const f32x16_t (&acc)[2][4], const Gemm256Params& p, int m0,
@@ -834,142 +675,8 @@ static int launch256w(Gemm256Params& p, hipStream_t stream) {
     return check_launch("maest_gemm_nt(256w)");
 }
 
-// ================================================================================================
-// 256x128-tile variant, TWO workgroups per CU.
-// The 256x256 kernel above holds a CU alone (128 KiB of LDS), so its prologue (ring fill) and, above all,
-// its epilogue (C tile -> LDS -> HBM, ~10 us against a 21 us main loop at K = 768) leave the matrix pipe
-// idle.  Here a workgroup is 4 waves (2 x 2, still 128 x 64 outputs and 128 accumulators per wave), a
-// 3-deep ring of 24 KiB slices (72 KiB), and two workgroups share a CU: while one drains its C tile the other
-// one owns the MFMA pipe, and in steady state the two waves of a SIMD alternate LOAD (ds_read + DMA issue +
-// barrier) and COMPUTE (16 MFMAs) by themselves -- the role the explicit stagger plays above.
-// ================================================================================================
-constexpr int H2_TN = 128;
-constexpr int H2_A = 256 * G2_ROWB;                   // 16384
-constexpr int H2_STAGE = (256 + H2_TN) * G2_ROWB;     // 24576
-constexpr int H2_STAGES = 3;
-constexpr int H2_SMEM = H2_STAGES * H2_STAGE;         // 73728
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_nt256x128_kernel(Gemm256Params p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;          // 0..3
-    const int wm = wave >> 1, wn = wave & 1;
-    const int h = lane >> 5;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = wg / p.tiles_n;
-    const int tile_n = wg - tile_m * p.tiles_n;
-    const int m0 = tile_m * 256, n0 = tile_n * H2_TN;
-
-    constexpr int ELT = (int)sizeof(T);
-    constexpr int KS = G2_ROWB / ELT;
-    const int nslices = p.K / KS;
-
-    // LDS-DMA map: A piece i of wave w = rows [(w*4+i)*16, +16); B piece i = rows [(w*2+i)*16, +16)
-    const char* a_src[4];
-    const char* b_src[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 16 + (lane >> 2);
-        int ra = m0 + r;
-        if (ra > p.M - 1) ra = p.M - 1;
-        a_src[i] = p.A + (int64_t)ra * p.lda * ELT + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (wave * 2 + i) * 16 + (lane >> 2);
-        int rb = n0 + r;
-        if (rb > p.N - 1) rb = p.N - 1;
-        b_src[i] = p.B + (int64_t)rb * p.ldb * ELT + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
-    }
-
-    f32x16_t acc[2][4];   // [nt][mt]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    auto issue = [&](int s, int buf) {
-        const int sc = s < nslices ? s : nslices - 1;   // past-the-end: re-load the last slice into a dead buffer
-        char* la = smem + buf * H2_STAGE;
-        char* lb = la + H2_A;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)sc * G2_ROWB),
-                                             (__attribute__((address_space(3))) void*)(la + (wave * 4 + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (int64_t)sc * G2_ROWB),
-                                             (__attribute__((address_space(3))) void*)(lb + (wave * 2 + i) * 1024), 16, 0, 0);
-    };
-
-    int a_off[4], b_off[2], a_swz[4], b_swz[2];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int row = wm * 128 + mt * 32 + (lane & 31);
-        a_off[mt] = row * G2_ROWB;
-        a_swz[mt] = (row >> 2) & 3;
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int row = wn * 64 + nt * 32 + (lane & 31);
-        b_off[nt] = H2_A + row * G2_ROWB;
-        b_swz[nt] = (row >> 2) & 3;
-    }
-
-    // one barrier per slice: after it, slice s+1 is resident for everybody (each wave retired its own share with
-    // the counted vmcnt(6): only slice s+2's six loads may still fly) and nobody reads buffer s any more, so the
-    // next iteration may refill it.
-    issue(0, 0);
-    issue(1, 1);
-    MAEST_WAIT_VMCNT(6);
-    __builtin_amdgcn_s_barrier();
-    int buf = 0;
-    chunk16 fa[2][4], fb[2][2];
-    for (int s = 0; s < nslices; ++s) {
-        const char* st = smem + buf * H2_STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int kc = 2 * ks + h;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                fa[ks][mt] = *reinterpret_cast<const chunk16*>(st + a_off[mt] + ((kc ^ a_swz[mt]) << 4));
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                fb[ks][nt] = *reinterpret_cast<const chunk16*>(st + b_off[nt] + ((kc ^ b_swz[nt]) << 4));
-        }
-        const int nb = buf == 0 ? 2 : buf - 1;          // (s + 2) % 3
-        issue(s + 2, nb);
-        __builtin_amdgcn_s_waitcnt(0x0076);             // vmcnt(6) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(acc[nt][mt], fb[ks][nt], fa[ks][mt]);
-        __builtin_amdgcn_s_setprio(0);
-        buf = buf == 2 ? 0 : buf + 1;
-    }
-    MAEST_WAIT_VMCNT(0);
-    __syncthreads();   // LDS becomes the C staging area
-    if (p.out_dtype == MAEST_BF16) epilogueT<2, sizeof(T) == 4, H2_TN, 256>(smem, acc, p, m0, n0, wm, wn, lane, tid);
-    else epilogueT<4, sizeof(T) == 4, H2_TN, 256>(smem, acc, p, m0, n0, wm, wn, lane, tid);
-}
-
-template <typename T>
-static int launch256x128(Gemm256Params& p, hipStream_t stream) {
-    static DeviceOnce once;
-    ensure_dynamic_lds(once, &gemm_nt256x128_kernel<T>, H2_SMEM);
-    hipLaunchKernelGGL(gemm_nt256x128_kernel<T>, dim3(p.tiles_m * p.tiles_n), dim3(256), H2_SMEM, stream, p);
-    return check_launch("maest_gemm_nt(256x128)");
-}
+// (gemm_nt256x128_kernel -- 256 x 128 tiles, two workgroups per CU: MAEST_GEMM_VARIANT = 2 and the N % 256 != 0 shapes -- was removed in round 6: no
+// shape of the model has N % 256 != 0 at large M, and such a call is served by gemm.hip's 128 x 128 kernel.)
 
 // Called by maest_gemm_nt for large, 16-byte-friendly problems.  Returns -1 when the shape does not qualify.
 int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int in_dtype, void* C, int64_t ldc,
@@ -977,8 +684,7 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
                    int64_t ld_aux, hipStream_t stream, float* rowdot, int ntok) {
     if (epi == MAEST_EPI_ATOMIC) return -1;
     // the row-dot side output lives in the epilogues of the full-line kernel only (two-pass form / 128-row tiles)
-    if (epi == MAEST_EPI_ROWDOT && ((N % 256) != 0 || option(MAEST_OPT_GEMM_VARIANT) == 1 || option(MAEST_OPT_GEMM_VARIANT) == 2 ||
-                                    (K * (in_dtype == MAEST_BF16 ? 2 : 4)) % W2_ROWB != 0))
+    if (epi == MAEST_EPI_ROWDOT && ((N % 256) != 0 || (K * (in_dtype == MAEST_BF16 ? 2 : 4)) % W2_ROWB != 0))
         return -1;
     const bool x3 = in_dtype == MAEST_F32X3;     // fp32 tensors, split-bf16 products (full-line kernel only)
     if (x3) in_dtype = MAEST_F32;
@@ -986,11 +692,11 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
     // grid wins there (measured: one 10 s clip 2.13 -> 1.50 ms, batch 8 2.44 -> 2.23 ms, batch 16 equal).
     // MAEST_OPT_GEMM_MIN_M overrides the threshold (the emulator tests run the big kernels at M = 512).
     const int min_m = option(MAEST_OPT_GEMM_MIN_M);
-    if (M < (min_m > 512 ? min_m : 512) || N < 128 || (N % 128) != 0) return -1;
-    if ((K * (in_dtype == MAEST_BF16 ? 2 : 4)) % G2_ROWB != 0) return -1;
+    if (M < (min_m > 512 ? min_m : 512) || N < 256 || (N % 256) != 0) return -1;
+    if ((K * (in_dtype == MAEST_BF16 ? 2 : 4)) % W2_ROWB != 0) return -1;
     const int variant = option(MAEST_OPT_GEMM_VARIANT);   // experiment switch (A/B timing, tests)
     if (out_dtype == MAEST_SPLIT3_A &&                    // (the split-row output exists in gemm_nt256o_kernel's epilogue only)
-        (variant == 1 || variant == 2 || variant == 3 || !gemm_nt256o_available() || (N % 256) != 0 || (K * 2) % W2_ROWB != 0)) return -1;
+        (variant == 3 || !gemm_nt256o_available())) return -1;
     Gemm256Params p;
     p.A = (const char*)A; p.B = (const char*)B; p.C = C;
     p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
@@ -998,11 +704,7 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
     p.M = M; p.N = N; p.K = K; p.out_dtype = out_dtype; p.epi = epi;
     p.rowdot = rowdot; p.ntok = ntok > 0 ? ntok : 1; p.row0 = 0; p.panel_w = 0;
     p.tiles_m = (M + 255) / 256;
-    // Measured (scratch/gemm_ab.py): the one-workgroup-per-CU 256x256 kernel wins on every ViT shape but the
-    // value-only GELU epilogue; the 256x128 two-per-CU kernel serves N % 256 != 0 and MAEST_GEMM_VARIANT=2.
-    // default: the full-cache-line kernel (fastest on every ViT shape, scratch/gemm_ab.py); MAEST_GEMM_VARIANT
-    // = 1 / 2 select the 64-byte-slice 256x256 kernel / the 256x128 two-per-CU kernel for A/B timing and tests
-    if (variant != 1 && variant != 2 && (N % 256) == 0 && (K * (in_dtype == MAEST_BF16 ? 2 : 4)) % W2_ROWB == 0) {
+    {
         p.tiles_n = N / 256;
         // epilogue form, measured side by side in one run (scratch/gemm_ab.py): the two-pass form wins for bf16
         // outputs by 1-5 %, the four-pass double-buffered form for the fp32 residual outputs by 3-5 %, the
@@ -1062,12 +764,6 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
         }
         return full(p);
     }
-    if (variant != 2 && (N % 256) == 0) {
-        p.tiles_n = N / 256;
-        return in_dtype == MAEST_BF16 ? launch256<bf16_t>(p, stream) : launch256<float>(p, stream);
-    }
-    p.tiles_n = N / H2_TN;
-    return in_dtype == MAEST_BF16 ? launch256x128<bf16_t>(p, stream) : launch256x128<float>(p, stream);
 }
 
 

@@ -675,7 +675,7 @@ class _Engine:
                 # (its first 32-row tile when it honours q_rows, every row otherwise)
                 dao = ops.scatter_head_rows(dao, B, N, HEAD_TOKENS, min(32, N) if s["q_rows"] else N)
                 dqkv = ops.attn_bwd(s["qkv"], s["ao_full"], dao, s["lse"], B, N, blk.attn.scale, q_rows=s["q_rows"], x3=x3m, q_prescaled=qs)
-            elif self.fold_delta and ops.get_option("attn_bwd") != 2:
+            elif self.fold_delta:
                 # delta = rowsum(dO * O) per (clip, head, query) out of the C-tile pass of the GEMM that produces dO
                 dao, delta = ops.gemm_nt_rowdot(dx1_lp, wt_proj, s["ao_full"], N, out_dtype=dt, x3=x3m)
                 dqkv = ops.attn_bwd(s["qkv"], None, dao, s["lse"], B, N, blk.attn.scale, x3=x3m, delta=delta, q_prescaled=qs)

@@ -389,9 +389,6 @@ def case_attention(dev, dtype, B, N, seed=20, spike=False, bf16_tol=3e-2, fwd_to
         close(dq2[:, 768:1536], g[:, 768:1536], rt, at, "attention dK (two-kernel)")
         close(dq2[:, :768], g[:, :768], rt, at, "attention dQ (two-kernel)")
         close(dqkv, dq2.float(), 2e-2, 2e-2, "fused vs two-kernel attention backward")
-        with ops.options(attn_bwd=2):     # the fused form with register-fed tiles (delta computed in flight)
-            dq3 = attn_bwd(qkv.to(dev), out_ref_lp.to(dev), dout.to(dev), ref_lse.detach().contiguous().to(dev), B, N, scale)
-        close(dq3, g, rt, at, "attention backward (fused, register-fed)")
         if N > 256:
             # the default call above took the PERSISTENT form (one workgroup per CU walking its (batch, head) items); the
             # one-workgroup-per-item form against the oracle as well, and the two bit for bit (same sums in the same order)

@@ -26,17 +26,6 @@ def test_emu_gemm_ragged_n_scalar_epilogue(emu, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT_BIG)
-def test_emu_gemm_256_tile_lds_dma_kernel(emu, dtype, gemm_options):
-    """The 64-byte-slice kernels of gemm256.hip: 256x128 two-per-CU (N % 256 != 0) and 256x256 (variant 1)."""
-    # 6 K slices: the 3- / 4-deep rings wrap
-    K = 96 if dtype == torch.float32 else 192
-    gemm_options(gemm_min_m=512)
-    KC.case_gemm(emu, dtype, 512, 128, K, identity=False)   # (orientation is pinned by the small-shape cases)
-    gemm_options(gemm_variant=1)
-    KC.case_gemm(emu, dtype, 512, 256, K, identity=False)
-
-
-@pytest.mark.parametrize("dtype", DT_BIG)
 def test_emu_gemm_256_tile_full_line_stages(emu, dtype, gemm_options):
     """gemm_nt256w_kernel (M >= 512, N % 256 == 0; fp32 / bf16x3 operands, and bf16 under gemm_variant = 3): 128-byte K stages through a 5-buffer unit
     ring (6 stages: the ring wraps)."""

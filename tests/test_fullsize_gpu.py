@@ -127,8 +127,9 @@ def test_mel_frontend_batch256_waveforms():
 
 def test_training_step_batch256_bf16_is_the_path_the_bench_times():
     """The exact code path bench.py times: bf16, batch 256, T = 626, patchout 30 -> M = 74240 token rows, i.e. the
-    full-line 256x256 NT kernel (gemm_nt256w_kernel<bf16>), the 256-tile TN wgrad kernel (gemm_tn256_kernel<bf16>)
-    and the bf16 attention / LayerNorm kernels at their benchmark shapes -- against the fp32 parity-mode step of the
+    one-wave-per-SIMD 256x256 NT kernel (gemm_nt256o_kernel, 16x16x32 MFMAs) with gemm_nt256w_kernel<bf16> on the 128-row tail
+    tiles and the fp32-output patch embedding, the one-wave-per-SIMD wgrad kernel (gemm_tn256o_kernel), the persistent fused attention
+    backward (attn_bwd_fused3_kernel), the LDS-DMA attention forward and the LayerNorm kernels at their benchmark shapes -- against the fp32 parity-mode step of the
     SAME batch and draws, which test_training_step_batch256_is_the_mean_of_its_quarters_fp32 anchors to the oracle.
     Gates are ~3x the deviations observed on MI355X (loss 1.1e-4 relative; per-parameter relative L2 4e-3 .. 7e-3;
     largest single element 0.11 x the gradient's RMS): bf16 operands, fp32 accumulation."""
