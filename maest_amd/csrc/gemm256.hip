@@ -713,9 +713,10 @@ int gemm_nt256_try(const void* A, int64_t lda, const void* B, int64_t ldb, int i
         const int ev = epi == MAEST_EPI_ROWDOT ? 0 : (eopt >= 0 ? eopt : (epi == MAEST_EPI_RESIDUAL ? 1 : 0));
         auto full = [&](Gemm256Params& q) {
             // bf16 operands: the one-wave-per-SIMD kernel (gemm_nt_ow.hip); MAEST_OPT_GEMM_VARIANT = 3 keeps the 8-wave kernel (A/B, tests)
-            // (its 16-bit-output forms; fp32 outputs of bf16 operands -- the patch embedding, the RESIDUAL form -- take the kernel below)
-            if (!x3 && in_dtype == MAEST_BF16 && variant != 3 && gemm_nt256o_available() && epi != MAEST_EPI_RESIDUAL &&
-                (out_dtype == MAEST_BF16 || (out_dtype == MAEST_SPLIT3_A && epi == MAEST_EPI_GELU && aux_out == nullptr)))
+            // (every 16-bit-output form but RESIDUAL; fp32 outputs in the plain and RESIDUAL forms; the other fp32-output forms take the kernel below)
+            if (!x3 && in_dtype == MAEST_BF16 && variant != 3 && gemm_nt256o_available() &&
+                ((out_dtype == MAEST_BF16 && epi != MAEST_EPI_RESIDUAL) || (out_dtype == MAEST_SPLIT3_A && epi == MAEST_EPI_GELU && aux_out == nullptr) ||
+                 (out_dtype == MAEST_F32 && (epi == MAEST_EPI_NONE || epi == MAEST_EPI_RESIDUAL))))
                 return gemm_nt256o_launch(q, stream);
             if (x3) return ev == 1 ? launch256w<float, 1, true>(q, stream) : launch256w<float, 0, true>(q, stream);
             if (ev == 1) return in_dtype == MAEST_BF16 ? launch256w<bf16_t, 1>(q, stream) : launch256w<float, 1>(q, stream);

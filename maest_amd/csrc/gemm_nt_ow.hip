@@ -27,7 +27,7 @@
 //     compare and a branch not taken;
 //   * the first half's MFMAs of a tile take the constant 0 as their C operand (no clearing pass over 256 registers).
 // The C tile leaves through LDS in four 64-row passes with the bias / GELU / GELU' / multiply / row-dot epilogues of gemm256_epi.h; 16-bit
-// outputs only (bf16, split rows) -- fp32 outputs of bf16 operands stay with gemm_nt256w_kernel.  Results: the products of a k32 half are
+// outputs (bf16, split rows) in every form, fp32 outputs in the plain and RESIDUAL forms -- the rest stays with gemm_nt256w_kernel.  Results: the products of a k32 half are
 // rounded together where the 32 x 32 kernels round per 16: last-bit differences in fp32, at most one bf16 ulp in < 2 % of the outputs
 // (tests/kernel_cases.py: _same_products); bit-equal to the 8-wave kernel in the host emulator, whose MFMA twins add term by term.
 // Measured and dropped in round 6: the C tile packed to bf16 registers and stored from inside the next tile's main loop
@@ -520,8 +520,11 @@ int gemm_nt256o_launch(Gemm256Params& p, hipStream_t stream) {
     }
     p.panel_w = pw > 0 && pw < p.tiles_n ? pw : 0;
     if (gelu && p.aux_out == nullptr && p.out_dtype == MAEST_SPLIT3_A) return launch256o<2, 4, 0>(p, stream);
-    // (16-bit outputs only: the fp32-output forms -- the patch embedding once per step, the RESIDUAL form of MAEST_SPLIT_ADD = 0 -- stay with the
-    // eight-wave kernel; with 128 fragment registers owned here their epilogues spilled, round 6)
+    // (fp32 outputs: the plain and the RESIDUAL form only -- what the default evaluation mode's 3 K GEMMs write (bf16x3: qkv in fp32, proj / fc2 with
+    // the fp32 residual add) and the patch embedding; their epilogues spill a few dozen registers around the tile loop with 128 fragment registers owned
+    // here, which costs nothing measurable.  The other fp32-output forms stay with the eight-wave kernel.)
+    if (p.epi == MAEST_EPI_RESIDUAL && !bf) return launch256o<4, 0, 1>(p, stream);
+    if (p.epi == MAEST_EPI_NONE && p.out_dtype == MAEST_F32) return launch256o<4, 0, 0>(p, stream);
     if (gelu && p.aux_out != nullptr && bf) return launch256o<2, 3, 0>(p, stream);
     if (p.epi == MAEST_EPI_MUL && bf) return launch256o<2, 0, 2>(p, stream);
     if (gelu && p.aux_out == nullptr && bf) return launch256o<2, 1, 0>(p, stream);
