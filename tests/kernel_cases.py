@@ -95,7 +95,7 @@ def _same_products(new, old, exact, what, K=64):
         assert float((diff > 0).float().mean()) <= 0.02, f"{what}: {100 * float((diff > 0).float().mean()):.2f} % of the elements differ"
 
 
-def case_gemm_one_wave_per_simd(dev, M, N, K, seed=11, only=None, pair=True, both_bias=False):
+def case_gemm_one_wave_per_simd(dev, M, N, K, seed=11, only=None, pair=True, both_bias=False, exact=None):
     """gemm_nt256o_kernel (gemm_nt_ow.hip: bf16 operands, the default of the 256 x 256 path) against the 8-wave kernel it replaces
     (gemm_variant = 3): the same products summed in the same order and the same epilogue arithmetic -- bit for bit, in every
     epilogue form, ragged last tile row included -- and against the oracle's fp32 matmul."""
@@ -117,7 +117,8 @@ def case_gemm_one_wave_per_simd(dev, M, N, K, seed=11, only=None, pair=True, bot
             new = ops.gemm_nt(a, w, b, **kw)
             with ops.options(gemm_variant=3):
                 old = ops.gemm_nt(a, w, b, **kw)
-            _same_products(new, old, str(dev) == "cpu", f"one-wave-per-SIMD GEMM differs from the 8-wave kernel: {name}, bias {b is not None}", K)
+            _same_products(new, old, str(dev) == "cpu" if exact is None else exact,
+                           f"one-wave-per-SIMD GEMM differs from the 8-wave kernel: {name}, bias {b is not None}", K)
     c = ops.gemm_nt(a, w, bias, out_dtype=torch.float32)
     close(c, ref, 1e-5, 4e-7 * K, "one-wave-per-SIMD GEMM vs fp32 matmul")
     if not pair:
