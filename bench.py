@@ -161,12 +161,14 @@ def _median_times(fn, steps):
 
 
 def _best_thread_count(fn, steps):
-    """The oracle pass `fn` under torch.set_num_threads(c) for c in {16, 32, 64, all host cores}: one warm-up pass, then ONE timed pass
+    """The oracle pass `fn` under torch.set_num_threads(c) for c in {8, 16, 32, 64 (, all host cores if fewer)}: one warm-up pass, then ONE timed pass
     per count (a batch of 8 clips oversubscribes 128 threads: round 5's all-cores figure was below an 8-core run of the reference
     itself), then the best count again until it has `steps` passes.  Returns (median seconds per pass at the best count, best count,
     {count: seconds} of the sweep).  The thread count is left at the best one (the CPU baseline is the last thing the bench does)."""
     ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (16, 32, 64, ncpu) if c <= ncpu})
+    # (all host threads is part of the sweep only up to 64: on the 256-thread hosts of this pool one batch-8 step took 165 s that way against 1.0 s at
+    # 16 threads -- profiles/r06a_bench_default_line.json has that sweep -- and the default line has to finish within minutes)
+    cands = sorted({c for c in (8, 16, 32, 64, ncpu if ncpu <= 64 else 64) if c <= ncpu})
     torch.set_num_threads(cands[0])
     fn(0)                                   # warm-up: allocations, thread pool
     sweep = {}
