@@ -260,6 +260,7 @@ def build_case(args, dev, rank, world, mode, T, B, patchout, reducer_kw=None):
         net._engine.head_tail = False
     if args.serial_kernels:
         net._engine.overlap_wgrad = False
+        net.eval_streams = 1
     if args.no_fold_delta:
         net._engine.fold_delta = False
     mod = (TeacherStudentModule if ts else Module)(net=net, mixup_alpha=0.3)
@@ -401,14 +402,15 @@ def kernel_pass(case, steps):
     out of the timed region: ~400 event records per step cost ~10 % of a step on the host."""
     from maest_amd import ops
     net = case["net"]
-    prev = net._engine.overlap_wgrad
+    prev, prev_streams = net._engine.overlap_wgrad, net.eval_streams
     net._engine.overlap_wgrad = False
+    net.eval_streams = 1          # (evaluation forwards of large batches run as two half batches on two streams: MAEST._eval_forward)
     net.enable_hip_graph(False)
     with ops.KernelTimer(kinds=TIMED_KINDS) as timer:
         for _ in range(steps):
             case["step"]()
     torch.cuda.synchronize()
-    net._engine.overlap_wgrad = prev
+    net._engine.overlap_wgrad, net.eval_streams = prev, prev_streams
     return timer
 
 
@@ -589,6 +591,8 @@ def side_case(args, dev, mode, T, B, patchout, steps, warmup, workload, precisio
            "model_tflops_per_s": round((step_flops - skipped) / (elapsed / steps) / 1e12, 1),
            "model_mfma_frac": round((step_flops - skipped) / (elapsed / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
            "executed_flop_fraction": round(1.0 - skipped / step_flops, 4)}
+    if mode == "infer":
+        out["eval_streams"] = int(case["net"].eval_streams)   # 2: batches of >= MAEST.EVAL_SPLIT_ROWS token rows run as two halves on two streams
     if not args.no_kernel_timing:
         out.update(kernel_report(case, kernel_pass(case, steps), steps, args.precision, with_traffic=False))
     if args.precision != "fp32":

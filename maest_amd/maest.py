@@ -128,6 +128,7 @@ class _Weights:
         self._cache = {}
         self.seen_train = 0     # _Engine._train_forwards at the last clear()
         self.epoch = 0          # bumped whenever every copy is dropped (part of the hipGraph cache key)
+        self.builds = 0         # copies (re)built so far: a forward during which it moves found the cache cold (MAEST._eval_forward)
         # {id(parameter): rows}: parameters whose PLAIN low-precision copy carries `row_scale` on its first `rows` rows (the q rows of
         # the qkv projections in bf16 mode: include/maest_hip.h MAEST_BF16_QS); the transposed copies (dgrad) stay unscaled
         self.scaled_rows = {}
@@ -150,6 +151,7 @@ class _Weights:
             return hit
         src = p.detach()
         w2 = src.reshape(src.shape[0], -1)
+        self.builds += 1
         if not transposed:
             if dtype == torch.float32:
                 out = w2
@@ -187,6 +189,7 @@ class _Weights:
                     break
         if not stale:
             return
+        self.builds += 1
         outs = ops.cast_weights_multi([p.detach() for p in stale], dtype, want=dtype != torch.float32, want_t=with_t,
                                       scaled_rows=[self._srows(p, dtype) for p in stale], row_scale=self.row_scale)
         for p, (o, ot) in zip(stale, outs):
@@ -201,6 +204,7 @@ class _Weights:
         key = lambda p: (id(p), "split3b", False, 0)
         stale = [p for p in params if self._fresh(key(p), p) is None]
         if stale:
+            self.builds += 1
             outs = ops.cast_weights_multi([p.detach() for p in stale], ops.SPLIT3, want=True, want_t=False)
             for p, (o, _) in zip(stale, outs):
                 self._cache[key(p)] = (p._version, o, weakref.ref(p))
@@ -212,6 +216,7 @@ class _Weights:
         bkey = lambda b: (id(b), "scaled-bias", False, rows, self.row_scale)
         stale = [b for b in biases if self._fresh(bkey(b), b) is None]
         if stale:
+            self.builds += 1
             outs = ops.cast_weights_multi([b.detach().reshape(-1, 1) for b in stale], torch.float32, want=True, want_t=False,
                                           scaled_rows=[rows] * len(stale), row_scale=self.row_scale)
             for b, (o, _) in zip(stale, outs):
@@ -221,6 +226,7 @@ class _Weights:
     def clear(self):
         self._cache.clear()
         self.epoch += 1
+        self.builds += 1
 
 
 def _split_k(n_out: int, k_out: int, tokens: int) -> int:
@@ -333,6 +339,12 @@ class _Engine:
 
     def _side_stream(self, dev):
         key = str(dev)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
+
+    def _eval_stream(self, dev):
+        key = "eval:" + str(dev)
         if key not in self._side:
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
@@ -821,6 +833,7 @@ class MAEST(nn.Module):
         self._param_names = None
         self._tok_cache = {}
         self.hip_graph = False
+        self.eval_streams = int(os.environ.get("MAEST_EVAL_STREAMS", "2"))     # see _eval_forward
         self._toffset_choices = 1
         self._graphs = {}
         self._param_list = None
@@ -1076,8 +1089,48 @@ class MAEST(nn.Module):
                         and _specmask is None):
                     outs = self._graph_forward(x3, dt, kw)
                 else:
-                    outs, _ = self._engine.forward(x3, dt, **kw)
+                    outs = self._eval_forward(x3, dt, kw)
         return outs
+
+    # Rows of a batch (clips x tokens) from which an eager evaluation forward runs as two half batches on two streams (below, ~1.5 rounds of
+    # 256 x 256 tiles per half at N = 768, the split costs more launches than its tails give back)
+    EVAL_SPLIT_ROWS = 98304
+
+    def _eval_forward(self, x3, dt, kw):
+        """Eager evaluation forward.  A large batch runs as TWO HALF BATCHES ON TWO STREAMS: every kernel of the forward is per clip or per
+        token, so the halves are independent and their results are the full batch's, bit for bit; what the second stream buys is the tail of
+        every persistent GEMM launch -- 1680 tiles of 256 x 256 over 256 CUs are 6.56 rounds, the seventh runs on 144 CUs (proj / fc2 at 256
+        clips x 560 tokens; 3.9 % of the GEMM time over the four linears) -- which the other half's kernels now fill: -2.0 ... -3.3 % on the
+        inference pass in every numeric mode (profiles/r06_eval_two_streams.txt).  MAEST_EVAL_STREAMS = 1 (or model.eval_streams = 1): one
+        stream.  The first half runs on the caller's stream; the second starts beside it when the operand copies of the weights are warm, and
+        behind it when this very forward had to rebuild them (they are made on the caller's stream)."""
+        eng = self._engine
+        B = x3.shape[0]
+        rows = B * (2 + int(kw["tok_ft"].shape[0]))
+        if (self.eval_streams < 2 or not x3.is_cuda or B < 2 or rows < self.EVAL_SPLIT_ROWS or kw.get("perm") is not None
+                or kw.get("stripes") is not None or torch.cuda.is_current_stream_capturing()):
+            return eng.forward(x3, dt, **kw)[0]
+        dev = x3.device
+        wc = eng.w_f16 if kw.get("f16") else eng.w
+        cur, side = torch.cuda.current_stream(dev), eng._eval_stream(dev)
+        start = torch.cuda.Event()
+        start.record(cur)                      # the input (and everything the caller queued before it) is ready
+        h = (B + 1) // 2
+        xa, xb = x3[:h], x3[h:]
+        built = wc.builds
+        outs_a, _ = eng.forward(xa, dt, **kw)
+        if wc.builds != built:
+            side.wait_stream(cur)              # cold cache: the copies were made by kernels of the first half's stream
+        else:
+            side.wait_event(start)
+        with torch.cuda.stream(side):
+            outs_b, _ = eng.forward(xb, dt, **kw)
+        xb.record_stream(side)                 # (allocated on the caller's stream, read on the other one)
+        cur.wait_stream(side)
+        for o in outs_b:
+            if o is not None:
+                o.record_stream(cur)
+        return tuple(None if a is None else torch.cat([a, b]) for a, b in zip(outs_a, outs_b))
 
     # ---- hipGraph-captured inference forward (north_star / BASELINE configs[4]) ---------------------------
     def enable_hip_graph(self, on: bool = True):

@@ -418,6 +418,39 @@ def test_model_without_qkv_bias(precision):
     assert torch.equal(la, lb)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "fp16"])
+def test_large_eval_batches_on_two_streams_equal_the_single_stream_forward(precision):
+    """MAEST._eval_forward: an eager evaluation forward of >= EVAL_SPLIT_ROWS token rows runs as two half batches on two streams (the
+    second stream fills the tails of the first one's persistent GEMM launches).  Every kernel is per clip / per token, so the result is
+    the one-stream forward's bit for bit -- with cold operand copies (the very first forward, and the first one after a parameter update:
+    the copies are made on the caller's stream and the second half must wait for them), with warm ones, with an odd batch, and when the
+    caller itself is on a side stream."""
+    net = build("discogs-maest-10s-pw-129e", 625, precision=precision).eval()
+    assert net.eval_streams == 2
+    net.EVAL_SPLIT_ROWS = 8 * 562          # (a small batch takes the path: the instance attribute shadows the class constant)
+    x = randn((9, 96, 626), 500).to(DEV)
+    with torch.no_grad():
+        cold = tuple(o.clone() for o in net(x))                       # first forward ever: cold cache, two streams
+        warm = tuple(o.clone() for o in net(x))
+        net.eval_streams = 1
+        one = tuple(o.clone() for o in net(x))
+        net.eval_streams = 2
+        for a, b, c in zip(cold, warm, one):
+            assert torch.equal(a, c) and torch.equal(b, c)
+        net.head[1].bias.add_(1.0)                                     # parameter update: stale copies are rebuilt inside the next forward
+        upd = net(x)[0]
+        assert torch.allclose(upd, one[0] + 1.0, atol=1e-5)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            y = x * 1.0                                               # produced on the caller's side stream, right before the call
+            on_side = net(y)[0]
+        torch.cuda.current_stream().wait_stream(s)
+        assert torch.equal(on_side, upd)
+        small = net(x[:3])[0]                                         # below the row count: one stream
+        assert torch.equal(small, upd[:3])
+
+
 def test_hip_graph_captured_inference_is_bit_identical():
     """north_star configs[4]: the eval forward replayed from a HIP graph equals the eager launches bit for bit,
     for successive inputs, and is re-captured after a parameter update."""
