@@ -579,13 +579,20 @@ def side_case(args, dev, mode, T, B, patchout, steps, warmup, workload, precisio
     # two: ADVICE r5), unless it is more than 25 % slower than the second -- the signature of the allocator stall a side case can catch
     # right after another configuration released tens of GB to the caching allocator (363 ms/step against a kernel sum of 83 once in ~7
     # default runs: profiles/r05d_default_line_boxes.txt) -- in which case the second is reported and `bracket_used` says so.
+    def alloc_counts():
+        st = torch.cuda.memory_stats(dev)
+        return [int(st.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")]
+    a0 = alloc_counts()
     brackets = [timed_steps(case["step"], steps, warmup, 1, dev), timed_steps(case["step"], steps, 0, 1, dev)]
+    a1 = alloc_counts()
     used = 1 if brackets[0] > 1.25 * brackets[1] else 0
     elapsed = brackets[used]
     step_flops, skipped, _, _ = flop_counts(case, args.precision)
     out = {"workload": workload, "value": round(B * steps / elapsed, 2), "unit": "clips/s", "steps": steps,
            "brackets_ms_per_step": [round(b / steps * 1e3, 3) for b in brackets],
            "bracket_used": "first" if used == 0 else "second (the first one was > 25 % slower: allocator stall)",
+           # hipMalloc / hipFree calls and allocator retries of the caching allocator over the warm-up and both brackets (a hipFree drains the device)
+           "device_alloc_free_retry": [a1[i] - a0[i] for i in range(3)],
            "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "per_gpu_batch": B, "mel": [96, T],
            "s_patchout_t": patchout, "tokens": case["N"], "dtype": args.precision,
            "model_tflops_per_s": round((step_flops - skipped) / (elapsed / steps) / 1e12, 1),

@@ -249,6 +249,35 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int, out=None, 
     return dw
 
 
+# The engines' extra streams, ONE set per device and process (every engine of a device shares them).  torch hands out the 32 streams of
+# its pool round robin and the runtime multiplexes them onto a few hardware queues: which pool entry an engine's weight-gradient stream is
+# decides whether it has a queue of its own or sits behind the caller's stream -- where the narrow (108 - 126 workgroups) wgrad launches run
+# one after the other INSTEAD of beside the dgrad chain.  With a stream per engine, the fifth model of a process lost 12 % of its training
+# step to exactly that (bench.py's 30 s training case behind three evaluation cases that had each taken a stream: 89.2 ms against 79.6,
+# profiles/r06_stream_identity.txt).  All three roles are created together, on first use, in a fixed order.
+# Measured per pool entry (scratch/r06_stream_identity.py: a 108-workgroup wgrad on pool stream k beside an NT GEMM on the default stream,
+# 503 + 281 us alone): 575 - 600 us together on entries 0 - 5, 7 - 9, 11; 755 - 786 us -- nearly serial -- on entries 6 and 10, the ones that
+# land on the default stream's hardware queue under this runtime (four queues, entries >= 4 dealt round robin).  Entries with
+# index >= 4 and index % 4 == 2 are therefore passed over (the index is the pool stream's id >> 5); a runtime that maps differently loses nothing.
+_ENGINE_STREAMS = {}
+
+
+def _pool_stream(dev):
+    for _ in range(8):
+        s = torch.cuda.Stream(device=dev)
+        k = int(s.stream_id) >> 5
+        if not (k >= 4 and k % 4 == 2):
+            break
+    return s
+
+
+def _engine_stream(dev, role):
+    key = str(dev)
+    if key not in _ENGINE_STREAMS:
+        _ENGINE_STREAMS[key] = {r: _pool_stream(dev) for r in ("side", "comm", "eval")}
+    return _ENGINE_STREAMS[key][role]
+
+
 class _Engine:
     """Forward / backward of the whole network as a fixed sequence of C-ABI kernel launches."""
 
@@ -288,7 +317,6 @@ class _Engine:
         self.split_add_eval = int(os.environ.get("MAEST_SPLIT_ADD_EVAL", os.environ.get("MAEST_SPLIT_ADD", "1")))
         self._weights_dirty = False
         self._train_forwards = 0         # training-mode forwards so far: an operand-copy cache made before the latest one is stale (see _forward)
-        self._side = {}
         # Training steps in flight: the host enqueues a step in ~10 ms, the GPU runs it in ~47, and nothing in a bare training loop makes
         # the host wait -- so it runs ahead, and blocks the caching allocator is asked for while their previous use (recorded on the side
         # stream) is still queued cannot be recycled: 60 unsynchronised steps took the reserved pool from 90 to 247 GB in 545 hipMallocs,
@@ -338,22 +366,13 @@ class _Engine:
         return self._layout
 
     def _side_stream(self, dev):
-        key = str(dev)
-        if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=dev)
-        return self._side[key]
+        return _engine_stream(dev, "side")
 
     def _eval_stream(self, dev):
-        key = "eval:" + str(dev)
-        if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=dev)
-        return self._side[key]
+        return _engine_stream(dev, "eval")
 
     def _comm_stream(self, dev):
-        key = "comm:" + str(dev)
-        if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=dev)
-        return self._side[key]
+        return _engine_stream(dev, "comm")
 
     def _gemm_form(self, shared: bool, wgs: int = 256):
         """The bf16 NT GEMM's launch form for a pass (csrc/gemm_nt_ow.hip): persistent -- one workgroup per CU walking its tiles, the next
