@@ -578,7 +578,9 @@ def side_case(args, dev, mode, T, B, patchout, steps, warmup, workload, precisio
     # Two brackets of K timed steps; `value` is the FIRST one, like the headline's single bracket (round 5 reported the faster of the
     # two: ADVICE r5), unless it is more than 25 % slower than the second -- the signature of the allocator stall a side case can catch
     # right after another configuration released tens of GB to the caching allocator (363 ms/step against a kernel sum of 83 once in ~7
-    # default runs: profiles/r05d_default_line_boxes.txt) -- in which case the second is reported and `bracket_used` says so.
+    # default runs: profiles/r05d_default_line_boxes.txt) -- in which case the second is reported and `bracket_used` says so.  (The 30 s training
+    # cases warm up for 6 steps: with four steps in flight the pool of a fresh 100 GB configuration is still growing after 2 -- four of five
+    # round-6 boxes caught the stall in train30s's first bracket, profiles/r06_default_line_boxes.txt.)
     def alloc_counts():
         st = torch.cuda.memory_stats(dev)
         return [int(st.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")]
@@ -812,14 +814,14 @@ def main():
             except Exception as e:  # pragma: no cover
                 out["infer_fp16"] = {"error": repr(e)}
             try:
-                out["ts"] = side_case(args, dev, "ts", 1876, 128, 90, 10, 2,
+                out["ts"] = side_case(args, dev, "ts", 1876, 128, 90, 10, 6,
                                       "discogs-maest-30s-pw-73e-ts teacher-student training step (BASELINE configs[4], per-GPU "
                                       "shape): batch 128 x 30 s waveforms -> HIP log-mel on the fly -> mixup -> fwd (519-way "
                                       "separated heads) -> (BCE + BCE)/2 -> bwd -> AdamW", graph_too=True)
             except Exception as e:  # pragma: no cover
                 out["ts"] = {"error": repr(e)}
             try:
-                out["train30s"] = side_case(args, dev, "train", 1876, 128, 90, 10, 2,
+                out["train30s"] = side_case(args, dev, "train", 1876, 128, 90, 10, 6,
                                             "maest_30s_from_passt_pretrain-shaped training step (BASELINE configs[3], the "
                                             "per-GPU shape of global batch 1024 over 8 GPUs): batch 128 x (96 x 1876), "
                                             "s_patchout_t 90, N = 875 tokens")
