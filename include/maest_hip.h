@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MAEST_ABI_VERSION 7
+#define MAEST_ABI_VERSION 8
 
 #define MAEST_OK 0
 #define MAEST_ERR_INVALID 1 /* bad argument (shape / alignment / dtype) */
@@ -269,6 +269,12 @@ int maest_scatter_head_rows(const void* src, int clips, int n_tok, int n_head, i
 int maest_patch_im2col(const void* x, int x_dtype, int B, int F, int T, const int32_t* perm, const float* lam,
                        const int32_t* tok_ft, int P, const int32_t* t_stripes, int n_t,
                        const int32_t* f_stripes, int n_f, void* out, int dtype, void* stream);
+/* The same with the convolution's stride as an argument (ABI 8): patch origin (stride_f * f, stride_t * t).  The reference takes the
+ * strides as constructor arguments (get_maest(stride_f=, stride_t=): models/maest.py:1505-1507, 1537; PatchEmbed: models/maest.py:214-241) and
+ * only warns that the checkpoints were trained with (10, 10); maest_patch_im2col is this entry with (10, 10). */
+int maest_patch_im2col_strided(const void* x, int x_dtype, int B, int F, int T, int stride_f, int stride_t, const int32_t* perm,
+                               const float* lam, const int32_t* tok_ft, int P, const int32_t* t_stripes, int n_t,
+                               const int32_t* f_stripes, int n_f, void* out, int dtype, void* stream);
 
 /* ---- K5 + K6: positional add + token assembly (models/maest.py:645-675, 769, 785-796) ------------
  * patches: fp32 [B*P, 768] (conv output incl. bias); x0: fp32 [B, 2 + P, 768]

@@ -46,6 +46,7 @@ SIGNATURES = {
     "maest_gather_head_rows": [_P, _I, _I, _I, _I, _P, _P],
     "maest_scatter_head_rows": [_P, _I, _I, _I, _I, _I, _P, _P],
     "maest_patch_im2col": [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P],
+    "maest_patch_im2col_strided": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "maest_token_assemble": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P, _P],
     "maest_token_assemble_bwd": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "maest_head_pool_fwd": [_P, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P],
@@ -70,7 +71,7 @@ SIGNATURES = {
 }
 FORM_GEMM_NT_OW, FORM_GEMM_TN_OW, FORM_ATTN_FWD_PW = 1, 2, 4
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 OPTIONS = {"gemm_min_m": 0, "gemm_variant": 1, "gemm_epilogue": 2, "attn_bwd": 3, "ln_bwd_blocks": 4, "gemm_tail": 5, "attn_fwd": 6, "attn_fwd_waves": 7,
            "tn_reduce": 8, "gemm_wgs": 9, "gemm_panel": 10}
 

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const XT* __restrict_
                                                            const int32_t* __restrict__ tok_ft, int P,
                                                            const int32_t* __restrict__ t_stripes, int n_t,
                                                            const int32_t* __restrict__ f_stripes, int n_f,
-                                                           void* __restrict__ out, int dtype) {
+                                                           void* __restrict__ out, int dtype, int stride_f, int stride_t) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)B * P * PE_K;
     if (gid >= total) return;
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const XT* __restrict_
     const int j = (int)(prow % P);
     const int b = (int)(prow / P);
     const int f = tok_ft[2 * j];
-    const int tcol = tok_ft[2 * j + 1] * PE_S;
-    const int frow = f * PE_S + ky;
+    const int tcol = tok_ft[2 * j + 1] * stride_t;
+    const int frow = f * stride_f + ky;
     const bool masked = n_t + n_f > 0;
     const XT* src = x + ((int64_t)b * F + frow) * T + tcol;
     float v[16];
@@ -290,12 +290,13 @@ __global__ __launch_bounds__(256) void melfile_assemble_kernel(const uint16_t* _
 
 using namespace maest;
 
-extern "C" int maest_patch_im2col(const void* x, int x_dtype, int B, int F, int T, const int32_t* perm, const float* lam,
-                                  const int32_t* tok_ft, int P, const int32_t* t_stripes, int n_t,
-                                  const int32_t* f_stripes, int n_f, void* out, int dtype, void* stream) {
+extern "C" int maest_patch_im2col_strided(const void* x, int x_dtype, int B, int F, int T, int stride_f, int stride_t, const int32_t* perm,
+                                          const float* lam, const int32_t* tok_ft, int P, const int32_t* t_stripes, int n_t,
+                                          const int32_t* f_stripes, int n_f, void* out, int dtype, void* stream) {
     MAEST_REQUIRE(x && out && tok_ft, "maest_patch_im2col: null pointer");
     MAEST_REQUIRE(B > 0 && P > 0, "maest_patch_im2col: bad shape B=%d P=%d", B, P);
     MAEST_REQUIRE(F >= PE_K && T >= PE_K, "maest_patch_im2col: input %dx%d smaller than a patch", F, T);
+    MAEST_REQUIRE(stride_f > 0 && stride_t > 0, "maest_patch_im2col: bad patch stride (%d, %d)", stride_f, stride_t);
     MAEST_REQUIRE((perm == nullptr) == (lam == nullptr), "maest_patch_im2col: perm and lam go together");
     MAEST_REQUIRE(dtype == MAEST_F32 || dtype == MAEST_BF16, "maest_patch_im2col: bad dtype");
     MAEST_REQUIRE(x_dtype == MAEST_F32 || x_dtype == MAEST_F16, "maest_patch_im2col: input must be fp32 or fp16");
@@ -305,11 +306,17 @@ extern "C" int maest_patch_im2col(const void* x, int x_dtype, int B, int F, int 
     const dim3 grid((unsigned)((total + 255) / 256));
     if (x_dtype == MAEST_F16)
         hipLaunchKernelGGL(patch_im2col_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, B,
-                           F, T, perm, lam, tok_ft, P, t_stripes, n_t, f_stripes, n_f, out, dtype);
+                           F, T, perm, lam, tok_ft, P, t_stripes, n_t, f_stripes, n_f, out, dtype, stride_f, stride_t);
     else
         hipLaunchKernelGGL(patch_im2col_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, B, F,
-                           T, perm, lam, tok_ft, P, t_stripes, n_t, f_stripes, n_f, out, dtype);
+                           T, perm, lam, tok_ft, P, t_stripes, n_t, f_stripes, n_f, out, dtype, stride_f, stride_t);
     return check_launch("maest_patch_im2col");
+}
+
+extern "C" int maest_patch_im2col(const void* x, int x_dtype, int B, int F, int T, const int32_t* perm, const float* lam,
+                                  const int32_t* tok_ft, int P, const int32_t* t_stripes, int n_t,
+                                  const int32_t* f_stripes, int n_f, void* out, int dtype, void* stream) {
+    return maest_patch_im2col_strided(x, x_dtype, B, F, T, PE_S, PE_S, perm, lam, tok_ft, P, t_stripes, n_t, f_stripes, n_f, out, dtype, stream);
 }
 
 extern "C" int maest_token_assemble(const float* patches, const float* cls_token, const float* dist_token,

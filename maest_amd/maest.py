@@ -439,7 +439,7 @@ class _Engine:
             w3 = {(i, n): w3[4 * i + j] for i in range(len(m.blocks)) for j, n in enumerate(("qkv", "proj", "fc1", "fc2"))}
 
         t_str, f_str = stripes if stripes is not None else (None, None)
-        cols = ops.patch_im2col(x3, tok_ft, dt, perm=perm, lam=lam, t_stripes=t_str, f_stripes=f_str)
+        cols = ops.patch_im2col(x3, tok_ft, dt, perm=perm, lam=lam, t_stripes=t_str, f_stripes=f_str, stride=m.patch_embed.stride)
         patches = gemm_nt(cols, W.get(m.patch_embed.proj.weight, dt), m.patch_embed.proj.bias,
                               out_dtype=torch.float32)
         Tt = m.time_new_pos_embed.shape[-1]
@@ -829,8 +829,6 @@ class MAEST(nn.Module):
             self.labels = discogs_519labels
 
         stride = tuple(stride) if isinstance(stride, (tuple, list)) else (stride, stride)
-        if stride != (10, 10):
-            raise NotImplementedError("maest_amd kernels are specialised for patch stride (10, 10)")
         self.patch_embed = PatchEmbed(img_size=self.img_size, patch_size=patch_size, stride=stride,
                                       in_chans=in_chans, embed_dim=embed_dim)
         self.num_patches = self.patch_embed.num_patches
@@ -1040,6 +1038,13 @@ class MAEST(nn.Module):
             raise Exception(f"expected input of shape [B, 1, F, T], got {tuple(x.shape)}")
         B, _, F, T = x.shape
         Tp = self._check_patches_fit(T)
+        Fp = (F - PATCH) // self.patch_embed.stride[0] + 1
+        Fg = self.freq_new_pos_embed.shape[2]
+        if Fp != Fg:
+            # the reference adds the whole frequency table to the patch grid (models/maest.py:676: x + self.freq_new_pos_embed), which
+            # broadcasts only when the two agree: torch's error, raised before any device work.  (PatchEmbed.grid_size is img // stride,
+            # models/maest.py:234, the convolution yields (F - 16) // stride + 1 rows: at 96 bands they agree for strides 10, 11, 13 .. 16.)
+            raise RuntimeError(f"The size of tensor a ({Fp}) must match the size of tensor b ({Fg}) at non-singleton dimension 2")
         if not x.is_cuda and not ops._lib.host_emulation():
             raise ops._lib.MaestHipError(
                 f"maest_amd runs on MI355X only: input is on {x.device}. Move the model and the input to a HIP "
@@ -1055,10 +1060,6 @@ class MAEST(nn.Module):
                                   # through them fails loudly on outputs that do not require grad); a train() forward raises, see _resolve_precision
         dt = self._compute_dtype(need_grad)
 
-        Fp = (F - PATCH) // self.patch_embed.stride[0] + 1
-        if Fp > self.freq_new_pos_embed.shape[2]:
-            raise Exception(f"{Fp} frequency patches exceed the frequency positional table "
-                            f"{tuple(self.freq_new_pos_embed.shape)}")
         tok_key = (Fp, Tp, str(x3.device))
         # how many time-table offsets this call could have drawn (1: none drawn / pinned); the train-graph cache looks at it
         self._toffset_choices = (1 + self.time_new_pos_embed.shape[-1] - Tp) if (self.training and _patchout is None) else 1

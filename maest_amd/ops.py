@@ -361,10 +361,11 @@ def scatter_head_rows(xc: torch.Tensor, clips: int, n_tok: int, n_head: int, n_p
     return out
 
 
-def patch_im2col(x: torch.Tensor, tok_ft: torch.Tensor, dtype, perm=None, lam=None, t_stripes=None, f_stripes=None):
+def patch_im2col(x: torch.Tensor, tok_ft: torch.Tensor, dtype, perm=None, lam=None, t_stripes=None, f_stripes=None, stride=(10, 10)):
     """x fp32 or fp16 [B, F, T], tok_ft int32 [P, 2] -> im2col operand [B*P, 256] (SpecMasking stripes, mixup and
     patchout fused; a float16 batch -- what the reference's loader hands out, discogs/dataset.py:58-67 -- is widened in
-    the load).  t_stripes / f_stripes: int32 [B, n, 2] = (start, width) per clip, or None."""
+    the load).  t_stripes / f_stripes: int32 [B, n, 2] = (start, width) per clip, or None.  stride: (frequency, time) step of the
+    16 x 16 patches (models/maest.py:214-241)."""
     _chk(x, tok_ft, perm, lam, t_stripes, f_stripes)
     assert x.dtype in (torch.float32, torch.float16) and x.dim() == 3 and tok_ft.dtype == torch.int32
     B, F, T = x.shape
@@ -377,8 +378,8 @@ def patch_im2col(x: torch.Tensor, tok_ft: torch.Tensor, dtype, perm=None, lam=No
         assert f_stripes.dtype == torch.int32 and f_stripes.dim() == 3 and f_stripes.shape[0] == B and f_stripes.shape[2] == 2
         n_f = int(f_stripes.shape[1])
     out = torch.empty((B * P, 256), dtype=dtype, device=x.device)
-    call("maest_patch_im2col", _p(x), F16 if x.dtype == torch.float16 else F32, B, F, T, _p(perm), _p(lam), _p(tok_ft), P, _p(t_stripes) if n_t else None, n_t,
-         _p(f_stripes) if n_f else None, n_f, _p(out), DT[dtype], _s(x))
+    call("maest_patch_im2col_strided", _p(x), F16 if x.dtype == torch.float16 else F32, B, F, T, int(stride[0]), int(stride[1]), _p(perm), _p(lam),
+         _p(tok_ft), P, _p(t_stripes) if n_t else None, n_t, _p(f_stripes) if n_f else None, n_f, _p(out), DT[dtype], _s(x))
     return out
 
 

@@ -140,11 +140,12 @@ ARCH_DEFAULT_T = {
 }
 
 
-def state_dict_spec(img_t: int, n_classes: int = 400, img_f: int = 96, stride: int = 10):
+def state_dict_spec(img_t: int, n_classes: int = 400, img_f: int = 96, stride=10):
     """Ordered (name, shape) list of the MAEST state_dict (order is the
-    reference's ``state_dict()`` order, probed)."""
+    reference's ``state_dict()`` order, probed).  stride: int or (frequency, time)."""
     D = EMBED_DIM
-    gf, gt = img_f // stride, img_t // stride       # PatchEmbed.grid_size (maest.py:234)
+    sf, st = (stride, stride) if isinstance(stride, int) else stride
+    gf, gt = img_f // sf, img_t // st               # PatchEmbed.grid_size (maest.py:234)
     spec = [
         ("cls_token", (1, 1, D)), ("dist_token", (1, 1, D)), ("new_pos_embed", (1, 2, D)),
         ("freq_new_pos_embed", (1, D, gf, 1)), ("time_new_pos_embed", (1, D, 1, gt)),
@@ -170,14 +171,14 @@ def state_dict_spec(img_t: int, n_classes: int = 400, img_f: int = 96, stride: i
 
 
 def make_state_dict(img_t: int, n_classes: int = 400, seed: int = 1234,
-                    std: float = 0.02) -> Dict[str, torch.Tensor]:
+                    std: float = 0.02, stride=10) -> Dict[str, torch.Tensor]:
     """Deterministic synthetic weights: ``numpy.random.Generator(PCG64(seed))`` filling the
     state_dict in key order: N(0, std^2) everywhere, LayerNorm gains
     1 + N(0, std^2).  Independent of torch's RNG so the GPU box regenerates the same
     tensors that the golden fixtures were captured with."""
     rng = np.random.Generator(np.random.PCG64(seed))
     sd = {}
-    for name, shape in state_dict_spec(img_t, n_classes):
+    for name, shape in state_dict_spec(img_t, n_classes, stride=stride):
         a = rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
         if (".norm" in name or name.startswith("norm.") or name.startswith("head.0.")) \
                 and name.endswith("weight"):
@@ -221,10 +222,11 @@ def prepare_input(x: torch.Tensor, img_size: Tuple[int, int],
 # --------------------------------------------------------------------------------------
 # ViT pieces
 # --------------------------------------------------------------------------------------
-def patch_embed(x: torch.Tensor, sd) -> torch.Tensor:
+def patch_embed(x: torch.Tensor, sd, stride=10) -> torch.Tensor:
     """``PatchEmbed.forward`` with flatten=False (maest.py:243-256, 506-513):
-    Conv2d(1, 768, k=16, s=10) -> ``[B, 768, 9, T']``."""
-    return F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=10)
+    Conv2d(1, 768, k=16, s=10) -> ``[B, 768, 9, T']``; the stride is a constructor argument (maest.py:214-241; every published
+    architecture uses 10)."""
+    return F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=stride)
 
 
 def tokens_from_patches(p: torch.Tensor, sd, toffset: int = 0,
@@ -288,9 +290,9 @@ def block(x: torch.Tensor, sd, i: int, return_self_attention: bool = False) -> t
 
 def forward_features(x4: torch.Tensor, sd, transformer_block: int = -1,
                      return_self_attention: bool = False, toffset: int = 0,
-                     t_keep=None, f_keep=None, probes: Optional[list] = None, u_keep=None):
+                     t_keep=None, f_keep=None, probes: Optional[list] = None, u_keep=None, stride=10):
     """``MAEST.forward_features`` (maest.py:634-829)."""
-    x = tokens_from_patches(patch_embed(x4, sd), sd, toffset, t_keep, f_keep, u_keep)
+    x = tokens_from_patches(patch_embed(x4, sd, stride), sd, toffset, t_keep, f_keep, u_keep)
     if transformer_block == -1:
         for i in range(DEPTH):
             x = block(x, sd, i)
@@ -309,11 +311,11 @@ def forward_features(x4: torch.Tensor, sd, transformer_block: int = -1,
 def forward(x: torch.Tensor, sd, img_size: Tuple[int, int], transformer_block: int = -1,
             return_self_attention: bool = False, melspectrogram_input: bool = False,
             distilled_type: str = "mean", toffset: int = 0, t_keep=None, f_keep=None,
-            probes: Optional[list] = None, u_keep=None):
+            probes: Optional[list] = None, u_keep=None, stride=10):
     """``MAEST.forward`` (maest.py:831-933)."""
     x4 = prepare_input(x, img_size, melspectrogram_input)
     out = forward_features(x4, sd, transformer_block, return_self_attention,
-                           toffset, t_keep, f_keep, probes, u_keep)
+                           toffset, t_keep, f_keep, probes, u_keep, stride)
     if transformer_block != -1:
         return None, out
     cls, dist = out
@@ -345,7 +347,7 @@ def mixup(x: torch.Tensor, perm: torch.Tensor, lam: torch.Tensor) -> torch.Tenso
 
 
 def training_loss(x: torch.Tensor, y: torch.Tensor, sd, perm=None, lam=None, toffset: int = 0,
-                  t_keep=None, f_keep=None, y_teacher: Optional[torch.Tensor] = None):
+                  t_keep=None, f_keep=None, y_teacher: Optional[torch.Tensor] = None, stride=10):
     """``Module.training_step`` / ``TeacherStudentModule.training_step`` given the drawn
     (perm, lam, toffset, t_keep).  Returns (loss, logits...)."""
     if perm is not None:
@@ -355,10 +357,10 @@ def training_loss(x: torch.Tensor, y: torch.Tensor, sd, perm=None, lam=None, tof
             y_teacher = mixup(y_teacher, perm, lam)
     img = (x.shape[-2], x.shape[-1])
     if y_teacher is None:
-        logits, _ = forward(x, sd, img, toffset=toffset, t_keep=t_keep, f_keep=f_keep)
+        logits, _ = forward(x, sd, img, toffset=toffset, t_keep=t_keep, f_keep=f_keep, stride=stride)
         return F.binary_cross_entropy_with_logits(logits, y), logits
     lc, ld, _ = forward(x, sd, img, distilled_type="separated", toffset=toffset,
-                        t_keep=t_keep, f_keep=f_keep)
+                        t_keep=t_keep, f_keep=f_keep, stride=stride)
     loss = (F.binary_cross_entropy_with_logits(lc, y)
             + F.binary_cross_entropy_with_logits(ld, y_teacher)) / 2
     return loss, lc, ld

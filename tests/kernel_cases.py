@@ -448,11 +448,12 @@ def case_attention_head_rows(dev, dtype, B, N, seed=25):
 
 
 # ----------------------------------------------------------------------------- patch embed pieces
-def case_patch_embed(dev, dtype, B, T, patchout=0, mix=False, seed=30, masked=False):
+def case_patch_embed(dev, dtype, B, T, patchout=0, mix=False, seed=30, masked=False, stride=(10, 10)):
+    """stride: (frequency, time) step of the 16 x 16 patches (models/maest.py:214-241; every published architecture: (10, 10))."""
     Fdim = 96
     x = rnd((B, Fdim, T), seed)
-    Tp = (T - 16) // 10 + 1
-    Fp = 9
+    Tp = (T - 16) // stride[1] + 1
+    Fp = (Fdim - 16) // stride[0] + 1
     rng = np.random.Generator(np.random.PCG64(seed + 1))
     keep = np.sort(rng.permutation(Tp)[: Tp - patchout]).astype(np.int32) if patchout else None
     Tk = Tp - patchout
@@ -475,29 +476,29 @@ def case_patch_embed(dev, dtype, B, T, patchout=0, mix=False, seed=30, masked=Fa
         perm = torch.from_numpy(rng.permutation(B).astype(np.int32))
         lam = torch.from_numpy(rng.random(B).astype(np.float32))
         xm = O.mixup(xm, perm.long(), lam)
-    cols = ops.patch_im2col(x.to(dev), tok_dev, dtype,
+    cols = ops.patch_im2col(x.to(dev), tok_dev, dtype, stride=stride,
                             perm=None if perm is None else perm.to(dev), lam=None if lam is None else lam.to(dev),
                             t_stripes=None if t_str is None else t_str.to(dev), f_stripes=None if f_str is None else f_str.to(dev))
     if masked and not mix and dtype == torch.float32:
         # the fused predicate must equal the stand-alone kernel (maest_spec_mask) bit for bit
         xs = ops.spec_mask_(x.clone().to(dev), t_str.to(dev), f_str.to(dev))
-        cols2 = ops.patch_im2col(xs, tok_dev, dtype)
+        cols2 = ops.patch_im2col(xs, tok_dev, dtype, stride=stride)
         assert torch.equal(cols, cols2), "fused SpecMasking differs from spec_mask_ + im2col"
     # a float16 batch (what the reference's loader hands out, discogs/dataset.py:58-67) widened inside the load must
     # equal the same values passed as fp32, bit for bit
     xh = x.half()
-    kw = dict(perm=None if perm is None else perm.to(dev), lam=None if lam is None else lam.to(dev),
+    kw = dict(stride=stride, perm=None if perm is None else perm.to(dev), lam=None if lam is None else lam.to(dev),
               t_stripes=None if t_str is None else t_str.to(dev), f_stripes=None if f_str is None else f_str.to(dev))
     assert torch.equal(ops.patch_im2col(xh.to(dev), tok_dev, dtype, **kw),
                        ops.patch_im2col(xh.float().to(dev), tok_dev, dtype, **kw)), "fp16 input path differs from x.float()"
-    ref = F.unfold(xm.unsqueeze(1), kernel_size=16, stride=10)          # [B, 256, Fp*Tp]
+    ref = F.unfold(xm.unsqueeze(1), kernel_size=16, stride=stride)      # [B, 256, Fp*Tp]
     ref = ref.reshape(B, 256, Fp, Tp)
     if keep is not None:
         ref = ref[:, :, :, torch.from_numpy(keep).long()]
     ref = ref.permute(0, 2, 3, 1).reshape(B * Fp * Tk, 256)
     close(cols, ref.to(dtype), 0, 1e-6 if dtype == torch.float32 else 0, "im2col")
     # token assembly vs oracle.tokens_from_patches
-    Tt = 62 if T <= 640 else T // 10
+    Tt = (62 if T <= 640 else T // 10) if stride[1] == 10 else Tp + 1
     sd = {"cls_token": rnd((1, 1, 768), 40, .02), "dist_token": rnd((1, 1, 768), 41, .02),
           "new_pos_embed": rnd((1, 2, 768), 42, .02), "freq_new_pos_embed": rnd((1, 768, Fp, 1), 43, .02),
           "time_new_pos_embed": rnd((1, 768, 1, Tt), 44, .02)}

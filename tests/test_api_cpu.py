@@ -359,3 +359,23 @@ def test_run_ahead_bound_is_host_logic():
     eng.run_ahead = 1
     eng.throttle()
     assert waited == [0, 1, 2, 3, 4, 5, 6] and len(eng._inflight) == 0
+
+
+def test_patch_strides_are_constructor_arguments_like_in_the_reference():
+    """get_maest(stride_f=, stride_t=) (models/maest.py:1505-1507, 1537) warns and builds the tables of PatchEmbed.grid_size = img // stride
+    (models/maest.py:234); a stride whose frequency table does not match the (F - 16) // stride + 1 patch rows fails in the forward with the
+    error the reference raises from `x + self.freq_new_pos_embed` (class and message recorded from the reference: g12_patch_stride.npz) --
+    before any device work, so the contract is checked here on CPU tensors."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_patch_stride.npz"))
+    with pytest.warns(UserWarning):
+        m = get_maest("discogs-maest-10s-pw-129e", pretrained=False, stride_f=16, stride_t=13)
+    assert tuple(m.freq_new_pos_embed.shape) == (1, 768, 6, 1) and tuple(m.time_new_pos_embed.shape) == (1, 768, 1, 48)
+    assert m.patch_embed.proj.stride == (16, 13)
+    with pytest.warns(UserWarning):
+        bad = get_maest("discogs-maest-10s-pw-129e", pretrained=False, stride_f=8, stride_t=10).eval()
+    assert str(g["bad_stride_error_type"]) == "RuntimeError"
+    with pytest.raises(RuntimeError) as e:
+        bad(torch.zeros(2, 96, 626))
+    assert str(e.value) == str(g["bad_stride_error_message"])

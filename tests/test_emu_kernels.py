@@ -157,6 +157,7 @@ def test_emu_patch_embed(emu, dtype):
 
 def test_emu_patch_embed_eval(emu):
     KC.case_patch_embed(emu, torch.float32, 1, 56)
+    KC.case_patch_embed(emu, torch.float32, 2, 70, patchout=1, mix=True, masked=True, stride=(16, 13), seed=35)      # another patch stride
 
 
 @pytest.mark.parametrize("mix", [False, True])

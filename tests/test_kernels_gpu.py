@@ -191,6 +191,7 @@ def test_attention_rescale_branch():
 def test_patch_embed(dtype):
     KC.case_patch_embed(DEV, dtype, 3, 626, patchout=30, mix=True)
     KC.case_patch_embed(DEV, dtype, 2, 625)
+    KC.case_patch_embed(DEV, dtype, 3, 626, patchout=5, mix=True, masked=True, stride=(16, 13), seed=36)      # another patch stride
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -451,6 +451,48 @@ def test_large_eval_batches_on_two_streams_equal_the_single_stream_forward(preci
         assert torch.equal(small, upd[:3])
 
 
+@pytest.mark.parametrize("precision", EVAL_MODES + ["bf16"])
+def test_g12_another_patch_stride_matches_the_reference_fixture(precision):
+    """get_maest(stride_f=16, stride_t=13) (the reference takes the patch strides as constructor arguments, models/maest.py:1505-1507):
+    evaluation forward, and a training forward with structured patchout whose draws (time-table offset, kept columns) come out of the same
+    torch seed as the reference's; then loss and gradients of a training step against the oracle's autograd at that stride."""
+    g = np.load(os.path.join(GOLD, "g12_patch_stride.npz"))
+    stride = tuple(int(v) for v in g["stride"])
+    tol = 1e-3 if precision != "bf16" else 3e-2
+    sd = O.make_state_dict(625, stride=stride)
+
+    def make(**kw):
+        with pytest.warns(UserWarning):
+            m = get_maest("discogs-maest-10s-pw-129e", pretrained=False, stride_f=stride[0], stride_t=stride[1], precision=precision, **kw)
+        m.load_state_dict(sd, strict=True)
+        return m.to(DEV)
+    m = make().eval()
+    with torch.no_grad():
+        logits, feats = m(randn((2, 96, 626), 71).to(DEV))
+    assert rel_err(logits, g["logits"]) < tol and rel_err(feats, g["features"]) < tol
+    mt = make(s_patchout_t=7).train()
+    xs = randn((2, 96, 500), 72).to(DEV)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        lt, ft = mt(xs.clone())
+    assert rel_err(lt, g["train_logits"]) < tol and rel_err(ft, g["train_features"]) < tol
+    if precision != "fp32":
+        return
+    # one training step's loss and gradients (draws pinned) against the oracle's autograd
+    y = (randn((2, 400), 73) > 1.5).float()
+    pin = (int(g["toffset"]), torch.from_numpy(g["t_keep"]))
+    lg, _ = mt(xs.clone(), _patchout=pin)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(lg, y.to(DEV))
+    loss.backward()
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lo, _ = O.training_loss(xs.cpu().unsqueeze(1), y, sdo, toffset=pin[0], t_keep=pin[1].tolist(), stride=stride)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-5
+    for name in ("patch_embed.proj.weight", "freq_new_pos_embed", "time_new_pos_embed", "blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight"):
+        got = dict(mt.named_parameters())[name].grad
+        assert rel_err(got, sdo[name].grad) < 2e-3, name
+
+
 def test_hip_graph_captured_inference_is_bit_identical():
     """north_star configs[4]: the eval forward replayed from a HIP graph equals the eager launches bit for bit,
     for successive inputs, and is re-captured after a parameter update."""

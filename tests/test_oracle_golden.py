@@ -48,6 +48,19 @@ def test_g4_train_forward_with_captured_draws():
         assert len(g[f"t_keep_{T}"]) == (T - 16) // 10 + 1 - 30
 
 
+def test_g12_another_patch_stride_matches_reference_fixture():
+    """The patch strides are constructor arguments of the reference (get_maest(stride_f=, stride_t=)): (16, 13), evaluation forward and a
+    training forward with the reference's own draws (oracle/gen_golden_stride.py)."""
+    g = np.load(os.path.join(GOLD, "g12_patch_stride.npz"))
+    stride = tuple(int(v) for v in g["stride"])
+    sd = O.make_state_dict(625, stride=stride)
+    with torch.no_grad():
+        logits, feats = O.forward(randn((2, 96, 626), 71), sd, (96, 625), stride=stride)
+        lt, _ = O.forward(randn((2, 96, 500), 72), sd, (96, 625), toffset=int(g["toffset"]), t_keep=g["t_keep"].tolist(), stride=stride)
+    assert maxdiff(logits, g["logits"]) < 2e-5 and maxdiff(feats, g["features"]) < 2e-5
+    assert maxdiff(lt, g["train_logits"]) < 2e-5
+
+
 def test_g5_training_step_loss_and_grad_probes():
     g = np.load(os.path.join(GOLD, "g5_train_step.npz"))
     sd = {k: v.requires_grad_(True) for k, v in O.make_state_dict(625).items()}
