@@ -18,6 +18,11 @@ Pinning status
   algorithm (``torch.stft`` center/reflect, periodic Hann, ``melscale_fbanks`` with
   slaney scale + slaney norm); the only things the reference's own tests pin for this
   path are frame counts / shapes (``tests/test_maest.py:25-43``), which are checked.
+  Cross-check (not a pin: it is not torchaudio): the filter bank, the log-mel of a waveform and the
+  kaldi banks of ``augment_mel`` agree with ``transformers.audio_utils`` -- an independent implementation
+  of the same published definitions that this image holds -- to 1e-9 / 8e-7 / 2e-5
+  (``tests/test_oracle_golden.py::test_mel_restatements_agree_with_an_independent_implementation``).
+* Patch strides other than (10, 10): PINNED at (16, 13) (``oracle/gen_golden_stride.py``, fixture g12).
 
 Every function cites the reference lines it follows (paths relative to /root/reference).
 """

@@ -100,3 +100,27 @@ def test_oracle_exception_contract():
         O.forward(torch.randn(1, 96, 700), sd, (96, 625))      # 69 patch columns > 62-entry time table
     with pytest.raises(AssertionError):
         O.forward(np.zeros((96, 625)), sd, (96, 625))
+
+
+def test_mel_restatements_agree_with_an_independent_implementation():
+    """torchaudio is absent from this image, so the mel front end (a1) and the kaldi mel banks of AugmentMelSTFT (f3) are
+    RESTATEMENTS of torchaudio's published algorithms -- "parity unpinned" against torchaudio's own bits.  What can be checked here: a second,
+    independently written implementation of the same published definitions that the image does hold, transformers.audio_utils (Slaney mel
+    scale + Slaney area norm, periodic Hann, centred reflect-padded STFT; kaldi mel scale triangularised in mel space)."""
+    au = pytest.importorskip("transformers.audio_utils")
+    fb = au.mel_filter_bank(num_frequency_bins=257, num_mel_filters=96, min_frequency=0.0, max_frequency=8000.0, sampling_rate=16000,
+                            norm="slaney", mel_scale="slaney")
+    mine = O.mel_filterbank()
+    assert fb.shape == mine.shape == (257, 96) and np.abs(fb - mine).max() < 1e-7 * 32      # (peak weight 0.032; fp32 rounding of the table)
+    rng = np.random.Generator(np.random.PCG64(3))
+    wave = (rng.standard_normal(16000 * 3) * 0.1).astype(np.float32)
+    mel = au.spectrogram(wave.astype(np.float64), window=au.window_function(512, "hann", periodic=True), frame_length=512, hop_length=256,
+                         fft_length=512, power=2.0, center=True, pad_mode="reflect", mel_filters=fb, mel_floor=0.0, dtype=np.float64)
+    want = (np.log10(1 + mel * 10000) - O.NORM_MEAN) / (O.NORM_STD * 2)
+    got = O.logmel(torch.from_numpy(wave)).numpy()
+    assert got.shape == want.shape == (96, 1 + wave.size // 256) and np.abs(got - want).max() < 1e-5
+    for lo, hi in ((0.0, 16000.0), (20.0, 15000.0), (5.0, 14231.0), (0.0, 15500.0)):          # AugmentMelSTFT's jittered band edges
+        kb = au.mel_filter_bank(num_frequency_bins=513, num_mel_filters=128, min_frequency=lo, max_frequency=hi, sampling_rate=32000,
+                                norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+        k = O.kaldi_mel_banks(128, 1024, 32000, lo, hi).numpy()
+        assert np.abs(kb.T[:, :512] - k).max() < 5e-5 and np.abs(kb.T[:, 512]).max() == 0.0   # (the oracle forms the mel points in fp32)
