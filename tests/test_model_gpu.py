@@ -493,6 +493,21 @@ def test_g12_another_patch_stride_matches_the_reference_fixture(precision):
         assert rel_err(got, sdo[name].grad) < 2e-3, name
 
 
+def test_engine_streams_are_one_set_per_device_and_avoid_the_default_streams_queue():
+    """maest.py: _engine_stream -- every engine of a device shares ONE weight-gradient / exchange / second-evaluation stream, and none of
+    them is a pool entry that sits on the default stream's hardware queue (index >= 4, index % 4 == 2 under this runtime: the narrow wgrad
+    launches of a model that drew one ran serialized behind the dgrad chain, +12 % on its step: profiles/r06_stream_identity.txt)."""
+    from maest_amd import maest as M
+    dev = torch.device(DEV)
+    bad = lambda s: (int(s.stream_id) >> 5) >= 4 and (int(s.stream_id) >> 5) % 4 == 2
+    three = [M._engine_stream(dev, r) for r in ("side", "comm", "eval")]
+    assert len({int(s.stream_id) for s in three}) == 3 and not any(bad(s) for s in three)
+    a, b = build("discogs-maest-10s-pw-129e", 625), build("discogs-maest-10s-pw-129e", 625)
+    assert a._engine._side_stream(dev) is b._engine._side_stream(dev) is three[0]
+    assert a._engine._eval_stream(dev) is three[2] and a._engine._comm_stream(dev) is three[1]
+    assert not any(bad(M._pool_stream(dev)) for _ in range(40))       # (more draws than the pool has entries: the bad ones come up and are passed over)
+
+
 def test_hip_graph_captured_inference_is_bit_identical():
     """north_star configs[4]: the eval forward replayed from a HIP graph equals the eager launches bit for bit,
     for successive inputs, and is re-captured after a parameter update."""
