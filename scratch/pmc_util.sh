@@ -23,7 +23,7 @@ for f in glob.glob(O + "/pmc_util_*/**/p_counter_collection.csv", recursive=True
 out = {"_units": "per-launch averages over `launches` launches of scratch/kern_mix.py (B = 256, N = 290, bf16, random data). "
                  "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the fraction of SIMD cycles, at "
                  "the clock the kernel actually ran at, in which the matrix pipe was busy (SQ_VALU_MFMA_BUSY_CYCLES = 32 x "
-                 "SQ_INSTS_MFMA for 32x32x16 bf16; GRBM_GUI_ACTIVE is summed over the 8 XCDs).  *_frac_of_wave_cycles: SQ "
+                 "SQ_INSTS_MFMA for 32x32x16 bf16, 16 x for the 16x16x32 form gemm_nt256o_kernel uses since round 6; GRBM_GUI_ACTIVE is summed over the 8 XCDs).  *_frac_of_wave_cycles: SQ "
                  "wave-state counters over SQ_WAVE_CYCLES (quad-cycles).  lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."}
 for k, cs in agg.items():
     if not any(s in k for s in ("gemm", "attn", "layernorm")): continue
