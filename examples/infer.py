@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--arch", default="discogs-maest-30s-pw-129e")
     ap.add_argument("--seconds", type=float, default=35.0)
     ap.add_argument("--checkpoint", default=None, help="Lightning .ckpt with net_swa.* / net.* weights")
-    ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "bf16"])
+    ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "bf16", "bf16x3", "fp16"])
     args = ap.parse_args()
 
     model = get_maest(args.arch, pretrained=False, checkpoint=args.checkpoint, precision=args.precision).cuda().eval()
