@@ -284,14 +284,22 @@ def build_case(args, dev, rank, world, mode, T, B, patchout, reducer_kw=None):
             net._grad_sink = reducer
         batch = (x, None, y, y_teacher) if ts else (x, None, y)
 
+        # precision="fp16": the loop the reference's trainer runs under 16-mixed (ex_maest.py:51) -- torch.amp.GradScaler around the optimizer:
+        # scaled loss, gradients unscaled and checked for inf / nan (one host read per step), the step skipped and the scale halved on overflow
+        scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 14) if args.precision == "fp16" else None
+
         def step(xin=None):
             if reducer is not None:
                 reducer.reset()
             loss = mod.training_step(batch if xin is None else (xin,) + tuple(batch[1:]), 0)
-            loss.backward()
+            (loss if scaler is None else scaler.scale(loss)).backward()
             if reducer is not None:
                 reducer.finish()
-            opt.step()
+            if scaler is None:
+                opt.step()
+            else:
+                scaler.step(opt)
+                scaler.update()
             if reducer is None:      # (with a reducer the gradients are views of its flat buffer, zeroed by reset())
                 opt.zero_grad(set_to_none=True)
             return loss
@@ -635,7 +643,8 @@ def main():
     ap.add_argument("--patchout", type=int, default=None)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "fp16"],
                     help="bf16: perf mode (the headline number); fp32: exact-fp32 MFMA parity mode; bf16x3: split-bf16 parity mode; "
-                         "fp16: the perf mode's kernels on IEEE-half operands (evaluation forwards only: --mode infer)")
+                         "fp16: the perf mode's kernels on IEEE-half operands (the reference's 16-mixed arithmetic; training steps run "
+                         "under torch.amp.GradScaler)")
     ap.add_argument("--mode", default="train", choices=["train", "infer", "ts"],
                     help="train: BASELINE configs[2] (the headline metric); infer: configs[1]; ts: configs[4] "
                          "(teacher-student, waveform -> HIP log-mel on the fly -> mixup -> 519-way separated heads, 30 s)")
@@ -813,6 +822,13 @@ def main():
                                               precision="fp16")
             except Exception as e:  # pragma: no cover
                 out["infer_fp16"] = {"error": repr(e)}
+            try:
+                out["train_fp16"] = side_case(args, dev, "train", 626, 256, 30, 10, 3,
+                                              "the headline configuration (BASELINE configs[2]) in precision \"fp16\": graph recorded and differentiated on "
+                                              "IEEE-half operands -- the reference's own GPU arithmetic (16-mixed, ex_maest.py:51) -- with torch.amp.GradScaler "
+                                              "around AdamW as its trainer does (one host read of the inf / nan flag per step)", precision="fp16")
+            except Exception as e:  # pragma: no cover
+                out["train_fp16"] = {"error": repr(e)}
             try:
                 out["ts"] = side_case(args, dev, "ts", 1876, 128, 90, 10, 6,
                                       "discogs-maest-30s-pw-73e-ts teacher-student training step (BASELINE configs[4], per-GPU "

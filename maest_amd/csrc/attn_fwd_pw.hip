@@ -443,7 +443,7 @@ __device__ __forceinline__ void pw_pv_products(PwCtx& c) { pw_pv_all<I, BUF, TIL
 // ones: one instruction per slice instead of two adds.
 __device__ __forceinline__ void pw_sum_begin(PwCtx& c) {
 #if PW_DEV
-    if constexpr (PW_SUM == 1) asm volatile("v_mov_b32 v%c0, 0\n\tv_mov_b32 v%c1, 0x3f803f80" : : "i"(PW_V_T + 2), "i"(PW_V_T + 3));
+    if constexpr (PW_SUM == 1) asm volatile("v_mov_b32 v%c0, 0\n\tv_mov_b32 v%c1, " MAEST_ONE16X2_STR : : "i"(PW_V_T + 2), "i"(PW_V_T + 3));
     else asm volatile("v_mov_b32 v%c0, 0\n\tv_mov_b32 v%c1, 0" : : "i"(PW_V_T + 2), "i"(PW_V_T + 3));
 #else
     c.a0 = 0.0f;

@@ -16,16 +16,20 @@ typedef uint16_t bf16_t;  // raw 16-bit operand bits; all conversions are explic
 // (dtype code MAEST_BF16, `bf16_t` here) is bfloat16 -- the training mode --, and libmaest_hip_f16.so (-DMAEST_16BIT_F16), in which the same code
 // paths run on IEEE half: v_mfma_*_f16, v_cvt_pk_f16_f32, the same layouts and schedules.  fp16 has 11 significand bits against 8: logits
 // 6e-4 .. 8e-4 from fp32 where bf16 is at 5e-3 .. 8e-3 (scratch/fp16_operand_sim.py, confirmed on the GPU), i.e. INSIDE north_star's 1e-3, at the
-// bf16 kernels' speed -- and it is the reference's own GPU arithmetic (precision="16-mixed", ex_maest.py:51).  Evaluation forwards only
-// (precision="fp16"): gradients in half need loss scaling, the training path stays bf16.  Everything that interprets the 16 bits goes through
+// bf16 kernels' speed -- and it is the reference's own GPU arithmetic (precision="16-mixed", ex_maest.py:51).  precision="fp16": evaluation
+// forwards, and training steps under a scaled loss (gradients in half underflow without one).  Everything that interprets the 16 bits goes through
 // the few definitions below (and MAEST_T16 in the asm mnemonics of gemm_nt_ow.h / attn_fwd_pw.hip).
 #ifdef MAEST_16BIT_F16
 #define MAEST_T16 "f16"
+#define MAEST_ONE16X2 0x3c003c00u          // two 16-bit ones (colsum / row-sum operands)
+#define MAEST_ONE16X2_STR "0x3c003c00"
 typedef _Float16 native16_t;
 #define MAEST_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_f16
 #define MAEST_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_f16
 #else
 #define MAEST_T16 "bf16"
+#define MAEST_ONE16X2 0x3f803f80u
+#define MAEST_ONE16X2_STR "0x3f803f80"
 typedef __bf16 native16_t;
 #define MAEST_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
 #define MAEST_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_bf16

@@ -389,7 +389,7 @@ __device__ __forceinline__ chunk16 ones_chunk();
 template <>
 __device__ __forceinline__ chunk16 ones_chunk<bf16_t>() {
     chunk16 c;
-    c[0] = 0x3f803f80u; c[1] = 0x3f803f80u; c[2] = 0x3f803f80u; c[3] = 0x3f803f80u;
+    c[0] = MAEST_ONE16X2; c[1] = MAEST_ONE16X2; c[2] = MAEST_ONE16X2; c[3] = MAEST_ONE16X2;
     return c;
 }
 template <>

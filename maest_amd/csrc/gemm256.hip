@@ -500,8 +500,8 @@ __global__ __launch_bounds__(512) void gemm_nt256w_kernel(Gemm256Params p) {
     chunk16 fa[2][MTW], fb[2][2];
 #ifdef MAEST_ABLATE_NO_DSREAD
     for (int i = 0; i < 2; ++i) {
-        for (int j = 0; j < MTW; ++j) fa[i][j] = chunk16{0x3f803f80u + (uint32_t)lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-        for (int j = 0; j < 2; ++j) fb[i][j] = chunk16{0x3f803f80u, 0x3f803f80u + (uint32_t)lane, 0x3f803f80u, 0x3f803f80u};
+        for (int j = 0; j < MTW; ++j) fa[i][j] = chunk16{MAEST_ONE16X2 + (uint32_t)lane, MAEST_ONE16X2, MAEST_ONE16X2, MAEST_ONE16X2};
+        for (int j = 0; j < 2; ++j) fb[i][j] = chunk16{MAEST_ONE16X2, MAEST_ONE16X2 + (uint32_t)lane, MAEST_ONE16X2, MAEST_ONE16X2};
     }
 #endif
     auto load_frags = [&](int abuf, int bbuf, int kh) {

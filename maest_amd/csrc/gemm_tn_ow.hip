@@ -189,7 +189,7 @@ __device__ __forceinline__ void tw_colsum_init(TwCtx& c) {
                  "i"(TW_V_CS + 2), "i"(TW_V_CS + 3));
     asm volatile("v_mov_b32 v%c0, 0\n\tv_mov_b32 v%c1, 0\n\tv_mov_b32 v%c2, 0\n\tv_mov_b32 v%c3, 0" : : "i"(TW_V_CS + 4), "i"(TW_V_CS + 5),
                  "i"(TW_V_CS + 6), "i"(TW_V_CS + 7));
-    asm volatile("v_mov_b32 v%c0, 0x3f803f80" : : "i"(TW_V_ONE));
+    asm volatile("v_mov_b32 v%c0, " MAEST_ONE16X2_STR : : "i"(TW_V_ONE));
 #else
     for (int blk = 0; blk < 2; ++blk)
         for (int e = 0; e < 4; ++e) c.cs[blk][e] = 0.0f;

@@ -23,9 +23,10 @@ Numeric modes (``model.precision``):
   "bf16x3" fast parity mode: fp32 tensors everywhere, the linear layers and the attention forward as three bf16
           MFMAs on hi/lo splits of the fp32 operands (SURVEY H1 "split-bf16"): meets the same 1e-3 gate as "fp32"
           at 2-2.5x its speed (forward and backward; small / ragged GEMMs stay exact fp32);
-  "fp16"  fast parity mode for EVALUATION (round 6): the "bf16" kernels' schedules with IEEE-half operands (v_mfma_*_f16; the library's second
+  "fp16"  fast parity mode (round 6): the "bf16" kernels' schedules with IEEE-half operands (v_mfma_*_f16; the library's second
           build, libmaest_hip_f16.so) -- the reference's own GPU arithmetic (16-mixed autocast) --: logits 6e-4 .. 8e-4 from fp32, inside the
-          1e-3 gate, at the bf16 mode's speed.  Forwards that record a graph raise (gradients in half need loss scaling: train in bf16);
+          1e-3 gate, at the bf16 mode's speed.  A train() forward records and differentiates in half too (gradients 8 x closer to fp32 than
+          bf16's) and, as under autocast, wants a SCALED loss (torch.amp.GradScaler); eval() forwards never record;
   "auto"  (default) bf16 for a training forward that records a graph; every other forward -- eval(), no_grad,
           predict_labels -- runs "bf16x3" (the reference computes inference in fp32; the split products meet the
           same 1e-3 / identical-ranking gates at twice the speed of the exact ones; precision="fp32" selects those).
@@ -408,7 +409,7 @@ class _Engine:
         P = int(tok_ft.shape[0])
         N = 2 + P
         M = B * N
-        ctx = {"B": B, "N": N, "toffset": toffset, "tok_ft": tok_ft, "dt": dt, "x3m": x3m} if save else None
+        ctx = {"B": B, "N": N, "toffset": toffset, "tok_ft": tok_ft, "dt": dt, "x3m": x3m, "f16": bool(f16)} if save else None
         # Operand copies are keyed on the parameters' version counters, but FUSED optimizers (torch.optim.AdamW(...,
         # fused=True), multi-tensor kernels in general) update parameters in place WITHOUT bumping them -- a stale
         # bf16 copy then keeps training on the initial weights.  So every training-mode forward recasts everything
@@ -556,8 +557,13 @@ class _Engine:
 
     # ---- backward ---------------------------------------------------------------------------
     def backward(self, ctx, grads_out, sink=None):
-        with self._gemm_form(shared=sink is not None, wgs=self.bwd_gemm_wgs):
-            G = self._backward(ctx, grads_out, sink)
+        if ctx.get("f16"):     # recorded by libmaest_hip_f16.so: its 16-bit tensors are IEEE half, the backward is that build's too (this thread's calls)
+            from . import _lib as _L
+            with _L.flavour("f16"), self._gemm_form(shared=sink is not None, wgs=self.bwd_gemm_wgs):
+                G = self._backward(ctx, grads_out, sink)
+        else:
+            with self._gemm_form(shared=sink is not None, wgs=self.bwd_gemm_wgs):
+                G = self._backward(ctx, grads_out, sink)
         self._step_done(ctx["x_final"].device)
         return G
 
@@ -566,7 +572,7 @@ class _Engine:
         Returns {parameter name: fp32 gradient}.  With a `sink` (maest_amd.dist.GradReducer) every
         gradient is written straight into the sink's flat bucket view and reported as soon as it is
         complete, so the RCCL all-reduce of a bucket overlaps with the rest of the backward."""
-        m, W = self.m, self.w
+        m, W = self.m, (self.w_f16 if ctx.get("f16") else self.w)
         x3m = ctx["x3m"]
         qs = ctx["qs"]
         gemm_nt = partial(ops.gemm_nt, x3=x3m)
@@ -758,7 +764,7 @@ class _MaestFn(torch.autograd.Function):
         ctx.graph_lease = None
         if x3.is_cuda:
             model._engine.throttle()
-        if model.hip_graph and x3.is_cuda:
+        if model.hip_graph and x3.is_cuda and not kw.get("f16"):      # (the captured training forward exists for the bf16 build only)
             outs, saved, ctx.graph_lease = model._graph_train_forward(x3, dt, kw)
         else:
             outs, saved = model._engine.forward(x3, dt, save=True, **kw)
@@ -921,10 +927,9 @@ class MAEST(nn.Module):
         if p in ("fp16", "float16", "half"):
             # IEEE half operands: the bf16 kernels' schedules on v_mfma_*_f16 (libmaest_hip_f16.so: the same sources, csrc/common.h
             # MAEST_16BIT_F16) -- the reference's own GPU arithmetic (16-mixed autocast, ex_maest.py:51), 6e-4 .. 8e-4 from fp32 where bf16 is at
-            # 5e-3 .. 8e-3, at the bf16 mode's speed.  Evaluation only: gradients in half need loss scaling, training stays bf16.
-            if recording:
-                raise NotImplementedError('precision="fp16" serves forwards that record no graph (eval() / no_grad / predict_labels); '
-                                          'train in "bf16" (or "auto", which does)')
+            # 5e-3 .. 8e-3, at the bf16 mode's speed.  A train() forward records the graph in half as well, like the reference's autocast:
+            # gradients in half underflow without LOSS SCALING (torch.amp.GradScaler, which the reference's trainer applies under 16-mixed;
+            # Module.training_step leaves that to the loop as the reference's does) -- eval() forwards never record in this mode.
             return "fp16"
         raise ValueError(f"precision must be 'auto', 'fp32', 'bf16x3', 'bf16' or 'fp16', got {self.precision!r}")
 
@@ -1056,8 +1061,8 @@ class MAEST(nn.Module):
         need_grad = (transformer_block == -1 and torch.is_grad_enabled()
                      and any(p.requires_grad for p in self.parameters()))
         if need_grad and not self.training and self.precision in ("fp16", "float16", "half"):
-            need_grad = False     # precision="fp16" is an evaluation mode: eval() forwards record no graph even outside no_grad (a backward
-                                  # through them fails loudly on outputs that do not require grad); a train() forward raises, see _resolve_precision
+            need_grad = False     # precision="fp16": eval() forwards record no graph even outside no_grad (a backward through them fails loudly
+                                  # on outputs that do not require grad); a train() forward records in half and wants a scaled loss (_resolve_precision)
         dt = self._compute_dtype(need_grad)
 
         tok_key = (Fp, Tp, str(x3.device))

@@ -161,11 +161,9 @@ def test_g1_eval_fp16_meets_the_logits_gate_at_the_fast_kernels():
     assert rel_err(l30, g2["logits"]) < 1e-3 and rel_err(f30, g2["features"]) < 1e-3
     lc, fc = m30(randn((96, 3752), 10).to(DEV), melspectrogram_input=True)
     assert rel_err(lc, g2["chunk_logits"]) < 1e-3 and rel_err(fc, g2["chunk_features"]) < 1e-3
-    # training in half is refused (gradients would need loss scaling): the message says what to use
     assert not logits.requires_grad          # (an eval() forward in this mode records no graph, inside no_grad or not)
-    m.train()
-    with pytest.raises(NotImplementedError, match="bf16"):
-        m(x.clone())
+    m.train()                                # a train() forward records in half (test_g5_training_step_in_fp16_with_a_scaled_loss)
+    assert m(x.clone())[0].requires_grad
     with torch.no_grad():                    # (a train-mode forward that records nothing -- predict_labels on a fresh model -- is served)
         m(x.clone())
 
@@ -276,6 +274,57 @@ def test_g5_training_step_loss_and_gradients(precision, tol):
     assert rel_err(params["blocks.0.attn.qkv.weight"].grad[:16, :16], g["grad_qkv0"]) < tol * 5
     assert rel_err(params["patch_embed.proj.weight"].grad.reshape(768, 256)[:8], g["grad_patch"]) < tol * 5
     assert rel_err(params["time_new_pos_embed"].grad.reshape(768, 62)[:4], g["grad_tpe"]) < tol * 5
+
+
+def test_g5_training_step_in_fp16_with_a_scaled_loss():
+    """precision="fp16" on a train() forward: the graph is recorded by the half-precision build (the reference's own GPU arithmetic, 16-mixed
+    autocast, ex_maest.py:51) and differentiated by it; like under torch's autocast the LOSS MUST BE SCALED (gradients of a mean BCE are ~1e-6:
+    below half's normal range) -- here by 2^14, exactly undone afterwards.  Loss and every parameter gradient against the reference fixture
+    G5 at a fifth of the bf16 gate; then torch.amp.GradScaler drives two optimizer steps the way the reference's trainer does."""
+    g = np.load(os.path.join(GOLD, "g5_train_step.npz"))
+    net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision="fp16").train()
+    mod = Module(net=net, mixup_alpha=0.3)
+    x, y, mix, po = _g5_batch(g)
+    S = 2.0 ** 14
+    loss = mod.training_step((x, None, y), 0, _mixup=mix, _patchout=po)
+    assert loss.requires_grad
+    (loss * S).backward()
+    le = abs(loss.item() - float(g["loss"])) / float(g["loss"])
+    names = [n for n, _ in O.state_dict_spec(625, 400)]
+    params = dict(net.named_parameters())
+    worst = 0.0
+    tol = 1e-3       # (observed: 2.1e-4; the bf16 gate is 1e-2 for 1.9e-3)
+    for i, n in enumerate(names):
+        p = params[n]
+        if not g["grad_present"][i]:
+            continue
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+        gr = p.grad / S
+        gn, ref_n = float(gr.norm()), float(g["grad_norm"][i])
+        e = abs(gn - ref_n) / max(ref_n, 1e-12)
+        pe = (gr.flatten()[:8].cpu() - torch.from_numpy(g["grad_probe"][i])).abs().max().item()
+        scale = max(float(np.abs(g["grad_probe"][i]).max()), ref_n / np.sqrt(p.numel()))
+        worst = max(worst, e, pe / max(scale, 1e-12) * 0.1)
+        assert e < tol * 3, f"{n}: grad norm {gn:.4e} vs {ref_n:.4e}"
+        assert pe <= tol * 10 * scale + 1e-9, f"{n}: grad probe err {pe:.3e} (scale {scale:.3e})"
+    print(f"G5 fp16: loss rel {le:.2e}, worst relative gradient deviation {worst:.2e}")
+    assert le < 1e-4
+    assert rel_err(params["blocks.0.attn.qkv.weight"].grad[:16, :16] / S, g["grad_qkv0"]) < tol * 5
+    # the reference's loop: GradScaler around the optimizer (Lightning's 16-mixed plugin)
+    opt = mod.get_optimizer(net.parameters())
+    opt.zero_grad(set_to_none=True)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 14)
+    before = net.blocks[3].mlp.fc1.weight.detach().clone()
+    l0 = None
+    for _ in range(2):
+        l = mod.training_step((x, None, y), 0, _mixup=mix, _patchout=po)
+        scaler.scale(l).backward()
+        scaler.step(opt)
+        scaler.update()
+        opt.zero_grad(set_to_none=True)
+        l0 = l.item() if l0 is None else l0
+    assert scaler.get_scale() == 2.0 ** 14, "a step was skipped: non-finite gradients"
+    assert not torch.equal(net.blocks[3].mlp.fc1.weight, before) and l.item() < l0
 
 
 def test_g5_teacher_student_step_fp32():
