@@ -127,7 +127,7 @@ class _Weights:
 
     def __init__(self):
         self._cache = {}
-        self.seen_train = 0     # _Engine._train_forwards at the last clear()
+        self.seen_train = 0     # _Engine._train_forwards when an EVALUATION forward last filled the cache; -1: a training forward did (stale)
         self.epoch = 0          # bumped whenever every copy is dropped (part of the hipGraph cache key)
         self.builds = 0         # copies (re)built so far: a forward during which it moves found the cache cold (MAEST._eval_forward)
         # {id(parameter): rows}: parameters whose PLAIN low-precision copy carries `row_scale` on its first `rows` rows (the q rows of
@@ -418,7 +418,11 @@ class _Engine:
             self._train_forwards += 1
         if save or W.seen_train != self._train_forwards:
             W.clear()
-            W.seen_train = self._train_forwards
+            # a cache a TRAINING forward fills is stale for every later forward (the optimizer steps behind it): -1 matches no count, so the
+            # first forward after it -- evaluation or training -- recasts; a cache an evaluation forward fills serves until the next training one.
+            # (Round 6 first stored the count here in both cases: an evaluation forward behind a fused-optimizer step then ran on the weights of
+            # one step earlier -- bench.py's training cases showed it as deviation_vs_fp32 1e-2 instead of 2e-3.)
+            W.seen_train = -1 if save else self._train_forwards
         self._weights_dirty = bool(save)
         mats = [lin.weight for blk in m.blocks for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)]
         mats += [m.patch_embed.proj.weight, m.head[1].weight]

@@ -557,6 +557,45 @@ def test_engine_streams_are_one_set_per_device_and_avoid_the_default_streams_que
     assert not any(bad(M._pool_stream(dev)) for _ in range(40))       # (more draws than the pool has entries: the bad ones come up and are passed over)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "auto"])
+def test_evaluation_after_a_fused_optimizer_step_sees_the_updated_weights(precision):
+    """The operand copies of the weights are cached; fused optimizers (Module.get_optimizer: AdamW(fused=True)) update parameters in place
+    WITHOUT moving their version counters, so a cache filled by a training forward must not serve the evaluation forward behind the step.
+    (Round 6 had broken exactly that for one step: the bench's deviation_vs_fp32 of the training cases read 1e-2 instead of 2e-3.)
+    Evaluation right after two optimizer steps, eager and through a captured graph, equals a FRESH model holding the same state_dict."""
+    net = build("passt_s_swa_p16_128_ap476", 625, input_t=625, s_patchout_t=30, precision=precision).train()
+    mod = Module(net=net, mixup_alpha=0.3)
+    opt = mod.get_optimizer(net.parameters(), )
+    for g_ in opt.param_groups:
+        g_["lr"] = 1e-3          # (a visible update)
+    x = randn((4, 1, 96, 625), 21).to(DEV)
+    y = (randn((4, 400), 22) > 1.5).float().to(DEV)
+    k = 2.0 ** 14 if precision == "fp16" else 1.0
+    with torch.no_grad():
+        net.eval(); before = net(x)[0].clone(); net.train()          # (fills the evaluation cache before any step)
+    for _ in range(2):
+        loss = mod.training_step((x, None, y), 0)
+        (loss * k).backward()
+        if k != 1.0:
+            for p in net.parameters():
+                if p.grad is not None:
+                    p.grad.div_(k)
+        opt.step(); opt.zero_grad(set_to_none=True)
+    net.eval()
+    with torch.no_grad():
+        after = net(x)[0].clone()
+        net.enable_hip_graph()
+        g1 = net(x)[0].clone(); g2 = net(x)[0].clone(); g3 = net(x)[0].clone()
+        net.enable_hip_graph(False)
+    fresh = get_maest("passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30, precision=precision)
+    fresh.load_state_dict(net.state_dict(), strict=True)
+    fresh = fresh.to(DEV).eval()
+    with torch.no_grad():
+        want = fresh(x)[0]
+    assert not torch.equal(before, after)
+    assert torch.equal(after, want) and torch.equal(g1, want) and torch.equal(g2, want) and torch.equal(g3, want)
+
+
 def test_hip_graph_captured_inference_is_bit_identical():
     """north_star configs[4]: the eval forward replayed from a HIP graph equals the eager launches bit for bit,
     for successive inputs, and is re-captured after a parameter update."""
