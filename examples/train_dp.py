@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per GPU")
     ap.add_argument("--no-spec-masking", action="store_true")
     ap.add_argument("--hip-graph", action="store_true", help="replay the training forward from a captured HIP graph")
+    ap.add_argument("--precision", default="auto", choices=["auto", "bf16", "fp16", "fp32"],
+                    help="fp16: the reference's 16-mixed arithmetic (IEEE-half operands) -- the loop then runs under torch.amp.GradScaler like its trainer")
     args = ap.parse_args()
     rank, local, world = init_from_env()
     torch.cuda.set_device(local)
@@ -60,6 +62,8 @@ def main():
 
     mod = Module(arch="passt_s_swa_p16_128_ap476", pretrained=False, input_t=625, s_patchout_t=30,
                  spec_masking=None if args.no_spec_masking else SpecMasking()).to(dev)
+    mod.net.precision = args.precision
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 14) if args.precision == "fp16" else None    # gradients in half need a scaled loss
     mod.net.train()
     if args.hip_graph:
         mod.net.enable_hip_graph()
@@ -80,10 +84,14 @@ def main():
         if reducer is not None:
             reducer.reset()
         loss = mod.training_step((x, None, y), step)
-        loss.backward()
+        (loss if scaler is None else scaler.scale(loss)).backward()
         if reducer is not None:
             reducer.finish()
-        opt.step()
+        if scaler is None:
+            opt.step()
+        else:
+            scaler.step(opt)               # unscales, skips the step on inf / nan
+            scaler.update()
         opt.zero_grad(set_to_none=reducer is None)
         if (step + 1) % 10 == 0:          # this toy run calls 10 steps an epoch
             sched.step()
