@@ -26,6 +26,8 @@ import sys
 import gc
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first HIP call: see maest_amd/__init__.py
+
 import numpy as np
 import torch
 
@@ -280,7 +282,7 @@ def build_case(args, dev, rank, world, mode, T, B, patchout, reducer_kw=None):
         if world > 1 or args.force_collective:
             skip = () if ts else ("head_dist.weight", "head_dist.bias")
             reducer = GradReducer(net.named_parameters(), skip=skip, force_collective=args.force_collective)
-            reducer.timing = True       # two event records per bucket: launch -> complete of every all-reduce, printed as `dp_buckets`
+            reducer.timing = os.environ.get("MAEST_DP_BUCKET_TIMING", "1") != "0"      # two event records per bucket: launch -> complete of every all-reduce, printed as `dp_buckets`
             net._grad_sink = reducer
         batch = (x, None, y, y_teacher) if ts else (x, None, y)
 

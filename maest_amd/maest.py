@@ -257,17 +257,22 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, n_out: int, k_out: int, out=None, 
 # step to exactly that (bench.py's 30 s training case behind three evaluation cases that had each taken a stream: 89.2 ms against 79.6,
 # profiles/r06_stream_identity.txt).  All three roles are created together, on first use, in a fixed order.
 # Measured per pool entry (scratch/r06_stream_identity.py: a 108-workgroup wgrad on pool stream k beside an NT GEMM on the default stream,
-# 503 + 281 us alone): 575 - 600 us together on entries 0 - 5, 7 - 9, 11; 755 - 786 us -- nearly serial -- on entries 6 and 10, the ones that
-# land on the default stream's hardware queue under this runtime (four queues, entries >= 4 dealt round robin).  Entries with
-# index >= 4 and index % 4 == 2 are therefore passed over (the index is the pool stream's id >> 5); a runtime that maps differently loses nothing.
+# 503 + 281 us alone).  With the runtime's default of four hardware queues: 575 - 600 us together on entries 0 - 5, 7 - 9, 11; 755 - 786 us --
+# nearly serial -- on entries 6 and 10, which land on the default stream's queue.  With GPU_MAX_HW_QUEUES = 8 (what maest_amd/__init__.py sets):
+# 585 - 600 us, and 662 - 677 us on entries 3 and 10.  Those entries are passed over (the index is the pool stream's id >> 5); with any other
+# queue count nothing is skipped, and a runtime that maps differently loses nothing.
 _ENGINE_STREAMS = {}
+
+
+def _on_default_queue(k: int) -> bool:
+    q = os.environ.get("GPU_MAX_HW_QUEUES", "4")
+    return (k >= 4 and k % 4 == 2) if q == "4" else (k % 7 == 3) if q == "8" else False
 
 
 def _pool_stream(dev):
     for _ in range(8):
         s = torch.cuda.Stream(device=dev)
-        k = int(s.stream_id) >> 5
-        if not (k >= 4 and k % 4 == 2):
+        if not _on_default_queue(int(s.stream_id) >> 5):
             break
     return s
 

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # the configuration the package runs in (maest_amd/__init__.py), set before any HIP call
+
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

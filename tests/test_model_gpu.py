@@ -544,11 +544,13 @@ def test_g12_another_patch_stride_matches_the_reference_fixture(precision):
 
 def test_engine_streams_are_one_set_per_device_and_avoid_the_default_streams_queue():
     """maest.py: _engine_stream -- every engine of a device shares ONE weight-gradient / exchange / second-evaluation stream, and none of
-    them is a pool entry that sits on the default stream's hardware queue (index >= 4, index % 4 == 2 under this runtime: the narrow wgrad
-    launches of a model that drew one ran serialized behind the dgrad chain, +12 % on its step: profiles/r06_stream_identity.txt)."""
+    them is a pool entry that sits on the default stream's hardware queue (with the package's eight hardware queues: index % 7 == 3; with the
+    runtime's default four: index >= 4, index % 4 == 2 -- the narrow wgrad launches of a model that drew one ran serialized behind the dgrad
+    chain, +12 % on its step: profiles/r06_stream_identity.txt, r06_hw_queues.txt)."""
     from maest_amd import maest as M
     dev = torch.device(DEV)
-    bad = lambda s: (int(s.stream_id) >> 5) >= 4 and (int(s.stream_id) >> 5) % 4 == 2
+    bad = lambda s: M._on_default_queue(int(s.stream_id) >> 5)
+    assert os.environ.get("GPU_MAX_HW_QUEUES") == "8" and M._on_default_queue(3) and M._on_default_queue(10) and not M._on_default_queue(6)
     three = [M._engine_stream(dev, r) for r in ("side", "comm", "eval")]
     assert len({int(s.stream_id) for s in three}) == 3 and not any(bad(s) for s in three)
     a, b = build("discogs-maest-10s-pw-129e", 625), build("discogs-maest-10s-pw-129e", 625)
